@@ -1,0 +1,59 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def has_gpu():
+    return torch.cuda.is_available()
+
+
+def load_golden(name):
+    """(meta, tensors) of a fixture written by tests/golden/make_golden.py."""
+    with open(os.path.join(GOLDEN, name + ".json")) as f:
+        meta = json.load(f)
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    tensors = {k: torch.from_numpy(np.asarray(z[k])) for k in z.files}
+    return meta, tensors
+
+
+def load_tiny_sd():
+    z = np.load(os.path.join(GOLDEN, "tiny_sd.npz"))
+    return {k: torch.from_numpy(np.asarray(z[k])).float() for k in z.files}
+
+
+def golden_param_dict(meta, tensors, which="adapter"):
+    """Backbone state-dict (tiny) + the fixture's adapter tensors."""
+    sd = load_tiny_sd()
+    for k, v in tensors.items():
+        if k.startswith(which + "/"):
+            sd[k[len(which) + 1:]] = v.float().clone()
+    return sd
+
+
+def rel_err(a, b):
+    a = a.double().flatten(); b = b.double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def max_rel(a, b):
+    a = a.double(); b = b.double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+@pytest.fixture(scope="session")
+def gpu_required():
+    if not has_gpu():
+        pytest.skip("no GPU")
