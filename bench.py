@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""Fine-tune throughput of CLIP ViT-B/32 + KAdaptation on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One process per GPU (the driver launches N>1 through torch.distributed.run); a "step" is one
+pass of the reference's train_one body (kadaptation_clip.py:347-353): zero_grad -> forward ->
+cross-entropy -> backward -> [all-reduce of the flat adapter-gradient buffer over RCCL] -> SGD,
+on a synthetic CIFAR100-shaped batch (B=128 per GPU, 3x224x224, C=100) that is resident in HBM
+before the timed region.  Weak scaling: every rank processes its own 128-image shard.
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md section "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# ---- algorithmic FLOPs per image of one training step (MAC x 2) --------------
+def train_gflop_per_image(E, L, P, R, D, C, rank, attention_site=True):
+    N = (R // P) ** 2 + 1
+    lin = 12 * E * E
+    attn = 2 * N * E
+    conv = (N - 1) * 3 * P * P * E
+    tail = E * D + D * C
+    tail_b = E * D + 2 * D * C
+    if attention_site:
+        a_f = 2 * (2 * E * rank)
+        fwd = 2 * (N * L * (lin + attn + a_f) + conv + tail)
+        bwd = 2 * (N * (L * lin - 3 * E * E) + 2 * N * L * attn + 2 * N * L * a_f + tail_b)
+    else:
+        a_f = 2 * E * 64
+        fwd = 2 * (N * L * (lin + attn + a_f) + conv + tail)
+        bwd = 2 * (N * (L - 1) * (lin + 2 * attn) + 2 * N * (L - 1) * a_f + N * a_f + tail_b)
+    return (fwd + bwd) / 1e9
+
+
+PEAK_TFLOPS_BF16 = 2500.0     # dense MFMA bf16, MI355X_MICROARCH.md
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """The oracle (op-for-op restatement of the reference algorithm, dense-H einsum) timed on the
+    host cores: BASELINE config 1 (ViT-B/32 + KAdaptation, fp32, bs=32), bounded sample."""
+    from oracle import ref_cpu
+    from pevit_amd.synth import ARCHS, synth_batch, synth_state_dict
+    # one intra-op thread per core is pathological on a 256-core host (measured 166 s/step);
+    # 16 threads is where the reference's eager fp32 step stops scaling.
+    cores = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    arch = ARCHS["ViT-B/32"]
+    sd = {k: v for k, v in synth_state_dict(arch, seed=2, text_tower=False).items() if k.startswith("visual.")}
+    sd.update(ref_cpu.init_adapter_params("kadaptation", arch.width, arch.layers))
+    tr = ref_cpu.OracleTrainer(sd, "kadaptation", 100, lr=0.01, wd=0.0)
+    bs = 32
+    images, labels = synth_batch(bs, 224, 100)
+    t0 = time.time(); tr.step(images, labels); warm = time.time() - t0        # warm-up
+    times = []
+    t_end = time.time() + seconds_budget
+    while len(times) < 10 and (time.time() < t_end or len(times) < 1):
+        t0 = time.time(); tr.step(images, labels); times.append(time.time() - t0)
+        if times[-1] > seconds_budget:
+            break
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": bs / med, "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} fine-tune steps of ViT-B/32+KAdaptation fp32 bs={bs} (BASELINE config 1), "
+                      f"median {med * 1e3:.0f} ms/step, torch {torch.__version__} CPU"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=128, help="images per GPU (BASELINE config 2: 128)")
+    ap.add_argument("--method", default="kadaptation")
+    ap.add_argument("--arch", default="ViT-B/32")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from pevit_amd.engine import HipEngine
+    from pevit_amd.synth import ARCHS, synth_batch, synth_state_dict
+    arch = ARCHS[args.arch]
+    classes = 100
+    sd = synth_state_dict(arch, seed=2, text_tower=False)
+    eng = HipEngine(arch, args.method, classes, args.batch, lora_rank=8 if args.method == "lora" else 4, device=dev)
+    eng.load_state_dict(sd)
+    # adapters at the reference initialisation; head ~ nn.Linear default
+    views = eng.param_views()
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for name, v in views.items():
+            if "phm_rule" in name:
+                v.copy_(((torch.rand(v.shape, generator=g) * 2 - 1) * 0.01).to(dev))
+            elif name.endswith("adapter1.weight"):
+                v.copy_((torch.randn(v.shape, generator=g) * 0.02).to(dev))
+        bound = arch.embed_dim ** -0.5
+        views["layers.0.weight"].copy_(((torch.rand(views["layers.0.weight"].shape, generator=g) * 2 - 1) * bound).to(dev))
+        views["layers.0.bias"].copy_(((torch.rand(views["layers.0.bias"].shape, generator=g) * 2 - 1) * bound).to(dev))
+    images, labels = synth_batch(args.batch, arch.resolution, classes, seed_img=rank * 2, seed_lbl=rank * 2 + 1)
+    images, labels = images.to(dev), labels.to(dev)
+
+    def step():
+        return eng.train_step(images, labels, lr=0.01, momentum=0.9, weight_decay=1e-6, world_size=world)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        logits, loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt)
+    final_loss = float(loss)
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = args.batch * world * args.steps / dt
+        site = args.method in ("kadaptation", "lora")
+        r = 32 if args.method == "kadaptation" else 8
+        gflop = train_gflop_per_image(arch.width, arch.layers, arch.patch, arch.resolution, arch.embed_dim, classes, r, site)
+        achieved = value / world * gflop / 1e3      # TFLOP/s per GPU
+        out = {
+            "metric": "images/sec fine-tune, CLIP ViT-B/32 + KAdaptation, bs=128, 1/2/4/8 GPU",
+            "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"CLIP {args.arch} + {args.method} fine-tune step (fwd+CE+bwd+SGD), "
+                                   f"{args.batch} images/GPU 3x{arch.resolution}x{arch.resolution}, C={classes}, "
+                                   f"synthetic OpenAI-layout checkpoint, adapters at reference init",
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                       "train_gflop_per_image": gflop, "final_loss": final_loss},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS_BF16, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_TFLOPS_BF16, "traffic": None,
+                         "note": "whole-step algorithmic FLOPs (SURVEY 8d formula) / wall step time, per GPU"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

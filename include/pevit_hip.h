@@ -1,0 +1,147 @@
+/* pevit_hip.h -- C ABI of the MI355X (gfx950) engine for parameter-efficient fine-tuning of
+ * CLIP vision transformers.
+ *
+ * The reference (eric-ai-lab/PEViT) has no FFI/plugin layer: its hot path sits behind plain
+ * PyTorch module methods.  This header declares the drop-in boundary for that path; every
+ * entry point names the reference interface it replaces (paths relative to
+ * vision_benchmark/evaluation/ of the reference):
+ *
+ *   pevit_transformer_forward / _backward   Transformer.forward            model.py:1013-1014
+ *                                           = 12 x ResidualAttentionBlock.forward  model.py:972-975
+ *                                           incl. MultiheadAttention.multi_head_attention_forward
+ *                                           (model.py:612-834) and adapter_forward (model.py:563-584;
+ *                                           lora_model.py:490-514), and their autograd backward
+ *   pevit_visual_forward / _backward        VisionTransformer.forward      model.py:1034-1051
+ *                                           (= CLIP.encode_image, model.py:1151-1152)
+ *   pevit_head_forward_backward             Classifier.forward tail + CrossEntropyLoss
+ *                                           kadaptation_clip.py:128-132,176-185,276,351-352
+ *   pevit_sgd_step                          optimizer.step()               kadaptation_clip.py:353,
+ *                                           optim/build.py:120-127
+ *   pevit_load_block / pevit_load_stem      build_model's load_state_dict  model.py:1247-1250
+ *
+ * Conventions: extern "C"; every function returns 0 on success and a negative value on error
+ * (pevit_last_error() gives the message); nothing throws; no allocation after
+ * pevit_ctx_create -- all device memory (weight arena, workspace, parameter and gradient
+ * buffers) is owned by the caller and only borrowed; all work is enqueued asynchronously on
+ * the caller's hipStream_t (passed as void*); a context is re-entrant across contexts but not
+ * thread-safe within one, matching the reference's single-threaded caller.
+ *
+ * Row order: the reference keeps activations sequence-first, (N, B, E).  Entry points with
+ * "_nbe" arguments take and return exactly that layout; internally rows are batch-major.
+ */
+#ifndef PEVIT_HIP_H
+#define PEVIT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pevit_ctx pevit_ctx;
+
+enum pevit_method {
+    PEVIT_KADAPTATION = 0, /* model.py          : Kronecker rank-32 delta on q and v + shared bias b */
+    PEVIT_LORA = 1,        /* lora_model.py     : low-rank A.B on q and v, scale alpha/r            */
+    PEVIT_ADAPTER = 2,     /* adapter_model.py  : bottleneck adapter after the MLP                  */
+    PEVIT_COMPACTER = 3,   /* compacter_model.py: PHM (n=4) bottleneck adapter after the MLP        */
+    PEVIT_NONE = 4         /* frozen tower, no adapter (linear probe)                               */
+};
+
+typedef struct pevit_dims {
+    int32_t width;       /* E: visual.conv1.weight.shape[0]                 (model.py:1214) */
+    int32_t layers;      /* L                                               (model.py:1215) */
+    int32_t patch;       /* P                                               (model.py:1216) */
+    int32_t resolution;  /* R = P * grid                                    (model.py:1218) */
+    int32_t out_dim;     /* D: visual.proj.shape[1]                                         */
+    int32_t method;      /* enum pevit_method                                               */
+    int32_t lora_rank;   /* r (reference hard-codes 4: lora_model.py:461)                   */
+    int32_t num_classes; /* C: DATASET.NUM_CLASSES          (kadaptation_clip.py:125)       */
+} pevit_dims;
+
+const char* pevit_last_error(void);
+int pevit_version(void);
+
+int pevit_ctx_create(const pevit_dims* dims, pevit_ctx** out);
+void pevit_ctx_destroy(pevit_ctx* ctx);
+
+/* sizes the caller must provide */
+size_t pevit_arena_bytes(const pevit_ctx* ctx);                 /* frozen weights, engine layout */
+size_t pevit_workspace_bytes(const pevit_ctx* ctx, int batch);  /* activations + scratch          */
+/* number of f32 trainable parameters: tower adapters (reference named_parameters() order,
+ * README.md:84-87 counts) followed by the head weight (C x D) and bias (C) */
+size_t pevit_num_tower_params(const pevit_ctx* ctx);
+size_t pevit_num_params(const pevit_ctx* ctx);
+/* mask[i] = 1 if parameter i ever receives a gradient; 0 for the v_proj_adapter1_* tensors
+ * of KAdaptation, which the reference never uses (model.py:580) and whose .grad stays None */
+int pevit_param_grad_mask(const pevit_ctx* ctx, unsigned char* host_mask, size_t n);
+
+int pevit_bind(pevit_ctx* ctx, void* arena, size_t arena_bytes, void* workspace, size_t workspace_bytes,
+               int max_batch);
+/* flat f32 parameter / gradient / momentum buffers (device, borrowed); gradients are
+ * accumulated into `grads`.  `grad_mask` is the device copy of pevit_param_grad_mask (may be
+ * NULL = every parameter is updated). */
+int pevit_set_params(pevit_ctx* ctx, float* params, float* grads, float* momentum,
+                     const unsigned char* grad_mask);
+
+/* frozen weights: device f32 pointers in the OpenAI state-dict layout */
+int pevit_load_block(pevit_ctx* ctx, void* stream, int layer, const float* in_proj_weight,
+                     const float* in_proj_bias, const float* out_proj_weight, const float* out_proj_bias,
+                     const float* ln_1_weight, const float* ln_1_bias, const float* c_fc_weight,
+                     const float* c_fc_bias, const float* c_proj_weight, const float* c_proj_bias,
+                     const float* ln_2_weight, const float* ln_2_bias);
+int pevit_load_stem(pevit_ctx* ctx, void* stream, const float* conv1_weight, const float* class_embedding,
+                    const float* positional_embedding, const float* ln_pre_weight, const float* ln_pre_bias,
+                    const float* ln_post_weight, const float* ln_post_bias, const float* proj);
+/* Compacter's frozen shared phm_rule (4,4,4) (compacter_model.py:511-519) */
+int pevit_load_phm_rule(pevit_ctx* ctx, void* stream, const float* phm_rule);
+
+/* ---- the hot path ------------------------------------------------------------------ */
+int pevit_transformer_forward(pevit_ctx* ctx, void* stream, const float* x_nbe, float* y_nbe, int batch,
+                              int save_for_backward);
+int pevit_transformer_backward(pevit_ctx* ctx, void* stream, const float* dy_nbe, float* dx_nbe_or_null,
+                               int batch);
+int pevit_visual_forward(pevit_ctx* ctx, void* stream, const float* images, float* feat, int batch,
+                         int save_for_backward);
+int pevit_visual_backward(pevit_ctx* ctx, void* stream, const float* dfeat, int batch);
+/* BatchNorm1d(D, affine=False) -> Linear(D, C) -> mean cross-entropy, forward + backward.
+ * bn_training: batch statistics + running-stat update (momentum 0.1); else running stats.
+ * Writes logits (B x C), loss (1), dfeat (B x D); accumulates head grads into the flat buffer. */
+int pevit_head_forward_backward(pevit_ctx* ctx, void* stream, const float* feat, const int64_t* labels,
+                                float* running_mean, float* running_var, int bn_training, float* logits,
+                                float* loss, float* dfeat_or_null, int batch);
+int pevit_zero_grads(pevit_ctx* ctx, void* stream);
+int pevit_sgd_step(pevit_ctx* ctx, void* stream, float lr, float momentum, float weight_decay,
+                   float grad_scale, int first_step);
+/* whole fine-tune step: zero_grad -> forward -> CE -> backward -> (caller all-reduces) -> SGD */
+int pevit_train_forward_backward(pevit_ctx* ctx, void* stream, const float* images, const int64_t* labels,
+                                 float* running_mean, float* running_var, int bn_training, float* logits,
+                                 float* loss, int batch);
+
+/* ---- single kernels, exposed for parity tests and profiling ------------------------- */
+int pevit_op_gemm(void* stream, int epilogue, const void* A_bf16, int lda, const void* B_bf16, int ldb, int b_rows,
+                  int M, int N, int K, const float* bias, const float* resid, int ldr, float* out_f32, int ldo,
+                  void* out_bf16, int ldob, void* out2_bf16, int ldob2, const void* aux_bf16, int ldaux,
+                  size_t head_stride, int E, int H, int tokens);
+int pevit_op_ln_fwd(void* stream, const float* x, const float* gamma, const float* beta, int rows, int E,
+                    void* y_bf16, float* y_f32, float* mean, float* rstd);
+int pevit_op_ln_bwd(void* stream, const float* dy, const float* x, const float* mean, const float* rstd,
+                    const float* gamma, const float* dres, float* dx, void* dx_bf16, int rows, int E);
+int pevit_op_attn_fwd(void* stream, const void* q, const void* k, const void* v, void* out, int ldo, float* lse,
+                      int B, int H, int N);
+int pevit_op_attn_bwd(void* stream, const void* q, const void* k, const void* v, const void* out, int ldo,
+                      const void* dout, int lddo, const float* lse, void* dqkv, int ld, int B, int H, int N);
+int pevit_op_cast_bf16(void* stream, const float* src, void* dst, size_t n, float scale);
+int pevit_op_delta_add(void* stream, void* qbuf, void* vbuf, const float* t, const float* q32, const float* bias,
+                       float ascale, int B, int N, int E);
+int pevit_op_lowrank_u(void* stream, const void* dqkv, int ld, const void* qT, float* u32, void* u_cols, int B,
+                       int H, int N, int E);
+int pevit_op_lowrank_grad(void* stream, const void* xn, int ldx, const float* u32, const void* dqkv, int ld,
+                          const float* t, float* partial, float* dbias_partial, int B, int H, int N, int E);
+int pevit_op_lowrank_chunks(int T);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PEVIT_HIP_H */

@@ -153,6 +153,51 @@ def init_adapter_params(method, width, layers, lora_r=4, seed=0):
 
 
 # --------------------------------------------------------------------------- #
+# optional operand rounding
+# --------------------------------------------------------------------------- #
+# With OPERAND_DTYPE = torch.bfloat16 every contraction of the *frozen-backbone path* (conv,
+# linear, bmm, x @ H, x @ proj) rounds its two operands to bf16 and accumulates in f32 -- the
+# arithmetic class of a bf16-MFMA engine, with nothing else changed.  Tests use it to measure
+# how far bf16 operand rounding ALONE moves logits / gradients away from the f32 reference on a
+# given case, which calibrates the tolerance of the HIP-vs-reference comparisons.
+OPERAND_DTYPE = None
+
+
+class operand_rounding:
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        global OPERAND_DTYPE
+        self.prev, OPERAND_DTYPE = OPERAND_DTYPE, self.dtype
+
+    def __exit__(self, *a):
+        global OPERAND_DTYPE
+        OPERAND_DTYPE = self.prev
+
+
+class _RoundSTE(torch.autograd.Function):
+    """round-to-dtype in forward, identity (also rounded) in backward."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.dtype = dtype
+        return x.to(dtype).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.dtype).to(g.dtype), None
+
+
+def _r(x):
+    return x if OPERAND_DTYPE is None else _RoundSTE.apply(x, OPERAND_DTYPE)
+
+
+def _linear(x, w, b=None):
+    return F.linear(_r(x), _r(w), b)
+
+
+# --------------------------------------------------------------------------- #
 # building blocks
 # --------------------------------------------------------------------------- #
 def layer_norm(x, w, b, eps=1e-5):
@@ -180,12 +225,12 @@ def kadapt_delta(x, p, a, t, which):
     r = "1" if which == "q" else "2"
     rule = torch.bmm(p[t + f"phm_rule{r}_left"], p[t + f"phm_rule{r}_right"])
     H = kron_sum(rule, Wq)
-    return torch.matmul(x, H) * KADAPT_SCALE + p[a + "b"]
+    return torch.matmul(_r(x), _r(H)) * KADAPT_SCALE + p[a + "b"]
 
 
 def lora_delta(x, w1, w2):
     r = w1.shape[0]
-    return torch.matmul(torch.matmul(x, w1.T), w2.T) * (LORA_ALPHA / r)
+    return torch.matmul(torch.matmul(_r(x), _r(w1.T)), w2.T) * (LORA_ALPHA / r)
 
 
 def _heads(x, N, B, H, hd):
@@ -196,7 +241,7 @@ def attention_site_mha(x, p, a, t, heads, method):
     """Self-attention with the delta injected at q and v. x: (N,B,E) contiguous."""
     N, B, E = x.shape
     hd = E // heads
-    qkv = F.linear(x, p[a + "in_proj_weight"], p[a + "in_proj_bias"])
+    qkv = _linear(x, p[a + "in_proj_weight"], p[a + "in_proj_bias"])
     q, k, v = qkv.chunk(3, dim=-1)
     q = _heads(q, N, B, heads, hd)
     k = _heads(k, N, B, heads, hd)
@@ -211,28 +256,28 @@ def attention_site_mha(x, p, a, t, heads, method):
     # raw reinterpretation of the contiguous (N,B,E) buffer
     q = q.contiguous() + dq.reshape(B * heads, N, hd)
     v = v.contiguous() + dv.reshape(B * heads, N, hd)
-    w = torch.softmax(torch.bmm(q, k.transpose(-2, -1)), dim=-1)
-    o = torch.bmm(w, v).transpose(0, 1).contiguous().view(N * B, E)
-    o = F.linear(o, p[a + "out_proj.weight"], p[a + "out_proj.bias"])
+    w = torch.softmax(torch.bmm(_r(q), _r(k).transpose(-2, -1)), dim=-1)
+    o = torch.bmm(_r(w), _r(v)).transpose(0, 1).contiguous().view(N * B, E)
+    o = _linear(o, p[a + "out_proj.weight"], p[a + "out_proj.bias"])
     return o.view(N, B, E)
 
 
 def stock_mha(x, p, a, heads):
     N, B, E = x.shape
     hd = E // heads
-    qkv = F.linear(x, p[a + "in_proj_weight"], p[a + "in_proj_bias"])
+    qkv = _linear(x, p[a + "in_proj_weight"], p[a + "in_proj_bias"])
     q, k, v = qkv.chunk(3, dim=-1)
     q = _heads(q, N, B, heads, hd) / math.sqrt(hd)
     k = _heads(k, N, B, heads, hd)
     v = _heads(v, N, B, heads, hd)
-    w = torch.softmax(torch.bmm(q, k.transpose(-2, -1)), dim=-1)
-    o = torch.bmm(w, v).transpose(0, 1).contiguous().view(N * B, E)
-    return F.linear(o, p[a + "out_proj.weight"], p[a + "out_proj.bias"]).view(N, B, E)
+    w = torch.softmax(torch.bmm(_r(q), _r(k).transpose(-2, -1)), dim=-1)
+    o = torch.bmm(_r(w), _r(v)).transpose(0, 1).contiguous().view(N * B, E)
+    return _linear(o, p[a + "out_proj.weight"], p[a + "out_proj.bias"]).view(N, B, E)
 
 
 def mlp(x, p, pre):
-    h = F.linear(x, p[pre + "mlp.c_fc.weight"], p[pre + "mlp.c_fc.bias"])
-    return F.linear(quick_gelu(h), p[pre + "mlp.c_proj.weight"], p[pre + "mlp.c_proj.bias"])
+    h = _linear(x, p[pre + "mlp.c_fc.weight"], p[pre + "mlp.c_fc.bias"])
+    return _linear(quick_gelu(h), p[pre + "mlp.c_proj.weight"], p[pre + "mlp.c_proj.bias"])
 
 
 def bottleneck_adapter(h, res, p, a):
@@ -290,7 +335,7 @@ def visual_dims(p):
 
 def visual_forward(images, p, method, return_tokens=False):
     d = visual_dims(p)
-    x = F.conv2d(images, p["visual.conv1.weight"], None, stride=d["patch"])
+    x = F.conv2d(_r(images), _r(p["visual.conv1.weight"]), None, stride=d["patch"])
     x = x.reshape(x.shape[0], x.shape[1], -1).permute(0, 2, 1)
     cls = p["visual.class_embedding"] + torch.zeros(x.shape[0], 1, x.shape[-1], dtype=x.dtype)
     x = torch.cat([cls, x], dim=1) + p["visual.positional_embedding"]
@@ -300,7 +345,7 @@ def visual_forward(images, p, method, return_tokens=False):
     tokens = x
     x = x.permute(1, 0, 2)
     x = layer_norm(x[:, 0, :], p["visual.ln_post.weight"], p["visual.ln_post.bias"])
-    x = x @ p["visual.proj"]
+    x = _r(x) @ _r(p["visual.proj"])
     return (x, tokens) if return_tokens else x
 
 

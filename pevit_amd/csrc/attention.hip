@@ -1,0 +1,334 @@
+// Softmax attention core (forward and backward) for one (batch, head) per workgroup.
+//
+// Reference math: model.py:806-812  (bmm(q,k^T) -> softmax(-1) -> bmm(w,v)), with q already
+// scaled by 1/sqrt(64) and q,v already carrying the adapter deltas (model.py:786-799).
+// CLIP ViTs have N = 50 / 197 / 257 tokens and head_dim 64, so one head's Q,K,V (<= 33 KB each
+// in bf16) fit in a single workgroup's LDS: no online-softmax rescaling is needed, the whole
+// score row of a 16-query tile lives in registers.
+//
+// MFMA formulation (v_mfma_f32_16x16x32_bf16, D[i][j] = sum_k A[i][k] B[k][j]):
+//   Z^T[y][x] = sum_d Y[y][d] X[x][d]        A = row fragment of Y, B = row fragment of X
+//       -> lane l holds column x = l&15 and rows y = 4*(l>>4)+reg : a whole softmax row
+//          (all y for one x) sits in ONE 16-lane column, so row max / sum are register
+//          reductions plus two shuffles.
+//   O^T[d][x] = sum_y Yt[d][y] W[y][x]       A = fragment of the TRANSPOSED Y (LDS), B = W
+//       -> W (P or dS) is fed straight from the Z^T accumulator registers: because the MFMA
+//          contraction order is arbitrary, k-slot (j, j+4) of lane group g is defined as
+//          y = 32s + 4g + j and 32s + 16 + 4g + j, exactly what the accumulators hold.
+//   The rows of O^T are permuted (d = 16*(m>>2) + 4*dt + (m&3)) so that each lane ends up with
+//   16 consecutive d of one token: 32-byte stores, 128 contiguous bytes per token.
+// Forward:  x = queries, y = keys  : Z = S, W = P, Yt = V^T                      -> O
+// Backward pass A: x = queries, y = keys: Z1 = S, Z2 = dP, W = dS, Yt = K^T      -> dQ
+// Backward pass B: x = keys, y = queries: Z1 = S, Z2 = dP, W = dS|P, Yt = Q^T|dO^T -> dK, dV
+// (S and dP are recomputed in each pass; 14 small MFMAs per 16x16 cell instead of 10, in
+// exchange for no cross-wave reductions and no atomics.)
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// 16-byte row fragment: row `row` of a row-major [*, stride] bf16 matrix, elements 32*s+8*g..+7
+__device__ __forceinline__ bf16x8 rowfrag(const bf16* base, size_t stride, int row, int s, int g) {
+    return load_bf16x8(base + (size_t)row * stride + 32 * s + 8 * g);
+}
+
+// fragment of a transposed tile Tt[64][LDT] (LDS): output row m -> d = 16*(m>>2) + 4*dt + (m&3)
+__device__ __forceinline__ bf16x8 tfrag(const bf16* Tt, int LDT, int dt, int s, int lane) {
+    const int m = lane & 15, g = lane >> 4;
+    const int d = 16 * (m >> 2) + 4 * dt + (m & 3);
+    const bf16* r = Tt + d * LDT + 32 * s + 4 * g;
+    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(r);
+    const bf16x4 hi = *reinterpret_cast<const bf16x4*>(r + 16);
+    bf16x8 o;
+    o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
+    o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
+    return o;
+}
+
+// Tt[d][y] = src[y][d] for y < N, 0 for N <= y < NPAD.  src rows are `stride` elements apart.
+__device__ __forceinline__ void stage_transposed(bf16* Tt, int LDT, const bf16* src, size_t stride, int N,
+                                                 int NPAD) {
+    for (int idx = threadIdx.x; idx < NPAD * 8; idx += blockDim.x) {
+        const int y = idx >> 3, c = idx & 7;
+        bf16x8 v = zero_bf16x8();
+        if (y < N) v = load_bf16x8(src + (size_t)y * stride + 8 * c);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) Tt[(8 * c + i) * LDT + y] = v[i];
+    }
+}
+
+__device__ __forceinline__ void store16(bf16* dst, const f32x4 o[4], float scale) {
+    bf16x8 a, b;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            a[dt * 4 + r] = f2bf(o[dt][r] * scale);
+            b[dt * 4 + r] = f2bf(o[dt + 2][r] * scale);
+        }
+    store_bf16x8(dst, a);
+    store_bf16x8(dst + 8, b);
+}
+
+// ------------------------------------------------------------------------------------
+template <int KT32>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
+                                                       const bf16* __restrict__ v, bf16* __restrict__ out, int ldo,
+                                                       float* __restrict__ lse, int H, int N) {
+    constexpr int NPAD = 32 * KT32, LDT = NPAD + 4, LDK = 72;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* Ks = reinterpret_cast<bf16*>(smem);                 // [NPAD][LDK] row-major, padded rows
+    bf16* Vt = Ks + NPAD * LDK;                               // [64][LDT]   transposed
+    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+    const bf16* qh = q + (size_t)bh * N * 64;
+    const bf16* kh = k + (size_t)bh * N * 64;
+    const bf16* vh = v + (size_t)bh * N * 64;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, g = lane >> 4, c16 = lane & 15;
+
+    for (int idx = threadIdx.x; idx < NPAD * 8; idx += 256) {
+        const int y = idx >> 3, c = idx & 7;
+        const int ys = y < N ? y : N - 1;
+        *reinterpret_cast<bf16x8*>(Ks + y * LDK + 8 * c) = load_bf16x8(kh + (size_t)ys * 64 + 8 * c);
+    }
+    stage_transposed(Vt, LDT, vh, 64, N, NPAD);
+    __syncthreads();
+
+    const int nxt = (N + 15) >> 4;
+    for (int xt = wid; xt < nxt; xt += 4) {
+        const int xq = 16 * xt + c16;                 // this lane's query (column)
+        const int xs = xq < N ? xq : N - 1;
+        bf16x8 qf[2];
+        qf[0] = rowfrag(qh, 64, xs, 0, g);
+        qf[1] = rowfrag(qh, 64, xs, 1, g);
+        f32x4 z[2 * KT32];
+        float m = -3.0e38f;
+#pragma unroll
+        for (int yt = 0; yt < 2 * KT32; ++yt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = mfma16(rowfrag(Ks, LDK, 16 * yt + c16, 0, g), qf[0], acc);
+            acc = mfma16(rowfrag(Ks, LDK, 16 * yt + c16, 1, g), qf[1], acc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = 16 * yt + 4 * g + r;
+                acc[r] = key < N ? acc[r] : -3.0e38f;
+                m = fmaxf(m, acc[r]);
+            }
+            z[yt] = acc;
+        }
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float l = 0.f;
+        bf16x8 pf[KT32];
+#pragma unroll
+        for (int s = 0; s < KT32; ++s)
+#pragma unroll
+            for (int half = 0; half < 2; ++half)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __expf(z[2 * s + half][r] - m);
+                    // the row sum uses the bf16-rounded probabilities that the PV product sees
+                    const bf16 pb = f2bf(p);
+                    l += bf2f(pb);
+                    pf[s][half * 4 + r] = pb;
+                }
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KT32; ++s) o[dt] = mfma16(tfrag(Vt, LDT, dt, s, lane), pf[s], o[dt]);
+        }
+        if (xq < N) {
+            store16(out + ((size_t)b * N + xq) * ldo + h * 64 + 16 * g, o, 1.0f / l);
+            if (g == 0) lse[(size_t)bh * N + xq] = m + __logf(l);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+template <int KT32>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
+                                                       const bf16* __restrict__ v, const bf16* __restrict__ out,
+                                                       int ldo, const bf16* __restrict__ dout, int lddo,
+                                                       const float* __restrict__ lse, bf16* __restrict__ dqkv, int ld,
+                                                       int H, int N) {
+    constexpr int NPAD = 32 * KT32, LDT = NPAD + 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* Kt = reinterpret_cast<bf16*>(smem);
+    bf16* Qt = Kt + 64 * LDT;
+    bf16* dOt = Qt + 64 * LDT;
+    float* lse_s = reinterpret_cast<float*>(dOt + 64 * LDT);
+    float* del_s = lse_s + NPAD;
+    const int bh = blockIdx.x, b = bh / H, h = bh - b * H, E = H * 64;
+    const bf16* qh = q + (size_t)bh * N * 64;
+    const bf16* kh = k + (size_t)bh * N * 64;
+    const bf16* vh = v + (size_t)bh * N * 64;
+    const bf16* oh = out + (size_t)b * N * ldo + h * 64;       // row y at oh + y*ldo
+    const bf16* doh = dout + (size_t)b * N * lddo + h * 64;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, g = lane >> 4, c16 = lane & 15;
+
+    stage_transposed(Kt, LDT, kh, 64, N, NPAD);
+    stage_transposed(Qt, LDT, qh, 64, N, NPAD);
+    stage_transposed(dOt, LDT, doh, (size_t)lddo, N, NPAD);
+    // delta[y] = sum_d dO[y][d] * O[y][d]   (== sum_keys P*dP), 8 lanes per row
+    for (int idx = threadIdx.x; idx < NPAD * 8; idx += 256) {
+        const int y = idx >> 3, c = idx & 7;
+        float acc = 0.f;
+        if (y < N) {
+            const bf16x8 a = load_bf16x8(doh + (size_t)y * lddo + 8 * c);
+            const bf16x8 o = load_bf16x8(oh + (size_t)y * ldo + 8 * c);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc += bf2f(a[i]) * bf2f(o[i]);
+        }
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        acc += __shfl_xor(acc, 4, 64);
+        if (c == 0) {
+            del_s[y] = acc;
+            lse_s[y] = y < N ? lse[(size_t)bh * N + y] : 0.f;
+        }
+    }
+    __syncthreads();
+
+    const int ntile = (N + 15) >> 4;
+    // ---------------- pass A: x = queries, y = keys -> dQ -----------------------------
+    for (int xt = wid; xt < ntile; xt += 4) {
+        const int xq = 16 * xt + c16;
+        const int xs = xq < N ? xq : N - 1;
+        bf16x8 x1[2], x2[2];
+        x1[0] = rowfrag(qh, 64, xs, 0, g);  x1[1] = rowfrag(qh, 64, xs, 1, g);
+        x2[0] = rowfrag(doh, lddo, xs, 0, g); x2[1] = rowfrag(doh, lddo, xs, 1, g);
+        const float lse_x = lse_s[xs], del_x = del_s[xs];
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll(KT32 <= 2 ? KT32 : 1)
+        for (int s = 0; s < KT32; ++s) {
+            bf16x8 dsb;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int yt = 2 * s + half;
+                int yr = 16 * yt + c16; yr = yr < N ? yr : N - 1;
+                f32x4 z1 = {0.f, 0.f, 0.f, 0.f}, z2 = {0.f, 0.f, 0.f, 0.f};
+                z1 = mfma16(rowfrag(kh, 64, yr, 0, g), x1[0], z1);
+                z1 = mfma16(rowfrag(kh, 64, yr, 1, g), x1[1], z1);
+                z2 = mfma16(rowfrag(vh, 64, yr, 0, g), x2[0], z2);
+                z2 = mfma16(rowfrag(vh, 64, yr, 1, g), x2[1], z2);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = 16 * yt + 4 * g + r;
+                    const float p = key < N ? __expf(z1[r] - lse_x) : 0.f;
+                    dsb[half * 4 + r] = f2bf(p * (z2[r] - del_x));
+                }
+            }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16(tfrag(Kt, LDT, dt, s, lane), dsb, o[dt]);
+        }
+        if (xq < N) store16(dqkv + ((size_t)b * N + xq) * ld + h * 64 + 16 * g, o, 1.0f);
+    }
+    // ---------------- pass B: x = keys, y = queries -> dK, dV -------------------------
+    for (int xt = wid; xt < ntile; xt += 4) {
+        const int xk = 16 * xt + c16;
+        const int xs = xk < N ? xk : N - 1;
+        bf16x8 x1[2], x2[2];
+        x1[0] = rowfrag(kh, 64, xs, 0, g); x1[1] = rowfrag(kh, 64, xs, 1, g);
+        x2[0] = rowfrag(vh, 64, xs, 0, g); x2[1] = rowfrag(vh, 64, xs, 1, g);
+        f32x4 ok[4], ov[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) { ok[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; ov[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll(KT32 <= 2 ? KT32 : 1)
+        for (int s = 0; s < KT32; ++s) {
+            bf16x8 dsb, pb;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int yt = 2 * s + half;
+                int yr = 16 * yt + c16; yr = yr < N ? yr : N - 1;
+                f32x4 z1 = {0.f, 0.f, 0.f, 0.f}, z2 = {0.f, 0.f, 0.f, 0.f};
+                z1 = mfma16(rowfrag(qh, 64, yr, 0, g), x1[0], z1);
+                z1 = mfma16(rowfrag(qh, 64, yr, 1, g), x1[1], z1);
+                z2 = mfma16(rowfrag(doh, lddo, yr, 0, g), x2[0], z2);
+                z2 = mfma16(rowfrag(doh, lddo, yr, 1, g), x2[1], z2);
+                const f32x4 lse_y = *reinterpret_cast<const f32x4*>(lse_s + 16 * yt + 4 * g);
+                const f32x4 del_y = *reinterpret_cast<const f32x4*>(del_s + 16 * yt + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int qy = 16 * yt + 4 * g + r;
+                    const float p = qy < N ? __expf(z1[r] - lse_y[r]) : 0.f;
+                    pb[half * 4 + r] = f2bf(p);
+                    dsb[half * 4 + r] = f2bf(p * (z2[r] - del_y[r]));
+                }
+            }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                ok[dt] = mfma16(tfrag(Qt, LDT, dt, s, lane), dsb, ok[dt]);
+                ov[dt] = mfma16(tfrag(dOt, LDT, dt, s, lane), pb, ov[dt]);
+            }
+        }
+        if (xk < N) {
+            bf16* dst = dqkv + ((size_t)b * N + xk) * ld + h * 64 + 16 * g;
+            store16(dst + E, ok, 1.0f);
+            store16(dst + 2 * E, ov, 1.0f);
+        }
+    }
+}
+
+template <int KT32>
+int launch_fwd(const bf16* q, const bf16* k, const bf16* v, bf16* out, int ldo, float* lse, int B, int H, int N,
+               hipStream_t s) {
+    constexpr int NPAD = 32 * KT32;
+    const int bytes = (NPAD * 72 + 64 * (NPAD + 4)) * 2;
+    static bool attr = false;
+    if (!attr && bytes > 48 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<KT32>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+            pevit_set_error("attn_fwd: cannot reserve %d bytes of LDS", bytes); return -1;
+        }
+        attr = true;
+    }
+    hipLaunchKernelGGL(attn_fwd_kernel<KT32>, dim3(B * H), dim3(256), bytes, s, q, k, v, out, ldo, lse, H, N);
+    return 0;
+}
+
+template <int KT32>
+int launch_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* out, int ldo, const bf16* dout, int lddo,
+               const float* lse, bf16* dqkv, int ld, int B, int H, int N, hipStream_t s) {
+    constexpr int NPAD = 32 * KT32;
+    const int bytes = 3 * 64 * (NPAD + 4) * 2 + 2 * NPAD * 4;
+    static bool attr = false;
+    if (!attr && bytes > 48 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<KT32>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+            pevit_set_error("attn_bwd: cannot reserve %d bytes of LDS", bytes); return -1;
+        }
+        attr = true;
+    }
+    hipLaunchKernelGGL(attn_bwd_kernel<KT32>, dim3(B * H), dim3(256), bytes, s, q, k, v, out, ldo, dout, lddo, lse,
+                       dqkv, ld, H, N);
+    return 0;
+}
+
+}  // namespace
+
+int pevit_launch_attn_fwd(const bf16* q, const bf16* k, const bf16* v, bf16* out, int ldo, float* lse, int B, int H,
+                          int N, hipStream_t s) {
+    if (N < 1 || N > 288) { pevit_set_error("attn_fwd: tokens per image N=%d outside [1,288]", N); return -1; }
+    if (ldo % 8) { pevit_set_error("attn_fwd: ldo must be a multiple of 8"); return -1; }
+    if (N <= 64) return launch_fwd<2>(q, k, v, out, ldo, lse, B, H, N, s);
+    if (N <= 224) return launch_fwd<7>(q, k, v, out, ldo, lse, B, H, N, s);
+    return launch_fwd<9>(q, k, v, out, ldo, lse, B, H, N, s);
+}
+
+int pevit_launch_attn_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* out, int ldo, const bf16* dout,
+                          int lddo, const float* lse, bf16* dqkv, int ld, int B, int H, int N, hipStream_t s) {
+    if (N < 1 || N > 288) { pevit_set_error("attn_bwd: tokens per image N=%d outside [1,288]", N); return -1; }
+    if ((ldo % 8) || (lddo % 8) || (ld % 8)) { pevit_set_error("attn_bwd: leading dims must be multiples of 8"); return -1; }
+    if (N <= 64) return launch_bwd<2>(q, k, v, out, ldo, dout, lddo, lse, dqkv, ld, B, H, N, s);
+    if (N <= 224) return launch_bwd<7>(q, k, v, out, ldo, dout, lddo, lse, dqkv, ld, B, H, N, s);
+    return launch_bwd<9>(q, k, v, out, ldo, dout, lddo, lse, dqkv, ld, B, H, N, s);
+}

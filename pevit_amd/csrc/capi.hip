@@ -1,0 +1,666 @@
+// C-ABI layer: context, memory layout of the weight arena / workspace, and the launch
+// sequences of the fine-tune step.  See include/pevit_hip.h for the boundary contract.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+
+#include "../../include/pevit_hip.h"
+#include "common.h"
+#include "kernels.h"
+
+// ------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+extern "C" void pevit_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* pevit_last_error(void) { return g_err; }
+extern "C" int pevit_version(void) { return 1; }
+
+#define CHECK(call)            \
+    do {                       \
+        if ((call) != 0) return -1; \
+    } while (0)
+
+namespace {
+
+struct Carver {
+    size_t off = 0;
+    size_t take(size_t bytes) {
+        const size_t o = off;
+        off = align_up(off + bytes, 256);
+        return o;
+    }
+};
+
+struct BlockArena {        // byte offsets inside the weight arena, one per layer
+    size_t wqkv, wqkvT, wo, woT, wfc, wfcT, wpr, wprT;
+    size_t bqkv, bo, bfc, bpr, ln1w, ln1b, ln2w, ln2b;
+    size_t q32, qT;
+};
+
+struct LayerSaved {        // byte offsets inside the workspace, one per layer (kept for backward)
+    size_t x_in, x_mid, mean1, rstd1, mean2, rstd2, xn1, qkv, t, lse, attn_out, h;
+};
+
+}  // namespace
+
+struct pevit_ctx {
+    pevit_dims d;
+    int E, L, H, N, P, R, D, C, G2, Kpatch;
+    int NQ, NQpad;            // 3E+64 and its multiple-of-128 padding
+    float ascale;             // 160 (model.py:564) or alpha/r (lora_model.py:491)
+    // arena
+    BlockArena* blk = nullptr;
+    size_t a_conv, a_cls, a_pos, a_lnpre_w, a_lnpre_b, a_lnpost_w, a_lnpost_b, a_proj, a_projT, a_phm;
+    size_t arena_bytes = 0;
+    char* arena = nullptr;
+    // workspace
+    LayerSaved* sav = nullptr;
+    size_t w_xfinal, w_xn2, w_g, w_dqkv, w_u32, w_dO, w_dh, w_dxn, w_dxa, w_dxb, w_dyb, w_partial, w_dbias;
+    size_t w_patches, w_xpost, w_feat, w_pmean, w_prstd, w_ybn, w_bnrstd, w_logits, w_dlogits, w_dybn, w_dfeat,
+        w_dfeatb, w_dxpost;
+    size_t ws_bytes_for_max = 0;
+    char* ws = nullptr;
+    int max_batch = 0;
+    // parameters
+    float* params = nullptr; float* grads = nullptr; float* mom = nullptr;
+    const unsigned char* grad_mask = nullptr;   // device, 1 = parameter receives gradients
+    size_t n_tower = 0, n_total = 0;
+    size_t p_layer0 = 0, p_layer_stride = 0;     // offsets in floats
+    size_t p_head_w = 0, p_head_b = 0;
+    int saved_batch = 0;
+};
+
+namespace {
+
+inline bool attention_site(const pevit_ctx* c) {
+    return c->d.method == PEVIT_KADAPTATION || c->d.method == PEVIT_LORA;
+}
+
+void layout_workspace(pevit_ctx* c, int B, LayerSaved* sav, size_t* total, pevit_ctx* fill) {
+    Carver cv;
+    const size_t T = (size_t)B * c->N, E = c->E;
+    for (int l = 0; l < c->L; ++l) {
+        LayerSaved s;
+        s.x_in = cv.take(T * E * 4);
+        s.x_mid = cv.take(T * E * 4);
+        s.mean1 = cv.take(T * 4); s.rstd1 = cv.take(T * 4);
+        s.mean2 = cv.take(T * 4); s.rstd2 = cv.take(T * 4);
+        s.xn1 = cv.take(T * E * 2);
+        s.qkv = cv.take(3 * T * E * 2);
+        s.t = cv.take(T * 64 * 4);
+        s.lse = cv.take((size_t)B * c->H * c->N * 4);
+        s.attn_out = cv.take(T * E * 2);
+        s.h = cv.take(T * 4 * E * 2);
+        if (sav) sav[l] = s;
+    }
+    const int chunks = pevit_lowrank_chunks((int)T);
+    size_t o;
+    o = cv.take(T * E * 4);                 if (fill) fill->w_xfinal = o;
+    o = cv.take(T * E * 2);                 if (fill) fill->w_xn2 = o;
+    o = cv.take(T * 4 * E * 2);             if (fill) fill->w_g = o;
+    o = cv.take(T * (size_t)c->NQ * 2);     if (fill) fill->w_dqkv = o;
+    o = cv.take(T * 64 * 4);                if (fill) fill->w_u32 = o;
+    o = cv.take(T * E * 2);                 if (fill) fill->w_dO = o;
+    o = cv.take(T * 4 * E * 2);             if (fill) fill->w_dh = o;
+    o = cv.take(T * E * 4);                 if (fill) fill->w_dxn = o;
+    o = cv.take(T * E * 4);                 if (fill) fill->w_dxa = o;
+    o = cv.take(T * E * 4);                 if (fill) fill->w_dxb = o;
+    o = cv.take(T * E * 2);                 if (fill) fill->w_dyb = o;
+    o = cv.take((size_t)(chunks + 1) * 4 * E * 32 * 4);  if (fill) fill->w_partial = o;
+    o = cv.take((size_t)chunks * 2 * E * 4);             if (fill) fill->w_dbias = o;
+    const size_t Bz = (size_t)B, D = c->D, Cc = c->C;
+    o = cv.take(Bz * c->G2 * (size_t)c->Kpatch * 2);      if (fill) fill->w_patches = o;
+    o = cv.take(Bz * E * 2);      if (fill) fill->w_xpost = o;
+    o = cv.take(Bz * D * 4);      if (fill) fill->w_feat = o;
+    o = cv.take(Bz * 4);          if (fill) fill->w_pmean = o;
+    o = cv.take(Bz * 4);          if (fill) fill->w_prstd = o;
+    o = cv.take(Bz * D * 4);      if (fill) fill->w_ybn = o;
+    o = cv.take(D * 4);           if (fill) fill->w_bnrstd = o;
+    o = cv.take(Bz * Cc * 4);     if (fill) fill->w_logits = o;
+    o = cv.take(Bz * Cc * 4);     if (fill) fill->w_dlogits = o;
+    o = cv.take(Bz * D * 4);      if (fill) fill->w_dybn = o;
+    o = cv.take(Bz * D * 4);      if (fill) fill->w_dfeat = o;
+    o = cv.take(Bz * D * 2);      if (fill) fill->w_dfeatb = o;
+    o = cv.take(Bz * E * 4);      if (fill) fill->w_dxpost = o;
+    *total = cv.off;
+}
+
+template <typename T>
+inline T* at(char* base, size_t off) { return reinterpret_cast<T*>(base + off); }
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------
+extern "C" int pevit_ctx_create(const pevit_dims* dims, pevit_ctx** out) {
+    if (!dims || !out) { pevit_set_error("ctx_create: null argument"); return -1; }
+    const pevit_dims d = *dims;
+    if (d.width <= 0 || d.width % 128 != 0 || d.width > 1024) {
+        pevit_set_error("ctx_create: width %d must be a multiple of 128 in (0,1024]", d.width); return -1;
+    }
+    if (d.layers <= 0 || d.patch <= 0 || d.resolution <= 0 || d.resolution % d.patch != 0) {
+        pevit_set_error("ctx_create: bad layers/patch/resolution %d/%d/%d", d.layers, d.patch, d.resolution); return -1;
+    }
+    if (d.method < 0 || d.method > PEVIT_NONE) { pevit_set_error("ctx_create: unknown method %d", d.method); return -1; }
+    if (d.method == PEVIT_LORA && (d.lora_rank < 1 || d.lora_rank > 32)) {
+        pevit_set_error("ctx_create: LoRA rank %d outside [1,32]", d.lora_rank); return -1;
+    }
+    if (d.out_dim <= 0 || d.out_dim % 8 != 0 || d.num_classes <= 0) {
+        pevit_set_error("ctx_create: bad out_dim/num_classes %d/%d", d.out_dim, d.num_classes); return -1;
+    }
+    pevit_ctx* c = new (std::nothrow) pevit_ctx();
+    if (!c) { pevit_set_error("ctx_create: out of host memory"); return -1; }
+    c->d = d;
+    c->E = d.width; c->L = d.layers; c->H = d.width / 64; c->P = d.patch; c->R = d.resolution;
+    const int grid = d.resolution / d.patch;
+    c->G2 = grid * grid; c->N = c->G2 + 1; c->D = d.out_dim; c->C = d.num_classes;
+    c->Kpatch = (int)align_up((size_t)3 * d.patch * d.patch, 64);
+    c->NQ = 3 * c->E + 64; c->NQpad = (int)align_up((size_t)c->NQ, 128);
+    c->ascale = d.method == PEVIT_LORA ? 128.0f / (float)d.lora_rank : 160.0f;
+    if (c->N > 288) { pevit_set_error("ctx_create: %d tokens per image exceeds 288", c->N); delete c; return -1; }
+
+    // ---- weight arena -------------------------------------------------------------
+    c->blk = new (std::nothrow) BlockArena[c->L];
+    c->sav = new (std::nothrow) LayerSaved[c->L];
+    if (!c->blk || !c->sav) { pevit_set_error("ctx_create: out of host memory"); pevit_ctx_destroy(c); return -1; }
+    Carver cv;
+    const size_t E = c->E;
+    for (int l = 0; l < c->L; ++l) {
+        BlockArena& b = c->blk[l];
+        b.wqkv = cv.take((size_t)c->NQpad * E * 2);
+        b.wqkvT = cv.take(E * (size_t)c->NQ * 2);
+        b.wo = cv.take(E * E * 2);   b.woT = cv.take(E * E * 2);
+        b.wfc = cv.take(4 * E * E * 2); b.wfcT = cv.take(4 * E * E * 2);
+        b.wpr = cv.take(4 * E * E * 2); b.wprT = cv.take(4 * E * E * 2);
+        b.bqkv = cv.take(3 * E * 4); b.bo = cv.take(E * 4); b.bfc = cv.take(4 * E * 4); b.bpr = cv.take(E * 4);
+        b.ln1w = cv.take(E * 4); b.ln1b = cv.take(E * 4); b.ln2w = cv.take(E * 4); b.ln2b = cv.take(E * 4);
+        b.q32 = cv.take(E * 64 * 4); b.qT = cv.take(64 * E * 2);
+    }
+    c->a_conv = cv.take(align_up(E, 128) * (size_t)c->Kpatch * 2);
+    c->a_cls = cv.take(E * 4);
+    c->a_pos = cv.take((size_t)c->N * E * 4);
+    c->a_lnpre_w = cv.take(E * 4); c->a_lnpre_b = cv.take(E * 4);
+    c->a_lnpost_w = cv.take(E * 4); c->a_lnpost_b = cv.take(E * 4);
+    c->a_proj = cv.take(align_up((size_t)c->D, 128) * E * 2);      // [D][E]  (proj^T)
+    c->a_projT = cv.take(E * (size_t)c->D * 2);                   // [E][D]
+    c->a_phm = cv.take(64 * 4);
+    c->arena_bytes = cv.off;
+
+    // ---- flat trainable parameters (reference named_parameters() order) -----------
+    if (d.method == PEVIT_KADAPTATION) {
+        c->p_layer0 = 4 * 32 * 32; c->p_layer_stride = 5 * E;
+    } else if (d.method == PEVIT_LORA) {
+        c->p_layer0 = 0; c->p_layer_stride = 4 * (size_t)d.lora_rank * E;
+    } else {
+        c->p_layer0 = 0; c->p_layer_stride = 0;      // post-MLP adapters: added in adapter.hip
+    }
+    c->n_tower = c->p_layer0 + c->p_layer_stride * c->L;
+    c->p_head_w = c->n_tower;
+    c->p_head_b = c->p_head_w + (size_t)c->C * c->D;
+    c->n_total = c->p_head_b + c->C;
+    *out = c;
+    return 0;
+}
+
+extern "C" void pevit_ctx_destroy(pevit_ctx* c) {
+    if (!c) return;
+    delete[] c->blk;
+    delete[] c->sav;
+    delete c;
+}
+
+extern "C" size_t pevit_arena_bytes(const pevit_ctx* c) { return c ? c->arena_bytes : 0; }
+extern "C" size_t pevit_workspace_bytes(const pevit_ctx* c, int batch) {
+    if (!c || batch <= 0) return 0;
+    size_t total = 0;
+    layout_workspace(const_cast<pevit_ctx*>(c), batch, nullptr, &total, nullptr);
+    return total;
+}
+extern "C" size_t pevit_num_tower_params(const pevit_ctx* c) { return c ? c->n_tower : 0; }
+extern "C" size_t pevit_num_params(const pevit_ctx* c) { return c ? c->n_total : 0; }
+
+extern "C" int pevit_param_grad_mask(const pevit_ctx* c, unsigned char* m, size_t n) {
+    if (!c || !m || n != c->n_total) { pevit_set_error("param_grad_mask: size mismatch"); return -1; }
+    memset(m, 1, n);
+    if (c->d.method == PEVIT_KADAPTATION) {
+        const size_t E = c->E;
+        for (int l = 0; l < c->L; ++l) {
+            const size_t base = c->p_layer0 + c->p_layer_stride * l;
+            memset(m + base + 2 * E, 0, 2 * E);       // v_proj_adapter1_left/right
+        }
+    }
+    return 0;
+}
+
+extern "C" int pevit_bind(pevit_ctx* c, void* arena, size_t arena_bytes, void* ws, size_t ws_bytes, int max_batch) {
+    if (!c || !arena || !ws) { pevit_set_error("bind: null argument"); return -1; }
+    if (arena_bytes < c->arena_bytes) { pevit_set_error("bind: arena too small (%zu < %zu)", arena_bytes, c->arena_bytes); return -1; }
+    const size_t need = pevit_workspace_bytes(c, max_batch);
+    if (ws_bytes < need) { pevit_set_error("bind: workspace too small (%zu < %zu)", ws_bytes, need); return -1; }
+    if (((uintptr_t)arena | (uintptr_t)ws) & 255) { pevit_set_error("bind: buffers must be 256-byte aligned"); return -1; }
+    c->arena = (char*)arena; c->ws = (char*)ws; c->max_batch = max_batch; c->ws_bytes_for_max = need;
+    return 0;
+}
+
+extern "C" int pevit_set_params(pevit_ctx* c, float* params, float* grads, float* mom, const unsigned char* mask) {
+    if (!c || !params || !grads) { pevit_set_error("set_params: null argument"); return -1; }
+    c->params = params; c->grads = grads; c->mom = mom; c->grad_mask = mask;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+extern "C" int pevit_load_block(pevit_ctx* c, void* stream, int l, const float* in_w, const float* in_b,
+                                const float* out_w, const float* out_b, const float* ln1w, const float* ln1b,
+                                const float* fc_w, const float* fc_b, const float* pr_w, const float* pr_b,
+                                const float* ln2w, const float* ln2b) {
+    if (!c || !c->arena) { pevit_set_error("load_block: context not bound"); return -1; }
+    if (l < 0 || l >= c->L) { pevit_set_error("load_block: layer %d out of range", l); return -1; }
+    hipStream_t s = (hipStream_t)stream;
+    const BlockArena& b = c->blk[l];
+    const size_t E = c->E;
+    char* A = c->arena;
+    // the 1/sqrt(head_dim) of model.py:786-787 is folded into the q rows (exact: a power of two)
+    HIP_OK(hipMemsetAsync(A + b.wqkv, 0, (size_t)c->NQpad * E * 2, s));
+    CHECK(pevit_launch_cast_bf16(in_w, at<bf16>(A, b.wqkv), E * E, 0.125f, s));
+    CHECK(pevit_launch_cast_bf16(in_w + E * E, at<bf16>(A, b.wqkv) + E * E, 2 * E * E, 1.0f, s));
+    HIP_OK(hipMemsetAsync(A + b.wqkvT, 0, E * (size_t)c->NQ * 2, s));
+    CHECK(pevit_launch_transpose_bf16(in_w, 3 * (int)E, (int)E, at<bf16>(A, b.wqkvT), c->NQ, (int)E, 0.125f, s));
+    CHECK(pevit_launch_cast_bf16(out_w, at<bf16>(A, b.wo), E * E, 1.0f, s));
+    CHECK(pevit_launch_transpose_bf16(out_w, (int)E, (int)E, at<bf16>(A, b.woT), (int)E, 0, 1.0f, s));
+    CHECK(pevit_launch_cast_bf16(fc_w, at<bf16>(A, b.wfc), 4 * E * E, 1.0f, s));
+    CHECK(pevit_launch_transpose_bf16(fc_w, 4 * (int)E, (int)E, at<bf16>(A, b.wfcT), 4 * (int)E, 0, 1.0f, s));
+    CHECK(pevit_launch_cast_bf16(pr_w, at<bf16>(A, b.wpr), 4 * E * E, 1.0f, s));
+    CHECK(pevit_launch_transpose_bf16(pr_w, (int)E, 4 * (int)E, at<bf16>(A, b.wprT), (int)E, 0, 1.0f, s));
+    // biases and LN affines stay f32; the q third of in_proj_bias carries the same 1/8
+    HIP_OK(hipMemcpyAsync(A + b.bqkv, in_b, 3 * E * 4, hipMemcpyDeviceToDevice, s));
+    CHECK(pevit_launch_scale_f32(at<float>(A, b.bqkv), E, 0.125f, s));
+    HIP_OK(hipMemcpyAsync(A + b.bo, out_b, E * 4, hipMemcpyDeviceToDevice, s));
+    HIP_OK(hipMemcpyAsync(A + b.bfc, fc_b, 4 * E * 4, hipMemcpyDeviceToDevice, s));
+    HIP_OK(hipMemcpyAsync(A + b.bpr, pr_b, E * 4, hipMemcpyDeviceToDevice, s));
+    HIP_OK(hipMemcpyAsync(A + b.ln1w, ln1w, E * 4, hipMemcpyDeviceToDevice, s));
+    HIP_OK(hipMemcpyAsync(A + b.ln1b, ln1b, E * 4, hipMemcpyDeviceToDevice, s));
+    HIP_OK(hipMemcpyAsync(A + b.ln2w, ln2w, E * 4, hipMemcpyDeviceToDevice, s));
+    HIP_OK(hipMemcpyAsync(A + b.ln2b, ln2b, E * 4, hipMemcpyDeviceToDevice, s));
+    HIP_OK(hipMemsetAsync(A + b.q32, 0, E * 64 * 4, s));
+    HIP_OK(hipMemsetAsync(A + b.qT, 0, 64 * E * 2, s));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+namespace {
+
+int check_ready(pevit_ctx* c, int B, const char* who) {
+    if (!c || !c->arena || !c->ws) { pevit_set_error("%s: context not bound", who); return -1; }
+    if (B <= 0 || B > c->max_batch) { pevit_set_error("%s: batch %d outside [1,%d]", who, B, c->max_batch); return -1; }
+    if (c->d.method != PEVIT_NONE && (!c->params || !c->grads)) { pevit_set_error("%s: parameters not set", who); return -1; }
+    return 0;
+}
+
+AdapterPanels panels(pevit_ctx* c, int l) {
+    const BlockArena& b = c->blk[l];
+    AdapterPanels p;
+    p.w_aug_rows = at<bf16>(c->arena, b.wqkv) + (size_t)3 * c->E * c->E;
+    p.ldw = c->E;
+    p.wT_aug_cols = at<bf16>(c->arena, b.wqkvT) + 3 * c->E;
+    p.ldwT = c->NQ;
+    p.q32 = at<float>(c->arena, b.q32);
+    p.qT = at<bf16>(c->arena, b.qT);
+    return p;
+}
+
+// rebuild the bf16 adapter panels of every layer from the f32 master parameters
+int prep_adapters(pevit_ctx* c, hipStream_t s) {
+    const size_t E = c->E;
+    for (int l = 0; l < c->L; ++l) {
+        const float* lp = c->params + c->p_layer0 + c->p_layer_stride * l;
+        if (c->d.method == PEVIT_KADAPTATION) {
+            const float* r = c->params;
+            CHECK(pevit_launch_prep_kadapt(r, r + 1024, r + 2048, r + 3072, lp, lp + E, panels(c, l), c->E, c->ascale, s));
+        } else if (c->d.method == PEVIT_LORA) {
+            const size_t rE = (size_t)c->d.lora_rank * E;
+            CHECK(pevit_launch_prep_lora(lp, lp + rE, lp + 2 * rE, lp + 3 * rE, c->d.lora_rank, panels(c, l), c->E,
+                                         c->ascale, s));
+        }
+    }
+    return 0;
+}
+
+GemmParams gp(const bf16* A, int lda, const bf16* B, int ldb, int Nb, int M, int N, int K) {
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.Nb = Nb; p.M = M; p.N = N; p.K = K;
+    return p;
+}
+
+// forward of the L residual blocks on internal (batch-major) rows.  x0 -> sav[0].x_in must
+// already hold the input; the output lands in ws + w_xfinal.
+int blocks_forward(pevit_ctx* c, hipStream_t s, int B) {
+    const int E = c->E, T = B * c->N, H = c->H, N = c->N;
+    char* W = c->ws; char* A = c->arena;
+    const bool site = attention_site(c);
+    if (site) CHECK(prep_adapters(c, s));
+    for (int l = 0; l < c->L; ++l) {
+        const BlockArena& b = c->blk[l];
+        const LayerSaved& v = c->sav[l];
+        float* x_in = at<float>(W, v.x_in);
+        float* x_mid = at<float>(W, v.x_mid);
+        float* x_out = (l + 1 < c->L) ? at<float>(W, c->sav[l + 1].x_in) : at<float>(W, c->w_xfinal);
+        bf16* qkv = at<bf16>(W, v.qkv);
+        const size_t plane = (size_t)T * E;
+        // x = x + attn(ln_1(x))                                         model.py:973
+        CHECK(pevit_launch_ln_fwd(x_in, at<float>(A, b.ln1w), at<float>(A, b.ln1b), T, E, at<bf16>(W, v.xn1), nullptr,
+                                  at<float>(W, v.mean1), at<float>(W, v.rstd1), s));
+        {
+            GemmParams p = gp(at<bf16>(W, v.xn1), E, at<bf16>(A, b.wqkv), E, c->NQpad, T, site ? c->NQ : 3 * E, E);
+            p.bias = at<float>(A, b.bqkv); p.outb = qkv; p.head_stride = plane; p.outf = at<float>(W, v.t); p.ldo = 64;
+            p.E = E; p.H = H; p.Ntok = N;
+            CHECK(pevit_launch_gemm(EPI_QKV_HEADS, p, s));
+        }
+        if (site) {
+            const float* bias = nullptr;
+            if (c->d.method == PEVIT_KADAPTATION) bias = c->params + c->p_layer0 + c->p_layer_stride * l + 4 * (size_t)E;
+            CHECK(pevit_launch_delta_add(qkv, qkv + 2 * plane, at<float>(W, v.t), at<float>(A, b.q32), bias, c->ascale, B, N,
+                                         E, s));
+        }
+        CHECK(pevit_launch_attn_fwd(qkv, qkv + plane, qkv + 2 * plane, at<bf16>(W, v.attn_out), E, at<float>(W, v.lse), B,
+                                    H, N, s));
+        {
+            GemmParams p = gp(at<bf16>(W, v.attn_out), E, at<bf16>(A, b.wo), E, E, T, E, E);
+            p.bias = at<float>(A, b.bo); p.resid = x_in; p.ldr = E; p.outf = x_mid; p.ldo = E;
+            CHECK(pevit_launch_gemm(EPI_BIAS_RESID_F32, p, s));
+        }
+        // x = x + mlp(ln_2(x))                                          model.py:974
+        CHECK(pevit_launch_ln_fwd(x_mid, at<float>(A, b.ln2w), at<float>(A, b.ln2b), T, E, at<bf16>(W, c->w_xn2), nullptr,
+                                  at<float>(W, v.mean2), at<float>(W, v.rstd2), s));
+        {
+            GemmParams p = gp(at<bf16>(W, c->w_xn2), E, at<bf16>(A, b.wfc), E, 4 * E, T, 4 * E, E);
+            p.bias = at<float>(A, b.bfc); p.outb = at<bf16>(W, v.h); p.ldob = 4 * E; p.outb2 = at<bf16>(W, c->w_g);
+            p.ldob2 = 4 * E;
+            CHECK(pevit_launch_gemm(EPI_BIAS_GELU, p, s));
+        }
+        {
+            GemmParams p = gp(at<bf16>(W, c->w_g), 4 * E, at<bf16>(A, b.wpr), 4 * E, E, T, E, 4 * E);
+            p.bias = at<float>(A, b.bpr); p.resid = x_mid; p.ldr = E; p.outf = x_out; p.ldo = E;
+            CHECK(pevit_launch_gemm(EPI_BIAS_RESID_F32, p, s));
+        }
+    }
+    return 0;
+}
+
+// backward of the blocks.  On entry ws+w_dxa holds dL/dx_final (f32) and ws+w_dyb its bf16 copy.
+// On exit ws+w_dxa holds dL/dx_0 if need_dx0.
+int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0) {
+    const int E = c->E, T = B * c->N, H = c->H, N = c->N;
+    char* W = c->ws; char* A = c->arena;
+    const bool site = attention_site(c);
+    const int chunks = pevit_lowrank_chunks(T);
+    float* dxa = at<float>(W, c->w_dxa);
+    float* dxb = at<float>(W, c->w_dxb);
+    bf16* dyb = at<bf16>(W, c->w_dyb);
+    float* dxn = at<float>(W, c->w_dxn);
+    bf16* dqkv = at<bf16>(W, c->w_dqkv);
+    for (int l = c->L - 1; l >= 0; --l) {
+        const BlockArena& b = c->blk[l];
+        const LayerSaved& v = c->sav[l];
+        bf16* qkv = at<bf16>(W, v.qkv);
+        const size_t plane = (size_t)T * E;
+        // ---- MLP branch: d h = (dy W_proj) * gelu'(h) ; d xn2 = d h W_fc
+        {
+            GemmParams p = gp(dyb, E, at<bf16>(A, b.wprT), E, 4 * E, T, 4 * E, E);
+            p.aux = at<bf16>(W, v.h); p.ldaux = 4 * E; p.outb = at<bf16>(W, c->w_dh); p.ldob = 4 * E;
+            CHECK(pevit_launch_gemm(EPI_DGELU_BF16, p, s));
+        }
+        {
+            GemmParams p = gp(at<bf16>(W, c->w_dh), 4 * E, at<bf16>(A, b.wfcT), 4 * E, E, T, E, 4 * E);
+            p.outf = dxn; p.ldo = E;
+            CHECK(pevit_launch_gemm(EPI_F32, p, s));
+        }
+        CHECK(pevit_launch_ln_bwd(dxn, at<float>(W, v.x_mid), at<float>(W, v.mean2), at<float>(W, v.rstd2),
+                                  at<float>(A, b.ln2w), dxa, dxb, dyb, T, E, s));
+        // ---- attention branch
+        {
+            GemmParams p = gp(dyb, E, at<bf16>(A, b.woT), E, E, T, E, E);
+            p.outb = at<bf16>(W, c->w_dO); p.ldob = E;
+            CHECK(pevit_launch_gemm(EPI_BF16, p, s));
+        }
+        CHECK(pevit_launch_attn_bwd(qkv, qkv + plane, qkv + 2 * plane, at<bf16>(W, v.attn_out), E, at<bf16>(W, c->w_dO), E,
+                                    at<float>(W, v.lse), dqkv, c->NQ, B, H, N, s));
+        if (site) {
+            CHECK(pevit_launch_lowrank_u(dqkv, c->NQ, at<bf16>(A, b.qT), at<float>(W, c->w_u32), dqkv + 3 * E, B, H, N, E, s));
+            CHECK(pevit_launch_lowrank_grad(at<bf16>(W, v.xn1), E, at<float>(W, c->w_u32), dqkv, c->NQ, at<float>(W, v.t),
+                                            at<float>(W, c->w_partial), at<float>(W, c->w_dbias), chunks, B, H, N, E, s));
+            float* lg = c->grads + c->p_layer0 + c->p_layer_stride * l;
+            const float* lp = c->params + c->p_layer0 + c->p_layer_stride * l;
+            if (c->d.method == PEVIT_KADAPTATION) {
+                const float* r = c->params; float* g = c->grads;
+                CHECK(pevit_launch_chain_kadapt(at<float>(W, c->w_partial), at<float>(W, c->w_dbias), chunks, c->ascale, r,
+                                                r + 1024, r + 2048, r + 3072, lp, lp + E, g, g + 1024, g + 2048, g + 3072,
+                                                lg, lg + E, lg + 4 * (size_t)E, E, s));
+            } else {
+                const size_t rE = (size_t)c->d.lora_rank * E;
+                CHECK(pevit_launch_chain_lora(at<float>(W, c->w_partial), chunks, c->ascale, c->d.lora_rank, lg, lg + rE,
+                                              lg + 2 * rE, lg + 3 * rE, E, s));
+            }
+        }
+        if (l > 0 || need_dx0) {
+            GemmParams p = gp(dqkv, c->NQ, at<bf16>(A, b.wqkvT), c->NQ, E, T, E, site ? c->NQ : 3 * E);
+            p.outf = dxn; p.ldo = E;
+            CHECK(pevit_launch_gemm(EPI_F32, p, s));
+            CHECK(pevit_launch_ln_bwd(dxn, at<float>(W, v.x_in), at<float>(W, v.mean1), at<float>(W, v.rstd1),
+                                      at<float>(A, b.ln1w), dxb, dxa, dyb, T, E, s));
+        }
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int pevit_transformer_forward(pevit_ctx* c, void* stream, const float* x_nbe, float* y_nbe, int B,
+                                         int save_for_backward) {
+    CHECK(check_ready(c, B, "transformer_forward"));
+    if (!attention_site(c) && c->d.method != PEVIT_NONE) {
+        pevit_set_error("transformer_forward: method %d not built into this library yet", c->d.method); return -1;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    size_t total; layout_workspace(c, B, c->sav, &total, c);
+    CHECK(pevit_launch_permute_rows(x_nbe, at<float>(c->ws, c->sav[0].x_in), c->N, B, c->E, 1, s));
+    CHECK(blocks_forward(c, s, B));
+    CHECK(pevit_launch_permute_rows(at<float>(c->ws, c->w_xfinal), y_nbe, c->N, B, c->E, 0, s));
+    c->saved_batch = save_for_backward ? B : 0;
+    return 0;
+}
+
+extern "C" int pevit_transformer_backward(pevit_ctx* c, void* stream, const float* dy_nbe, float* dx_nbe, int B) {
+    CHECK(check_ready(c, B, "transformer_backward"));
+    if (c->saved_batch != B) { pevit_set_error("transformer_backward: no saved forward for batch %d", B); return -1; }
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = (size_t)B * c->N * c->E;
+    CHECK(pevit_launch_permute_rows(dy_nbe, at<float>(c->ws, c->w_dxa), c->N, B, c->E, 1, s));
+    CHECK(pevit_launch_cast_bf16(at<float>(c->ws, c->w_dxa), at<bf16>(c->ws, c->w_dyb), n, 1.0f, s));
+    CHECK(blocks_backward(c, s, B, dx_nbe != nullptr));
+    if (dx_nbe) CHECK(pevit_launch_permute_rows(at<float>(c->ws, c->w_dxa), dx_nbe, c->N, B, c->E, 0, s));
+    return 0;
+}
+
+extern "C" int pevit_zero_grads(pevit_ctx* c, void* stream) {
+    if (!c || !c->grads) { pevit_set_error("zero_grads: parameters not set"); return -1; }
+    HIP_OK(hipMemsetAsync(c->grads, 0, c->n_total * sizeof(float), (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int pevit_sgd_step(pevit_ctx* c, void* stream, float lr, float momentum, float wd, float grad_scale,
+                              int first_step) {
+    if (!c || !c->params || !c->grads || !c->mom) { pevit_set_error("sgd_step: parameters/momentum not set"); return -1; }
+    return pevit_launch_sgd(c->params, c->grads, c->mom, c->grad_mask, c->n_total, lr, momentum, wd, first_step,
+                            grad_scale, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------
+extern "C" int pevit_load_stem(pevit_ctx* c, void* stream, const float* conv_w, const float* cls, const float* pos,
+                               const float* lnpre_w, const float* lnpre_b, const float* lnpost_w, const float* lnpost_b,
+                               const float* proj) {
+    if (!c || !c->arena) { pevit_set_error("load_stem: context not bound"); return -1; }
+    hipStream_t s = (hipStream_t)stream;
+    char* A = c->arena;
+    const size_t E = c->E;
+    CHECK(pevit_launch_conv_weight(conv_w, at<bf16>(A, c->a_conv), c->E, 3 * c->P * c->P, c->Kpatch, s));
+    HIP_OK(hipMemcpyAsync(A + c->a_cls, cls, E * 4, hipMemcpyDeviceToDevice, s));
+    HIP_OK(hipMemcpyAsync(A + c->a_pos, pos, (size_t)c->N * E * 4, hipMemcpyDeviceToDevice, s));
+    HIP_OK(hipMemcpyAsync(A + c->a_lnpre_w, lnpre_w, E * 4, hipMemcpyDeviceToDevice, s));
+    HIP_OK(hipMemcpyAsync(A + c->a_lnpre_b, lnpre_b, E * 4, hipMemcpyDeviceToDevice, s));
+    HIP_OK(hipMemcpyAsync(A + c->a_lnpost_w, lnpost_w, E * 4, hipMemcpyDeviceToDevice, s));
+    HIP_OK(hipMemcpyAsync(A + c->a_lnpost_b, lnpost_b, E * 4, hipMemcpyDeviceToDevice, s));
+    // proj is (E, D): feat = x @ proj  ->  B operand [D][E] = proj^T ; backward uses proj itself [E][D]
+    CHECK(pevit_launch_transpose_bf16(proj, c->E, c->D, at<bf16>(A, c->a_proj), c->E, 0, 1.0f, s));
+    CHECK(pevit_launch_cast_bf16(proj, at<bf16>(A, c->a_projT), E * (size_t)c->D, 1.0f, s));
+    return 0;
+}
+
+extern "C" int pevit_load_phm_rule(pevit_ctx* c, void* stream, const float* phm_rule) {
+    if (!c || !c->arena) { pevit_set_error("load_phm_rule: context not bound"); return -1; }
+    HIP_OK(hipMemcpyAsync(c->arena + c->a_phm, phm_rule, 64 * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+
+// images (B,3,R,R) f32 -> feat (B,D) f32                               model.py:1034-1051
+extern "C" int pevit_visual_forward(pevit_ctx* c, void* stream, const float* images, float* feat, int B,
+                                    int save_for_backward) {
+    CHECK(check_ready(c, B, "visual_forward"));
+    if (!attention_site(c) && c->d.method != PEVIT_NONE) {
+        pevit_set_error("visual_forward: method %d not built into this library yet", c->d.method); return -1;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    size_t total; layout_workspace(c, B, c->sav, &total, c);
+    char* W = c->ws; char* A = c->arena;
+    const int E = c->E, N = c->N, T = B * N;
+    float* xpre = at<float>(W, c->w_dxn);               // scratch, free during the forward pass
+    CHECK(pevit_launch_im2col(images, at<bf16>(W, c->w_patches), B, c->R, c->P, c->Kpatch, s));
+    CHECK(pevit_launch_cls_row(at<float>(A, c->a_cls), at<float>(A, c->a_pos), xpre, B, N, E, s));
+    {
+        GemmParams p = gp(at<bf16>(W, c->w_patches), c->Kpatch, at<bf16>(A, c->a_conv), c->Kpatch, E, B * c->G2, E, c->Kpatch);
+        p.resid = at<float>(A, c->a_pos); p.ldr = E; p.outf = xpre; p.ldo = E; p.Ntok = N;
+        CHECK(pevit_launch_gemm(EPI_PATCH_EMBED, p, s));
+    }
+    CHECK(pevit_launch_ln_fwd(xpre, at<float>(A, c->a_lnpre_w), at<float>(A, c->a_lnpre_b), T, E, nullptr,
+                              at<float>(W, c->sav[0].x_in), nullptr, nullptr, s));
+    CHECK(blocks_forward(c, s, B));
+    // ln_post on the class token of every image (row b*N), then @ proj
+    CHECK(pevit_launch_ln_fwd(at<float>(W, c->w_xfinal), at<float>(A, c->a_lnpost_w), at<float>(A, c->a_lnpost_b), B, E,
+                              at<bf16>(W, c->w_xpost), nullptr, at<float>(W, c->w_pmean), at<float>(W, c->w_prstd), s,
+                              (size_t)N * E));
+    {
+        GemmParams p = gp(at<bf16>(W, c->w_xpost), E, at<bf16>(A, c->a_proj), E, c->D, B, c->D, E);
+        p.outf = feat ? feat : at<float>(W, c->w_feat); p.ldo = c->D;
+        CHECK(pevit_launch_gemm(EPI_F32, p, s));
+    }
+    c->saved_batch = save_for_backward ? B : 0;
+    return 0;
+}
+
+// dfeat (B,D) f32 -> adapter gradients (nothing below the first block is trainable)
+extern "C" int pevit_visual_backward(pevit_ctx* c, void* stream, const float* dfeat, int B) {
+    CHECK(check_ready(c, B, "visual_backward"));
+    if (c->saved_batch != B) { pevit_set_error("visual_backward: no saved forward for batch %d", B); return -1; }
+    if (c->d.method == PEVIT_NONE) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    char* W = c->ws; char* A = c->arena;
+    const int E = c->E, N = c->N, T = B * N;
+    CHECK(pevit_launch_cast_bf16(dfeat, at<bf16>(W, c->w_dfeatb), (size_t)B * c->D, 1.0f, s));
+    {
+        GemmParams p = gp(at<bf16>(W, c->w_dfeatb), c->D, at<bf16>(A, c->a_projT), c->D, E, B, E, c->D);
+        p.outf = at<float>(W, c->w_dxpost); p.ldo = E;
+        CHECK(pevit_launch_gemm(EPI_F32, p, s));
+    }
+    // dL/dx_final is zero except on the class-token rows
+    HIP_OK(hipMemsetAsync(W + c->w_dxa, 0, (size_t)T * E * 4, s));
+    HIP_OK(hipMemsetAsync(W + c->w_dyb, 0, (size_t)T * E * 2, s));
+    CHECK(pevit_launch_ln_bwd(at<float>(W, c->w_dxpost), at<float>(W, c->w_xfinal), at<float>(W, c->w_pmean),
+                              at<float>(W, c->w_prstd), at<float>(A, c->a_lnpost_w), nullptr, at<float>(W, c->w_dxa),
+                              at<bf16>(W, c->w_dyb), B, E, s, (size_t)N * E));
+    CHECK(blocks_backward(c, s, B, false));
+    return 0;
+}
+
+extern "C" int pevit_head_forward_backward(pevit_ctx* c, void* stream, const float* feat, const int64_t* labels,
+                                           float* running_mean, float* running_var, int bn_training, float* logits,
+                                           float* loss, float* dfeat, int B) {
+    if (!c || !c->ws || !c->params || !c->grads) { pevit_set_error("head: context not ready"); return -1; }
+    if (B <= 0 || B > c->max_batch) { pevit_set_error("head: batch %d outside [1,%d]", B, c->max_batch); return -1; }
+    if (!feat || !running_mean || !running_var || !logits) { pevit_set_error("head: null argument"); return -1; }
+    if (labels && !loss) { pevit_set_error("head: labels given but loss is null"); return -1; }
+    hipStream_t s = (hipStream_t)stream;
+    char* W = c->ws;
+    if (c->saved_batch == 0) { size_t total; layout_workspace(c, B, c->sav, &total, c); }
+    return pevit_launch_head(feat, labels, c->params + c->p_head_w, c->params + c->p_head_b,
+                             labels ? c->grads + c->p_head_w : nullptr, labels ? c->grads + c->p_head_b : nullptr,
+                             running_mean, running_var, bn_training, at<float>(W, c->w_ybn), at<float>(W, c->w_bnrstd),
+                             logits, at<float>(W, c->w_dlogits), at<float>(W, c->w_dybn), loss, dfeat, B, c->D, c->C, s);
+}
+
+extern "C" int pevit_train_forward_backward(pevit_ctx* c, void* stream, const float* images, const int64_t* labels,
+                                            float* running_mean, float* running_var, int bn_training, float* logits,
+                                            float* loss, int B) {
+    CHECK(check_ready(c, B, "train_forward_backward"));
+    CHECK(pevit_zero_grads(c, stream));
+    CHECK(pevit_visual_forward(c, stream, images, nullptr, B, 1));
+    float* feat = at<float>(c->ws, c->w_feat);
+    float* dfeat = at<float>(c->ws, c->w_dfeat);
+    CHECK(pevit_head_forward_backward(c, stream, feat, labels, running_mean, running_var, bn_training, logits, loss,
+                                      dfeat, B));
+    CHECK(pevit_visual_backward(c, stream, dfeat, B));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// single-kernel entry points (parity tests, profiling)
+extern "C" int pevit_op_gemm(void* stream, int epi, const void* A, int lda, const void* Bm, int ldb, int b_rows, int M,
+                             int N, int K, const float* bias, const float* resid, int ldr, float* outf, int ldo,
+                             void* outb, int ldob, void* outb2, int ldob2, const void* aux, int ldaux,
+                             size_t head_stride, int E, int H, int tokens) {
+    GemmParams p = gp((const bf16*)A, lda, (const bf16*)Bm, ldb, b_rows, M, N, K);
+    p.bias = bias; p.resid = resid; p.ldr = ldr; p.outf = outf; p.ldo = ldo; p.outb = (bf16*)outb; p.ldob = ldob;
+    p.outb2 = (bf16*)outb2; p.ldob2 = ldob2; p.aux = (const bf16*)aux; p.ldaux = ldaux; p.head_stride = head_stride;
+    p.E = E; p.H = H; p.Ntok = tokens;
+    return pevit_launch_gemm(epi, p, (hipStream_t)stream);
+}
+extern "C" int pevit_op_ln_fwd(void* stream, const float* x, const float* gamma, const float* beta, int rows, int E,
+                               void* y_bf16, float* y_f32, float* mean, float* rstd) {
+    return pevit_launch_ln_fwd(x, gamma, beta, rows, E, (bf16*)y_bf16, y_f32, mean, rstd, (hipStream_t)stream);
+}
+extern "C" int pevit_op_ln_bwd(void* stream, const float* dy, const float* x, const float* mean, const float* rstd,
+                               const float* gamma, const float* dres, float* dx, void* dx_bf16, int rows, int E) {
+    return pevit_launch_ln_bwd(dy, x, mean, rstd, gamma, dres, dx, (bf16*)dx_bf16, rows, E, (hipStream_t)stream);
+}
+extern "C" int pevit_op_attn_fwd(void* stream, const void* q, const void* k, const void* v, void* out, int ldo,
+                                 float* lse, int B, int H, int N) {
+    return pevit_launch_attn_fwd((const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)out, ldo, lse, B, H, N,
+                                 (hipStream_t)stream);
+}
+extern "C" int pevit_op_attn_bwd(void* stream, const void* q, const void* k, const void* v, const void* out, int ldo,
+                                 const void* dout, int lddo, const float* lse, void* dqkv, int ld, int B, int H, int N) {
+    return pevit_launch_attn_bwd((const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)out, ldo,
+                                 (const bf16*)dout, lddo, lse, (bf16*)dqkv, ld, B, H, N, (hipStream_t)stream);
+}
+extern "C" int pevit_op_cast_bf16(void* stream, const float* src, void* dst, size_t n, float scale) {
+    return pevit_launch_cast_bf16(src, (bf16*)dst, n, scale, (hipStream_t)stream);
+}
+extern "C" int pevit_op_delta_add(void* stream, void* qbuf, void* vbuf, const float* t, const float* q32,
+                                  const float* bias, float ascale, int B, int N, int E) {
+    return pevit_launch_delta_add((bf16*)qbuf, (bf16*)vbuf, t, q32, bias, ascale, B, N, E, (hipStream_t)stream);
+}
+extern "C" int pevit_op_lowrank_u(void* stream, const void* dqkv, int ld, const void* qT, float* u32, void* u_cols, int B,
+                                  int H, int N, int E) {
+    return pevit_launch_lowrank_u((const bf16*)dqkv, ld, (const bf16*)qT, u32, (bf16*)u_cols, B, H, N, E,
+                                  (hipStream_t)stream);
+}
+extern "C" int pevit_op_lowrank_grad(void* stream, const void* xn, int ldx, const float* u32, const void* dqkv, int ld,
+                                     const float* t, float* partial, float* dbias_partial, int B, int H, int N, int E) {
+    return pevit_launch_lowrank_grad((const bf16*)xn, ldx, u32, (const bf16*)dqkv, ld, t, partial, dbias_partial,
+                                     pevit_lowrank_chunks(B * N), B, H, N, E, (hipStream_t)stream);
+}
+extern "C" int pevit_op_lowrank_chunks(int T) { return pevit_lowrank_chunks(T); }

@@ -1,0 +1,75 @@
+// Shared device helpers for the pevit_amd gfx950 kernels.
+// CDNA4 only: 64-wide wavefronts, MFMA bf16 (f32 accumulate), LDS-DMA staging.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+#define PEVIT_WAVE 64
+
+#define HIP_OK(expr)                                                         \
+    do {                                                                     \
+        hipError_t _e = (expr);                                              \
+        if (_e != hipSuccess) {                                              \
+            pevit_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr,     \
+                            hipGetErrorString(_e));                          \
+            return -1;                                                       \
+        }                                                                    \
+    } while (0)
+
+extern "C" void pevit_set_error(const char* fmt, ...);
+
+__device__ __forceinline__ float bf2f(bf16 v) { return (float)v; }
+__device__ __forceinline__ bf16 f2bf(float v) { return (bf16)v; }
+
+__device__ __forceinline__ bf16x8 load_bf16x8(const bf16* p) {
+    return *reinterpret_cast<const bf16x8*>(p);
+}
+__device__ __forceinline__ void store_bf16x8(bf16* p, bf16x8 v) {
+    *reinterpret_cast<bf16x8*>(p) = v;
+}
+__device__ __forceinline__ bf16x8 zero_bf16x8() {
+    bf16x8 z;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) z[i] = (bf16)0.0f;
+    return z;
+}
+
+// Asynchronous global -> LDS copy, 16 bytes per lane.  The LDS destination is
+// wave-uniform: the hardware writes lane l's 16 bytes at lds_wave_base + 16*l.
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)gsrc,
+        (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// XCD-aware, bijective block-id remap (8 XCDs, block b is dispatched to XCD b%8):
+// gives every XCD a contiguous run of tile indices so that neighbouring tiles
+// (which share an A row-panel) hit the same private L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

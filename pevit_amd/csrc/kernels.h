@@ -1,0 +1,108 @@
+// Internal launcher interface between the C-ABI layer (capi.hip) and the kernel files.
+#pragma once
+#include "common.h"
+
+enum GemmEpilogue {
+    EPI_QKV_HEADS = 0,       // +bias, bf16 -> (which, b*H+h, n, d) head layout; cols >= 3E -> f32 t[T][64]
+    EPI_BIAS_RESID_F32 = 1,  // out_f32 = acc + bias + resid
+    EPI_BIAS_GELU = 2,       // h = acc + bias (bf16, saved) ; g = QuickGELU(h) (bf16)
+    EPI_DGELU_BF16 = 3,      // out_bf16 = acc * QuickGELU'(aux)
+    EPI_F32 = 4,             // out_f32 = acc
+    EPI_BF16 = 5,            // out_bf16 = acc
+    EPI_BIAS_BF16 = 6,       // out_bf16 = acc + bias
+    EPI_PATCH_EMBED = 7,     // out_f32[b*Ntok+1+g] = acc + pos[1+g]
+    EPI_BIAS_RELU_BF16 = 8,  // out_bf16 = relu(acc + bias)
+};
+
+struct GemmParams {
+    const bf16* A; int lda;
+    const bf16* B; int ldb; int Nb;   // Nb = readable rows of B (>= N)
+    int M, N, K;
+    const float* bias;
+    const float* resid; int ldr;
+    float* outf; int ldo;
+    bf16* outb; int ldob;
+    bf16* outb2; int ldob2;
+    const bf16* aux; int ldaux;
+    // head-layout epilogue
+    size_t head_stride;   // elements between the q, k and v planes
+    int E, H, Ntok;
+};
+
+int pevit_launch_gemm(int epi, const GemmParams& p, hipStream_t stream);
+
+// ---- norm.hip --------------------------------------------------------------------
+// y = LN(x) * gamma + beta over the last dim (eps 1e-5, f32 statistics: model.py:154-160)
+int pevit_launch_ln_fwd(const float* x, const float* gamma, const float* beta, int rows, int E,
+                        bf16* y_bf16, float* y_f32, float* mean, float* rstd, hipStream_t s,
+                        size_t xstride = 0);
+// dx_out = dres + LN-backward(dy)   (gamma/beta frozen: no parameter grads)
+int pevit_launch_ln_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
+                        const float* gamma, const float* dres, float* dx_out, bf16* dx_bf16, int rows, int E,
+                        hipStream_t s, size_t xstride = 0);
+
+// ---- attention.hip ---------------------------------------------------------------
+// q,k,v: (B*H, N, 64) bf16 (q pre-scaled by 1/8, deltas already added); out: rows (b*N+n), cols h*64+d
+int pevit_launch_attn_fwd(const bf16* q, const bf16* k, const bf16* v, bf16* out, int ldo,
+                          float* lse, int B, int H, int N, hipStream_t s);
+// dqkv: row layout [T][ld]: cols [0,E) dq, [E,2E) dk, [2E,3E) dv
+int pevit_launch_attn_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* out, int ldo,
+                          const bf16* dout, int lddo, const float* lse, bf16* dqkv, int ld,
+                          int B, int H, int N, hipStream_t s);
+
+// ---- lowrank.hip -----------------------------------------------------------------
+struct AdapterPanels {      // per layer, rewritten every step from the f32 master parameters
+    bf16* w_aug_rows;       // &Wqkv_aug[3E][0]  : 64 rows x E  (P_q^T | P_v^T)
+    int ldw;
+    bf16* wT_aug_cols;      // &WqkvT_aug[0][3E] : E rows, 64 cols (ascale*P_q | ascale*P_v)
+    int ldwT;
+    float* q32;             // [E][64] f32 : Q_q | Q_v
+    bf16* qT;               // [64][E] bf16: Q_q^T ; Q_v^T
+};
+// KAdaptation: P[:,j] = s_j (x) l_j , Q[:,j] = t_j (x) r_j   (model.py:567-580)
+int pevit_launch_prep_kadapt(const float* rule1_l, const float* rule1_r, const float* rule2_l,
+                             const float* rule2_r, const float* q_left, const float* q_right,
+                             AdapterPanels pan, int E, float ascale, hipStream_t s);
+// LoRA: P_q = A1q^T, Q_q = A2q (rank r zero-padded to 32)   (lora_model.py:490-514)
+int pevit_launch_prep_lora(const float* a1q, const float* a2q, const float* a1v, const float* a2v,
+                           int r, AdapterPanels pan, int E, float ascale, hipStream_t s);
+// q_buf_flat[rr*E+e] += ascale * t[row(rr)][0:32] . Q_q[e] + bias[e]   (and v with cols 32:64)
+// rr is the reference's (n*B+b) row index of the raw reshape (model.py:796-799); row(rr)=b*N+n.
+int pevit_launch_delta_add(bf16* qbuf, bf16* vbuf, const float* t, const float* q32,
+                           const float* bias, float ascale, int B, int N, int E, hipStream_t s);
+// u[row(rr)][0:32] = dDelta_q[rr] . Q_q ; [32:64] = dDelta_v[rr] . Q_v ; written f32 (u32) and
+// bf16 into dqkv[:, 3E:3E+64]
+int pevit_launch_lowrank_u(const bf16* dqkv, int ld, const bf16* qT, float* u32, bf16* u_bf16_cols,
+                           int B, int H, int N, int E, hipStream_t s);
+// partial[chunk][4][E][32]: dP_q, dP_v (= xn^T u), dQ_q, dQ_v (= dDelta^T t_ref); dbias partial[chunk][E]
+int pevit_launch_lowrank_grad(const bf16* xn, int ldx, const float* u32, const bf16* dqkv, int ld,
+                              const float* t, float* partial, float* dbias_partial, int chunks,
+                              int B, int H, int N, int E, hipStream_t s);
+int pevit_lowrank_chunks(int T);
+// chain rule onto the reference's parameters; g_* point into the flat gradient buffer
+int pevit_launch_chain_kadapt(const float* partial, const float* dbias_partial, int chunks, float ascale,
+                              const float* rule1_l, const float* rule1_r, const float* rule2_l,
+                              const float* rule2_r, const float* q_left, const float* q_right,
+                              float* g_rule1_l, float* g_rule1_r, float* g_rule2_l, float* g_rule2_r,
+                              float* g_q_left, float* g_q_right, float* g_b, int E, hipStream_t s);
+int pevit_launch_chain_lora(const float* partial, int chunks, float ascale, int r,
+                            float* g_a1q, float* g_a2q, float* g_a1v, float* g_a2v, int E, hipStream_t s);
+
+// ---- misc.hip --------------------------------------------------------------------
+int pevit_launch_cast_bf16(const float* src, bf16* dst, size_t n, float scale, hipStream_t s);
+// dst[c][r] = scale(r) * src[r][c]  (bf16 out), used once at load for the backward weights
+int pevit_launch_transpose_bf16(const float* src, int rows, int cols, bf16* dst, int ldd,
+                                int scaled_rows, float scale, hipStream_t s);
+int pevit_launch_permute_rows(const float* src, float* dst, int N, int B, int E, int to_internal,
+                              hipStream_t s);
+int pevit_launch_scale_f32(float* p, size_t n, float scale, hipStream_t s);
+int pevit_launch_sgd(float* p, const float* g, float* mom, const unsigned char* has_grad, size_t n,
+                     float lr, float momentum, float wd, int first_step, float grad_scale, hipStream_t s);
+
+// ---- stem_head.hip -----------------------------------------------------------------
+int pevit_launch_im2col(const float* img, bf16* out, int B, int R, int P, int Kp, hipStream_t s);
+int pevit_launch_conv_weight(const float* w, bf16* out, int E, int K, int Kp, hipStream_t s);
+int pevit_launch_cls_row(const float* cls, const float* pos, float* x, int B, int N, int E, hipStream_t s);
+int pevit_launch_head(const float* feat, const int64_t* labels, const float* W, const float* bias, float* gW, float* gb,
+                      float* running_mean, float* running_var, int training, float* ybn, float* rstd, float* logits,
+                      float* dlogits, float* dybn, float* loss, float* dfeat, int B, int D, int Cc, hipStream_t s);

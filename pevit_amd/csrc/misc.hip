@@ -1,0 +1,103 @@
+// Small HBM-streaming helpers: weight conversion at load time, (N,B,E)<->(B,N,E) row
+// permutes at the API seam, and the fused SGD(momentum) update over the flat parameter
+// buffer (reference: optim/build.py:120-127 -> torch.optim.SGD, nesterov=False).
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+__global__ void cast_bf16_kernel(const float* __restrict__ src, bf16* __restrict__ dst, size_t n, float scale) {
+    size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
+    for (; i + 3 < n; i += stride) {
+        const float4 v = *reinterpret_cast<const float4*>(src + i);
+        bf16x4 o;
+        o[0] = f2bf(v.x * scale); o[1] = f2bf(v.y * scale); o[2] = f2bf(v.z * scale); o[3] = f2bf(v.w * scale);
+        *reinterpret_cast<bf16x4*>(dst + i) = o;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (size_t j = n & ~(size_t)3; j < n; ++j) dst[j] = f2bf(src[j] * scale);
+}
+
+// dst[c*ldd + r] = src[r*cols + c] * (r < scaled_rows ? scale : 1)
+__global__ void transpose_bf16_kernel(const float* __restrict__ src, int rows, int cols, bf16* __restrict__ dst,
+                                      int ldd, int scaled_rows, float scale) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < rows && c < cols) ? src[(size_t)r * cols + c] * (r < scaled_rows ? scale : 1.0f) : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < cols && r < rows) dst[(size_t)c * ldd + r] = f2bf(tile[tx][i]);
+    }
+}
+
+// to_internal: dst[(b*N+n)*E + e] = src[(n*B+b)*E + e] ; else the inverse
+__global__ void permute_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int B, int E,
+                                    int to_internal) {
+    const int row = blockIdx.x;              // destination row
+    int srow;
+    if (to_internal) { const int b = row / N, n = row - b * N; srow = n * B + b; }
+    else             { const int n = row / B, b = row - n * B; srow = b * N + n; }
+    const float4* s = reinterpret_cast<const float4*>(src + (size_t)srow * E);
+    float4* d = reinterpret_cast<float4*>(dst + (size_t)row * E);
+    for (int i = threadIdx.x; i < E / 4; i += blockDim.x) d[i] = s[i];
+}
+
+__global__ void scale_f32_kernel(float* p, size_t n, float scale) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] *= scale;
+}
+
+__global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ mom,
+                           const unsigned char* __restrict__ has_grad, size_t n, float lr, float momentum, float wd,
+                           int first_step, float grad_scale) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (has_grad && !has_grad[i]) return;       // torch skips parameters whose .grad is None
+    float d = g[i] * grad_scale + wd * p[i];
+    const float buf = first_step ? d : momentum * mom[i] + d;
+    mom[i] = buf;
+    p[i] -= lr * buf;
+}
+
+}  // namespace
+
+int pevit_launch_cast_bf16(const float* src, bf16* dst, size_t n, float scale, hipStream_t s) {
+    if (n == 0) return 0;
+    const int blocks = (int)((n / 4 + 255) / 256);
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks)), dim3(256), 0, s, src,
+                       dst, n, scale);
+    return 0;
+}
+
+int pevit_launch_transpose_bf16(const float* src, int rows, int cols, bf16* dst, int ldd, int scaled_rows, float scale,
+                                hipStream_t s) {
+    hipLaunchKernelGGL(transpose_bf16_kernel, dim3(ceil_div(cols, 32), ceil_div(rows, 32)), dim3(256), 0, s, src, rows,
+                       cols, dst, ldd, scaled_rows, scale);
+    return 0;
+}
+
+int pevit_launch_permute_rows(const float* src, float* dst, int N, int B, int E, int to_internal, hipStream_t s) {
+    if (E % 4) { pevit_set_error("permute_rows: width %d must be a multiple of 4", E); return -1; }
+    hipLaunchKernelGGL(permute_rows_kernel, dim3(N * B), dim3(192), 0, s, src, dst, N, B, E, to_internal);
+    return 0;
+}
+
+int pevit_launch_scale_f32(float* p, size_t n, float scale, hipStream_t s) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(scale_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, n, scale);
+    return 0;
+}
+
+int pevit_launch_sgd(float* p, const float* g, float* mom, const unsigned char* has_grad, size_t n, float lr,
+                     float momentum, float wd, int first_step, float grad_scale, hipStream_t s) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, g, mom, has_grad, n, lr,
+                       momentum, wd, first_step, grad_scale);
+    return 0;
+}

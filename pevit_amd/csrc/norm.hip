@@ -1,0 +1,139 @@
+// LayerNorm forward / backward for the frozen ln_1 / ln_2 / ln_pre / ln_post of the CLIP
+// vision tower (reference: model.py:154-160 -- statistics in f32, eps = 1e-5).
+// One 64-lane wavefront per row; the row lives in registers (E <= 1024), reductions are
+// wave shuffles, every global access is a 16-byte-per-lane coalesced segment.  These kernels
+// are pure HBM streaming: ~ (4+2) B/elem forward, (4+4+4+4) B/elem backward.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int MAXV = 4;   // float4 per lane -> E <= 1024
+
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, int rows, int E, size_t xstride,
+                                                     bf16* __restrict__ yb, float* __restrict__ yf,
+                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * xstride;
+    float4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane * 4 + i * 256;
+        if (c < E) {
+            v[i] = *reinterpret_cast<const float4*>(xr + c);
+            s += v[i].x + v[i].y + v[i].z + v[i].w;
+        }
+    }
+    const float mean = wave_sum(s) / (float)E;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane * 4 + i * 256;
+        if (c < E) {
+            const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+            q += a * a + b * b + cc * cc + d * d;
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)E + 1e-5f);
+    if (lane == 0) {
+        if (mean_out) mean_out[row] = mean;
+        if (rstd_out) rstd_out[row] = rstd;
+    }
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane * 4 + i * 256;
+        if (c < E) {
+            const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+            const float4 b = *reinterpret_cast<const float4*>(beta + c);
+            float4 o;
+            o.x = (v[i].x - mean) * rstd * g.x + b.x;
+            o.y = (v[i].y - mean) * rstd * g.y + b.y;
+            o.z = (v[i].z - mean) * rstd * g.z + b.z;
+            o.w = (v[i].w - mean) * rstd * g.w + b.w;
+            if (yb) {
+                bf16x4 ob;
+                ob[0] = f2bf(o.x); ob[1] = f2bf(o.y); ob[2] = f2bf(o.z); ob[3] = f2bf(o.w);
+                *reinterpret_cast<bf16x4*>(yb + (size_t)row * E + c) = ob;
+            }
+            if (yf) *reinterpret_cast<float4*>(yf + (size_t)row * E + c) = o;
+        }
+    }
+}
+
+// dx = dres + rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat))
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                     const float* __restrict__ gamma, const float* dres,
+                                                     float* dx, bf16* __restrict__ dx_bf16, int rows, int E, size_t xstride) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    const size_t base = (size_t)row * E;          // dy rows are always compact
+    const size_t xb = (size_t)row * xstride;      // x, dres, dx, dx_bf16 share the row stride
+    float4 gd[MAXV], xh[MAXV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane * 4 + i * 256;
+        if (c < E) {
+            const float4 d = *reinterpret_cast<const float4*>(dy + base + c);
+            const float4 xv = *reinterpret_cast<const float4*>(x + xb + c);
+            const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+            gd[i] = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
+            xh[i] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+            s1 += gd[i].x + gd[i].y + gd[i].z + gd[i].w;
+            s2 += gd[i].x * xh[i].x + gd[i].y * xh[i].y + gd[i].z * xh[i].z + gd[i].w * xh[i].w;
+        }
+    }
+    const float m1 = wave_sum(s1) / (float)E;
+    const float m2 = wave_sum(s2) / (float)E;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane * 4 + i * 256;
+        if (c < E) {
+            float4 o;
+            o.x = rstd * (gd[i].x - m1 - xh[i].x * m2);
+            o.y = rstd * (gd[i].y - m1 - xh[i].y * m2);
+            o.z = rstd * (gd[i].z - m1 - xh[i].z * m2);
+            o.w = rstd * (gd[i].w - m1 - xh[i].w * m2);
+            if (dres) {
+                const float4 r = *reinterpret_cast<const float4*>(dres + xb + c);
+                o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+            }
+            *reinterpret_cast<float4*>(dx + xb + c) = o;
+            if (dx_bf16) {
+                bf16x4 ob;
+                ob[0] = f2bf(o.x); ob[1] = f2bf(o.y); ob[2] = f2bf(o.z); ob[3] = f2bf(o.w);
+                *reinterpret_cast<bf16x4*>(dx_bf16 + xb + c) = ob;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+int pevit_launch_ln_fwd(const float* x, const float* gamma, const float* beta, int rows, int E, bf16* y_bf16,
+                        float* y_f32, float* mean, float* rstd, hipStream_t s, size_t xstride) {
+    if (xstride == 0) xstride = (size_t)E;
+    if (E % 4 != 0 || E > 256 * MAXV) { pevit_set_error("ln_fwd: unsupported width %d", E); return -1; }
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, s, x, gamma, beta, rows, E, xstride,
+                       y_bf16, y_f32, mean, rstd);
+    return 0;
+}
+
+int pevit_launch_ln_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                        const float* dres, float* dx_out, bf16* dx_bf16, int rows, int E, hipStream_t s,
+                        size_t xstride) {
+    if (xstride == 0) xstride = (size_t)E;
+    if (E % 4 != 0 || E > 256 * MAXV) { pevit_set_error("ln_bwd: unsupported width %d", E); return -1; }
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, s, dy, x, mean, rstd, gamma, dres,
+                       dx_out, dx_bf16, rows, E, xstride);
+    return 0;
+}

@@ -1,0 +1,248 @@
+"""Host-side owner of one HIP engine context (one per process / GPU).
+
+PyTorch is used here for what it is good at -- device memory, streams, the
+``torch.distributed`` collective on the flat gradient buffer -- while every
+FLOP of the fine-tune step runs in ``libpevit_hip.so`` (include/pevit_hip.h).
+The trainable parameters live in ONE flat f32 buffer in the reference's
+``named_parameters()`` order (adapters, then ``layers.0.weight/bias`` of the
+Classifier head, kadaptation_clip.py:132); ``param_views()`` exposes them under
+the reference's names so that state-dicts, the requires_grad-by-substring rule
+and DP all-reduce see exactly the tensors the reference has.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+
+import torch
+
+from . import _lib
+from .synth import VitArch
+
+PHM_DIM_KADAPT = 32     # model.py:485
+BOTTLENECK = 64         # adapter_model.py:305, compacter_model.py:472
+PHM_DIM_COMPACTER = 4   # compacter_model.py:512
+
+
+def adapter_param_spec(method: str, width: int, layers: int, lora_rank: int = 4):
+    """(name, shape, trainable) of the tensors the reference adds to the OpenAI layout, in the
+    reference's ``named_parameters()`` order (verified against the golden
+    fixtures' name lists in tests/test_host_api.py)."""
+    E, t = width, "visual.transformer."
+    out = []
+    if method == "kadaptation":
+        n = PHM_DIM_KADAPT
+        out += [(t + "phm_rule1_left", (n, n, 1), True), (t + "phm_rule1_right", (n, 1, n), True),
+                (t + "phm_rule2_left", (n, n, 1), True), (t + "phm_rule2_right", (n, 1, n), True)]
+        for i in range(layers):
+            a = f"{t}resblocks.{i}.attn."
+            out += [(a + "q_proj_adapter1_left", (n, E // n, 1), True), (a + "q_proj_adapter1_right", (n, 1, E // n), True),
+                    (a + "v_proj_adapter1_left", (n, E // n, 1), True), (a + "v_proj_adapter1_right", (n, 1, E // n), True),
+                    (a + "b", (E,), True)]
+    elif method == "lora":
+        for i in range(layers):
+            a = f"{t}resblocks.{i}.attn."
+            out += [(a + "q_proj_adapter1.weight", (lora_rank, E), True), (a + "q_proj_adapter2.weight", (E, lora_rank), True),
+                    (a + "v_proj_adapter1.weight", (lora_rank, E), True), (a + "v_proj_adapter2.weight", (E, lora_rank), True)]
+    elif method == "adapter":
+        for i in range(layers):
+            a = f"{t}resblocks.{i}.adapter."
+            out += [(a + "adapter_norm_before.weight", (E,), True), (a + "adapter_norm_before.bias", (E,), True),
+                    (a + "adapter_down.1.weight", (BOTTLENECK, E), True), (a + "adapter_down.1.bias", (BOTTLENECK,), True),
+                    (a + "adapter_up.weight", (E, BOTTLENECK), True), (a + "adapter_up.bias", (E,), True)]
+    elif method == "compacter":
+        n = PHM_DIM_COMPACTER
+        out += [(t + "phm_rule", (n, n, n), False)]          # name lacks 'compacter' -> frozen (compacter_clip.py:122)
+        for i in range(layers):
+            a = f"{t}resblocks.{i}.compacter."
+            out += [(a + "adapter_norm_before.weight", (E,), True), (a + "adapter_norm_before.bias", (E,), True),
+                    (a + "adapter_down.1.W_left", (n, E // n, 1), True), (a + "adapter_down.1.W_right", (n, 1, BOTTLENECK // n), True),
+                    (a + "adapter_down.1.b", (BOTTLENECK,), True),
+                    (a + "adapter_up.W_left", (n, BOTTLENECK // n, 1), True), (a + "adapter_up.W_right", (n, 1, E // n), True),
+                    (a + "adapter_up.b", (E,), True)]
+    elif method == "none":
+        pass
+    else:
+        raise ValueError(f"unknown PEFT method {method!r}")
+    return out
+
+
+def _numel(shape):
+    n = 1
+    for s in shape:
+        n *= s
+    return n
+
+
+class HipEngine:
+    def __init__(self, arch: VitArch, method: str, num_classes: int, max_batch: int, lora_rank: int = 4,
+                 device: str | torch.device = "cuda:0"):
+        if not torch.cuda.is_available():
+            raise _lib.PevitError("HipEngine needs a ROCm GPU (gfx950); there is no CPU fallback")
+        self.lib = _lib.load()
+        self.arch, self.method, self.num_classes = arch, method, num_classes
+        self.lora_rank, self.max_batch = lora_rank, max_batch
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        dims = _lib.PevitDims(arch.width, arch.layers, arch.patch, arch.resolution, arch.embed_dim,
+                              _lib.METHOD_IDS[method], lora_rank, num_classes)
+        self._ctx = C.c_void_p()
+        _lib.check(self.lib.pevit_ctx_create(C.byref(dims), C.byref(self._ctx)), "pevit_ctx_create")
+        self.arena = torch.zeros(self.lib.pevit_arena_bytes(self._ctx), dtype=torch.uint8, device=self.device)
+        self.workspace = torch.empty(self.lib.pevit_workspace_bytes(self._ctx, max_batch), dtype=torch.uint8,
+                                     device=self.device)
+        _lib.check(self.lib.pevit_bind(self._ctx, _lib.ptr(self.arena), self.arena.numel(), _lib.ptr(self.workspace),
+                                       self.workspace.numel(), max_batch), "pevit_bind")
+        self.n_tower = self.lib.pevit_num_tower_params(self._ctx)
+        self.n_params = self.lib.pevit_num_params(self._ctx)
+        self.params = torch.zeros(self.n_params, dtype=torch.float32, device=self.device)
+        self.grads = torch.zeros_like(self.params)
+        self.momentum = torch.zeros_like(self.params)
+        mask = (C.c_ubyte * self.n_params)()
+        _lib.check(self.lib.pevit_param_grad_mask(self._ctx, mask, self.n_params), "pevit_param_grad_mask")
+        self.grad_mask_host = torch.frombuffer(bytearray(mask), dtype=torch.uint8).clone()
+        self.grad_mask = self.grad_mask_host.to(self.device)
+        _lib.check(self.lib.pevit_set_params(self._ctx, _lib.ptr(self.params), _lib.ptr(self.grads),
+                                             _lib.ptr(self.momentum), _lib.ptr(self.grad_mask)), "pevit_set_params")
+        # BatchNorm1d(D, affine=False) buffers of the Classifier (kadaptation_clip.py:128-131)
+        self.running_mean = torch.zeros(arch.embed_dim, dtype=torch.float32, device=self.device)
+        self.running_var = torch.ones(arch.embed_dim, dtype=torch.float32, device=self.device)
+        self._spec = [(n, s) for n, s, tr in adapter_param_spec(method, arch.width, arch.layers, lora_rank) if tr]
+        total = sum(_numel(s) for _, s in self._spec)
+        if total != self.n_tower:
+            raise _lib.PevitError(f"host/engine parameter layout mismatch: {total} vs {self.n_tower}")
+        self._steps = 0
+        self._logits = torch.empty((max_batch, num_classes), dtype=torch.float32, device=self.device)
+        self._loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_ctx", None):
+                self.lib.pevit_ctx_destroy(self._ctx)
+                self._ctx = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ parameters
+    def param_views(self, buf: torch.Tensor | None = None) -> "OrderedDict[str, torch.Tensor]":
+        """Views of the flat buffer under the reference's parameter names (+ head)."""
+        buf = self.params if buf is None else buf
+        out, off = OrderedDict(), 0
+        for name, shape in self._spec:
+            n = _numel(shape)
+            out[name] = buf[off:off + n].view(shape)
+            off += n
+        D, Cc = self.arch.embed_dim, self.num_classes
+        out["layers.0.weight"] = buf[off:off + Cc * D].view(Cc, D); off += Cc * D
+        out["layers.0.bias"] = buf[off:off + Cc].view(Cc); off += Cc
+        assert off == self.n_params
+        return out
+
+    def grad_views(self):
+        return self.param_views(self.grads)
+
+    # ------------------------------------------------------------------ frozen weights
+    def load_state_dict(self, sd, prefix: str = "visual."):
+        """Frozen backbone from an OpenAI-layout state-dict (any float dtype, any device)."""
+        s = _lib.stream_ptr()
+
+        def dev(key):
+            return sd[prefix + key].detach().to(device=self.device, dtype=torch.float32).contiguous()
+
+        keep = []
+        for i in range(self.arch.layers):
+            b = f"transformer.resblocks.{i}."
+            ts = [dev(b + k) for k in ("attn.in_proj_weight", "attn.in_proj_bias", "attn.out_proj.weight",
+                                       "attn.out_proj.bias", "ln_1.weight", "ln_1.bias", "mlp.c_fc.weight",
+                                       "mlp.c_fc.bias", "mlp.c_proj.weight", "mlp.c_proj.bias", "ln_2.weight", "ln_2.bias")]
+            keep.append(ts)
+            _lib.check(self.lib.pevit_load_block(self._ctx, s, i, *[_lib.ptr(t) for t in ts]), "pevit_load_block")
+        ts = [dev(k) for k in ("conv1.weight", "class_embedding", "positional_embedding", "ln_pre.weight",
+                               "ln_pre.bias", "ln_post.weight", "ln_post.bias", "proj")]
+        keep.append(ts)
+        _lib.check(self.lib.pevit_load_stem(self._ctx, s, *[_lib.ptr(t) for t in ts]), "pevit_load_stem")
+        if self.method == "compacter":
+            r = dev("transformer.phm_rule"); keep.append([r])
+            _lib.check(self.lib.pevit_load_phm_rule(self._ctx, s, _lib.ptr(r)), "pevit_load_phm_rule")
+        torch.cuda.current_stream().synchronize()     # the temporaries above may now be freed
+        del keep
+        # adapter tensors present in the checkpoint overlay their initial values (model.py:1247-1250)
+        views = self.param_views()
+        with torch.no_grad():
+            for name, v in views.items():
+                if name in sd:
+                    v.copy_(sd[name].to(device=self.device, dtype=torch.float32).view_as(v))
+
+    # ------------------------------------------------------------------ hot path
+    def transformer_forward(self, x_nbe: torch.Tensor, save: bool = True) -> torch.Tensor:
+        N, B, E = x_nbe.shape
+        x = x_nbe.contiguous().float()
+        y = torch.empty_like(x)
+        _lib.check(self.lib.pevit_transformer_forward(self._ctx, _lib.stream_ptr(), _lib.ptr(x), _lib.ptr(y), B, int(save)),
+                   "pevit_transformer_forward")
+        return y
+
+    def transformer_backward(self, dy_nbe: torch.Tensor, need_dx: bool = True):
+        N, B, E = dy_nbe.shape
+        dy = dy_nbe.contiguous().float()
+        dx = torch.empty_like(dy) if need_dx else None
+        _lib.check(self.lib.pevit_transformer_backward(self._ctx, _lib.stream_ptr(), _lib.ptr(dy), _lib.ptr(dx), B),
+                   "pevit_transformer_backward")
+        return dx
+
+    def visual_forward(self, images: torch.Tensor, save: bool = True) -> torch.Tensor:
+        B = images.shape[0]
+        img = images.contiguous().float()
+        feat = torch.empty((B, self.arch.embed_dim), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.pevit_visual_forward(self._ctx, _lib.stream_ptr(), _lib.ptr(img), _lib.ptr(feat), B, int(save)),
+                   "pevit_visual_forward")
+        return feat
+
+    def visual_backward(self, dfeat: torch.Tensor):
+        B = dfeat.shape[0]
+        d = dfeat.contiguous().float()
+        _lib.check(self.lib.pevit_visual_backward(self._ctx, _lib.stream_ptr(), _lib.ptr(d), B), "pevit_visual_backward")
+
+    def head_forward_backward(self, feat, labels, bn_training=True, need_dfeat=True):
+        B = feat.shape[0]
+        logits = torch.empty((B, self.num_classes), dtype=torch.float32, device=self.device)
+        loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+        dfeat = torch.empty_like(feat) if (need_dfeat and labels is not None) else None
+        _lib.check(self.lib.pevit_head_forward_backward(
+            self._ctx, _lib.stream_ptr(), _lib.ptr(feat.contiguous()), _lib.ptr(labels), _lib.ptr(self.running_mean),
+            _lib.ptr(self.running_var), int(bn_training), _lib.ptr(logits), _lib.ptr(loss), _lib.ptr(dfeat), B),
+            "pevit_head_forward_backward")
+        return logits, loss, dfeat
+
+    def zero_grad(self):
+        _lib.check(self.lib.pevit_zero_grads(self._ctx, _lib.stream_ptr()), "pevit_zero_grads")
+
+    def forward_backward(self, images, labels, bn_training=True):
+        """zero_grad -> forward -> CE -> backward; gradients land in ``self.grads``.  Returns
+        (logits, loss) as device tensors without synchronising (the reference's
+        ``loss.item()`` per step, kadaptation_clip.py:354, is the caller's choice)."""
+        B = images.shape[0]
+        _lib.check(self.lib.pevit_train_forward_backward(
+            self._ctx, _lib.stream_ptr(), _lib.ptr(images), _lib.ptr(labels), _lib.ptr(self.running_mean),
+            _lib.ptr(self.running_var), int(bn_training), _lib.ptr(self._logits), _lib.ptr(self._loss), B),
+            "pevit_train_forward_backward")
+        return self._logits[:B], self._loss
+
+    def sgd_step(self, lr, momentum=0.9, weight_decay=0.0, grad_scale=1.0):
+        _lib.check(self.lib.pevit_sgd_step(self._ctx, _lib.stream_ptr(), lr, momentum, weight_decay, grad_scale,
+                                           int(self._steps == 0)), "pevit_sgd_step")
+        self._steps += 1
+
+    def reset_optimizer(self):
+        self._steps = 0
+        self.momentum.zero_()
+
+    def train_step(self, images, labels, lr, momentum=0.9, weight_decay=0.0, bn_training=True, process_group=None,
+                   world_size=1):
+        """One reference ``train_one`` iteration (kadaptation_clip.py:347-353).  With DP the flat
+        adapter-gradient buffer is the only thing that crosses xGMI (frozen backbone never does)."""
+        logits, loss = self.forward_backward(images, labels, bn_training)
+        if world_size > 1:
+            torch.distributed.all_reduce(self.grads, group=process_group)
+        self.sgd_step(lr, momentum, weight_decay, 1.0 / world_size)
+        return logits, loss

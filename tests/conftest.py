@@ -12,6 +12,12 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+# The GPU boxes have hundreds of host cores; PyTorch's default of one intra-op thread per core
+# makes the oracle's many small CPU ops crawl (measured: 166 s for one bs=32 oracle step with
+# 256 threads vs 1.5 s with 8).  Bound it.
+torch.set_num_threads(min(16, os.cpu_count() or 1))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -1,0 +1,251 @@
+"""Kernel-level parity: every HIP kernel, called through the C ABI, against a plain PyTorch
+fp32 statement of the same op evaluated on the same (bf16-rounded) operands.
+
+Tolerances: f32 outputs of bf16xbf16 MFMA contractions differ from the torch reference only by
+summation order -> 2e-4 relative-to-max; bf16 outputs add one rounding (2^-9) -> 1e-2.
+"""
+import ctypes as C
+import math
+
+import pytest
+import torch
+
+from conftest import max_rel, rel_err
+
+pytestmark = pytest.mark.gpu
+
+EPI = dict(QKV=0, BIAS_RESID=1, BIAS_GELU=2, DGELU=3, F32=4, BF16=5, BIAS_BF16=6, PATCH=7, BIAS_RELU=8)
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from pevit_amd import _lib
+    return _lib.load()
+
+
+def P(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def S():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ok(lib, rc):
+    assert rc == 0, lib.pevit_last_error().decode()
+
+
+def rnd(*shape, scale=1.0, seed=0, dtype=torch.float32):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).cuda()
+
+
+def gemm(lib, epi, A, B, M, N, K, bias=None, resid=None, outf=None, outb=None, outb2=None, aux=None,
+         head_stride=0, E=0, H=0, tokens=0, b_rows=None):
+    ok(lib, lib.pevit_op_gemm(S(), epi, P(A), A.stride(0), P(B), B.stride(0), b_rows or B.shape[0], M, N, K, P(bias),
+                              P(resid), resid.stride(0) if resid is not None else 0, P(outf),
+                              outf.stride(0) if outf is not None and outf.dim() == 2 else 64,
+                              P(outb), outb.stride(0) if outb is not None and outb.dim() == 2 else 0,
+                              P(outb2), outb2.stride(0) if outb2 is not None else 0,
+                              P(aux), aux.stride(0) if aux is not None else 0, head_stride, E, H, tokens))
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 136, 128), (6400, 768, 768), (1000, 3072, 768), (515, 768, 3072)])
+def test_gemm_f32_and_bf16(lib, M, N, K):
+    A = rnd(M, K, seed=1, dtype=torch.bfloat16)
+    B = rnd(N, K, seed=2, scale=0.05, dtype=torch.bfloat16)
+    ref = A.float() @ B.float().T
+    out = torch.full((M, N), float("nan"), device="cuda")
+    gemm(lib, EPI["F32"], A, B, M, N, K, outf=out)
+    assert max_rel(out.cpu(), ref.cpu()) < 2e-4
+    outb = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
+    gemm(lib, EPI["BF16"], A, B, M, N, K, outb=outb)
+    assert max_rel(outb.float().cpu(), ref.cpu()) < 1e-2
+
+
+def test_gemm_detects_transposes_with_identity(lib):
+    """A = I (padded) with an asymmetric B must reproduce B^T exactly (cdna guide: asymmetric check)."""
+    K = 128
+    A = torch.eye(K, dtype=torch.bfloat16, device="cuda")
+    B = (torch.arange(256 * K, device="cuda").reshape(256, K) % 251).to(torch.bfloat16)
+    out = torch.zeros((K, 256), device="cuda")
+    gemm(lib, EPI["F32"], A, B, K, 256, K, outf=out)
+    assert torch.equal(out, B.float().T)
+
+
+def test_gemm_bias_resid_gelu_dgelu(lib):
+    M, N, K = 300, 256, 192
+    A = rnd(M, K, seed=3, dtype=torch.bfloat16)
+    B = rnd(N, K, seed=4, scale=0.08, dtype=torch.bfloat16)
+    bias = rnd(N, seed=5, scale=0.1)
+    resid = rnd(M, N, seed=6)
+    acc = A.float() @ B.float().T
+    out = torch.zeros((M, N), device="cuda")
+    gemm(lib, EPI["BIAS_RESID"], A, B, M, N, K, bias=bias, resid=resid, outf=out)
+    assert max_rel(out.cpu(), (acc + bias + resid).cpu()) < 2e-4
+    # in place on the residual buffer
+    r2 = resid.clone()
+    gemm(lib, EPI["BIAS_RESID"], A, B, M, N, K, bias=bias, resid=r2, outf=r2)
+    assert torch.equal(r2, out)
+    h = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
+    g = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
+    gemm(lib, EPI["BIAS_GELU"], A, B, M, N, K, bias=bias, outb=h, outb2=g)
+    href = (acc + bias).to(torch.bfloat16)
+    assert max_rel(h.float().cpu(), href.float().cpu()) < 1e-2
+    gref = h.float() * torch.sigmoid(1.702 * h.float())
+    assert max_rel(g.float().cpu(), gref.cpu()) < 1e-2
+    d = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
+    gemm(lib, EPI["DGELU"], A, B, M, N, K, outb=d, aux=h)
+    s = torch.sigmoid(1.702 * h.float())
+    dref = acc * (s * (1 + 1.702 * h.float() * (1 - s)))
+    assert max_rel(d.float().cpu(), dref.cpu()) < 1e-2
+    o = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
+    gemm(lib, EPI["BIAS_RELU"], A, B, M, N, K, bias=bias, outb=o)
+    assert max_rel(o.float().cpu(), torch.relu(acc + bias).cpu()) < 1e-2
+
+
+def test_gemm_qkv_head_layout(lib):
+    E, H, Ntok, Bt = 128, 2, 10, 30
+    T, NQ = Bt * Ntok, 3 * E + 64
+    A = rnd(T, E, seed=7, dtype=torch.bfloat16)
+    W = torch.zeros((512, E), dtype=torch.bfloat16, device="cuda")
+    W[:NQ] = rnd(NQ, E, seed=8, scale=0.1, dtype=torch.bfloat16)
+    bias = rnd(3 * E, seed=9, scale=0.1)
+    qkv = torch.zeros((3, Bt * H, Ntok, 64), dtype=torch.bfloat16, device="cuda")
+    t = torch.zeros((T, 64), device="cuda")
+    gemm(lib, EPI["QKV"], A, W, T, NQ, E, bias=bias, outf=t, outb=qkv, head_stride=T * E, E=E, H=H, tokens=Ntok)
+    acc = A.float() @ W[:NQ].float().T
+    ref = (acc[:, :3 * E] + bias).view(Bt, Ntok, 3, H, 64).permute(2, 0, 3, 1, 4).reshape(3, Bt * H, Ntok, 64)
+    assert max_rel(qkv.float().cpu(), ref.cpu()) < 1e-2
+    assert max_rel(t.cpu(), acc[:, 3 * E:].cpu()) < 2e-4
+
+
+def test_gemm_patch_embed(lib):
+    E, Ntok, Bt, K = 128, 10, 7, 192
+    G2 = Ntok - 1
+    A = rnd(Bt * G2, K, seed=10, dtype=torch.bfloat16)
+    W = rnd(E, K, seed=11, scale=0.1, dtype=torch.bfloat16)
+    pos = rnd(Ntok, E, seed=12)
+    x = torch.zeros((Bt * Ntok, E), device="cuda")
+    ok(lib, lib.pevit_op_gemm(S(), EPI["PATCH"], P(A), K, P(W), K, E, Bt * G2, E, K, None, P(pos), E, P(x), E, None, 0,
+                              None, 0, None, 0, 0, E, 0, Ntok))
+    torch.cuda.synchronize()
+    ref = torch.zeros((Bt, Ntok, E), device="cuda")
+    ref[:, 1:] = (A.float() @ W.float().T).view(Bt, G2, E) + pos[1:]
+    assert max_rel(x.view(Bt, Ntok, E).cpu(), ref.cpu()) < 2e-4
+
+
+@pytest.mark.parametrize("rows,E", [(37, 128), (6400, 768), (257, 1024)])
+def test_layernorm_fwd_bwd(lib, rows, E):
+    x = rnd(rows, E, seed=1, scale=2.0) + 0.5
+    g = 1 + rnd(E, seed=2, scale=0.2); b = rnd(E, seed=3, scale=0.2)
+    yb = torch.zeros((rows, E), dtype=torch.bfloat16, device="cuda"); yf = torch.zeros((rows, E), device="cuda")
+    mean = torch.zeros(rows, device="cuda"); rstd = torch.zeros(rows, device="cuda")
+    ok(lib, lib.pevit_op_ln_fwd(S(), P(x), P(g), P(b), rows, E, P(yb), P(yf), P(mean), P(rstd)))
+    torch.cuda.synchronize()
+    xr = x.clone().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (E,), g, b, 1e-5)
+    assert max_rel(yf.cpu(), ref.detach().cpu()) < 1e-5
+    assert max_rel(yb.float().cpu(), ref.detach().cpu()) < 1e-2
+    dy = rnd(rows, E, seed=4); dres = rnd(rows, E, seed=5)
+    ref.backward(dy)
+    dx = torch.zeros((rows, E), device="cuda"); dxb = torch.zeros((rows, E), dtype=torch.bfloat16, device="cuda")
+    ok(lib, lib.pevit_op_ln_bwd(S(), P(dy), P(x), P(mean), P(rstd), P(g), P(dres), P(dx), P(dxb), rows, E))
+    torch.cuda.synchronize()
+    assert max_rel(dx.cpu(), (xr.grad + dres).cpu()) < 2e-5
+    assert max_rel(dxb.float().cpu(), dx.cpu()) < 1e-2
+
+
+def attn_ref(q, k, v):
+    s = torch.einsum("hqd,hkd->hqk", q, k)
+    p = torch.softmax(s, dim=-1)
+    return torch.einsum("hqk,hkd->hqd", p, v), torch.logsumexp(s, dim=-1)
+
+
+@pytest.mark.parametrize("Bt,H,N", [(3, 2, 50), (2, 2, 10), (1, 12, 50), (2, 2, 197), (1, 3, 257), (2, 1, 64), (1, 1, 1)])
+def test_attention_fwd_bwd(lib, Bt, H, N):
+    E = H * 64
+    q = rnd(Bt * H, N, 64, seed=1, scale=0.35, dtype=torch.bfloat16)
+    k = rnd(Bt * H, N, 64, seed=2, dtype=torch.bfloat16)
+    v = rnd(Bt * H, N, 64, seed=3, dtype=torch.bfloat16)
+    out = torch.zeros((Bt * N, E), dtype=torch.bfloat16, device="cuda")
+    lse = torch.zeros((Bt * H, N), device="cuda")
+    ok(lib, lib.pevit_op_attn_fwd(S(), P(q), P(k), P(v), P(out), E, P(lse), Bt, H, N))
+    torch.cuda.synchronize()
+    qf, kf, vf = (t.float().clone().requires_grad_(True) for t in (q, k, v))
+    o_ref, lse_ref = attn_ref(qf, kf, vf)
+    o_rows = o_ref.view(Bt, H, N, 64).permute(0, 2, 1, 3).reshape(Bt * N, E)
+    assert max_rel(out.float().cpu(), o_rows.detach().cpu()) < 1.5e-2
+    assert float((lse - lse_ref.detach()).abs().max()) < 2e-2
+    do = rnd(Bt * N, E, seed=4, dtype=torch.bfloat16)
+    o_rows.backward(do.float())
+    ld = 3 * E + 64
+    dqkv = torch.zeros((Bt * N, ld), dtype=torch.bfloat16, device="cuda")
+    ok(lib, lib.pevit_op_attn_bwd(S(), P(q), P(k), P(v), P(out), E, P(do), E, P(lse), P(dqkv), ld, Bt, H, N))
+    torch.cuda.synchronize()
+
+    def rows(g):
+        return g.view(Bt, H, N, 64).permute(0, 2, 1, 3).reshape(Bt * N, E)
+    for i, g in enumerate((qf.grad, kf.grad, vf.grad)):
+        got = dqkv[:, i * E:(i + 1) * E].float()
+        assert rel_err(got.cpu(), rows(g).cpu()) < 2e-2, (i, rel_err(got.cpu(), rows(g).cpu()))
+    assert float(dqkv[:, 3 * E:].abs().max()) == 0.0      # the u columns are not touched
+
+
+def _flat_case(Bt=6, N=10, E=128, seed=0):
+    H, T = E // 64, Bt * N
+    t = rnd(T, 64, seed=seed + 1)                                   # internal (b*N+n) row order
+    q32 = rnd(E, 64, seed=seed + 2, scale=0.3)
+    bias = rnd(E, seed=seed + 3, scale=0.2)
+    to_ref = lambda x: x.view(Bt, N, -1).permute(1, 0, 2).reshape(T, -1)     # rows rr = n*B+b
+    to_int = lambda x: x.view(N, Bt, -1).permute(1, 0, 2).reshape(T, -1)
+    return H, T, t, q32, bias, to_ref, to_int
+
+
+@pytest.mark.parametrize("Bt,N,E", [(6, 10, 128), (5, 50, 256), (128, 50, 768)])
+def test_delta_add_flat_reinterpretation(lib, Bt, N, E):
+    H, T, t, q32, bias, to_ref, _ = _flat_case(Bt, N, E)
+    qb = rnd(Bt * H, N, 64, seed=7, dtype=torch.bfloat16); vb = rnd(Bt * H, N, 64, seed=8, dtype=torch.bfloat16)
+    q0, v0 = qb.float().clone(), vb.float().clone()
+    ok(lib, lib.pevit_op_delta_add(S(), P(qb), P(vb), P(t), P(q32), P(bias), 160.0, Bt, N, E))
+    torch.cuda.synchronize()
+    tr = to_ref(t)
+    dq = (160.0 * tr[:, :32] @ q32[:, :32].T + bias).reshape(Bt * H, N, 64)     # the reference's raw reshape
+    dv = (160.0 * tr[:, 32:] @ q32[:, 32:].T + bias).reshape(Bt * H, N, 64)
+    assert max_rel(qb.float().cpu(), (q0 + dq).cpu()) < 1e-2
+    assert max_rel(vb.float().cpu(), (v0 + dv).cpu()) < 1e-2
+
+
+@pytest.mark.parametrize("Bt,N,E", [(6, 10, 128), (5, 50, 256), (16, 50, 768)])
+def test_lowrank_u_and_grads(lib, Bt, N, E):
+    H, T, t, q32, bias, to_ref, to_int = _flat_case(Bt, N, E, seed=20)
+    ld = 3 * E + 64
+    dqkv = torch.zeros((T, ld), dtype=torch.bfloat16, device="cuda")
+    dqkv[:, :3 * E] = rnd(T, 3 * E, seed=30, dtype=torch.bfloat16)
+    qT = q32.T.contiguous().to(torch.bfloat16)                      # [64][E]
+    u32 = torch.zeros((T, 64), device="cuda")
+    ok(lib, lib.pevit_op_lowrank_u(S(), P(dqkv), ld, P(qT), P(u32), C.c_void_p(dqkv.data_ptr() + 3 * E * 2), Bt, H, N, E))
+    torch.cuda.synchronize()
+
+    def flat(cols):      # row layout -> head layout -> the reference's (rr, e) view
+        return cols.float().view(Bt, N, H, 64).permute(0, 2, 1, 3).reshape(T, E)
+    dDq, dDv = flat(dqkv[:, :E]), flat(dqkv[:, 2 * E:3 * E])
+    u_ref = torch.cat([dDq @ qT[:32].float().T, dDv @ qT[32:].float().T], dim=1)      # rows rr
+    assert max_rel(u32.cpu(), to_int(u_ref).cpu()) < 2e-4
+    assert max_rel(dqkv[:, 3 * E:].float().cpu(), to_int(u_ref).cpu()) < 1e-2
+
+    xn = rnd(T, E, seed=31, dtype=torch.bfloat16)
+    chunks = lib.pevit_op_lowrank_chunks(T)
+    partial = torch.zeros((chunks + 1, 4, E, 32), device="cuda")
+    dbp = torch.zeros((chunks, 2, E), device="cuda")
+    ok(lib, lib.pevit_op_lowrank_grad(S(), P(xn), E, P(u32), P(dqkv), ld, P(t), P(partial), P(dbp), Bt, H, N, E))
+    torch.cuda.synchronize()
+    G = partial[:chunks].sum(0)
+    tr = to_ref(t)
+    ref = [xn.float().T @ u32[:, :32], xn.float().T @ u32[:, 32:], dDq.T @ tr[:, :32], dDv.T @ tr[:, 32:]]
+    for i in range(4):
+        assert max_rel(G[i].cpu(), ref[i].cpu()) < 2e-4, i
+    assert max_rel(dbp.sum(0).sum(0).cpu(), (dDq + dDv).sum(0).cpu()) < 2e-4
