@@ -173,9 +173,41 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
     const bf16* doh = dout + (size_t)b * N * lddo + h * 64;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, g = lane >> 4, c16 = lane & 15;
 
-    stage_transposed(Kt, LDT, kh, 64, N, NPAD);
-    stage_transposed(Qt, LDT, qh, 64, N, NPAD);
-    stage_transposed(dOt, LDT, doh, (size_t)lddo, N, NPAD);
+    // Small-N variant (N <= 64): the row-major operands are staged in LDS as well, so that every
+    // MFMA fragment of the two passes is an LDS read (the pass loops are otherwise chains of
+    // dependent global-load latencies).  Padded rows are zero.
+    constexpr bool ROWLDS = (KT32 == 2);
+    constexpr int LDR = 72;
+    bf16* Qs = reinterpret_cast<bf16*>(del_s + NPAD);
+    bf16* Ks = Qs + NPAD * LDR;
+    bf16* Vs = Ks + NPAD * LDR;
+    bf16* dOs = Vs + NPAD * LDR;
+    if constexpr (ROWLDS) {
+        for (int idx = threadIdx.x; idx < NPAD * 8; idx += 256) {
+            const int y = idx >> 3, c = idx & 7;
+            bf16x8 vq = zero_bf16x8(), vk = zero_bf16x8(), vv = zero_bf16x8(), vd = zero_bf16x8();
+            if (y < N) {
+                vq = load_bf16x8(qh + (size_t)y * 64 + 8 * c);
+                vk = load_bf16x8(kh + (size_t)y * 64 + 8 * c);
+                vv = load_bf16x8(vh + (size_t)y * 64 + 8 * c);
+                vd = load_bf16x8(doh + (size_t)y * lddo + 8 * c);
+            }
+            *reinterpret_cast<bf16x8*>(Qs + y * LDR + 8 * c) = vq;
+            *reinterpret_cast<bf16x8*>(Ks + y * LDR + 8 * c) = vk;
+            *reinterpret_cast<bf16x8*>(Vs + y * LDR + 8 * c) = vv;
+            *reinterpret_cast<bf16x8*>(dOs + y * LDR + 8 * c) = vd;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                Kt[(8 * c + i) * LDT + y] = vk[i];
+                Qt[(8 * c + i) * LDT + y] = vq[i];
+                dOt[(8 * c + i) * LDT + y] = vd[i];
+            }
+        }
+    } else {
+        stage_transposed(Kt, LDT, kh, 64, N, NPAD);
+        stage_transposed(Qt, LDT, qh, 64, N, NPAD);
+        stage_transposed(dOt, LDT, doh, (size_t)lddo, N, NPAD);
+    }
     // delta[y] = sum_d dO[y][d] * O[y][d]   (== sum_keys P*dP), 8 lanes per row
     for (int idx = threadIdx.x; idx < NPAD * 8; idx += 256) {
         const int y = idx >> 3, c = idx & 7;
@@ -197,13 +229,18 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
     __syncthreads();
 
     const int ntile = (N + 15) >> 4;
+    // operand sources for the MFMA row fragments
+    const bf16* Qr = ROWLDS ? Qs : qh;   const size_t qst = ROWLDS ? LDR : 64;
+    const bf16* Kr = ROWLDS ? Ks : kh;   const size_t kst = ROWLDS ? LDR : 64;
+    const bf16* Vr = ROWLDS ? Vs : vh;   const size_t vst = ROWLDS ? LDR : 64;
+    const bf16* Dr = ROWLDS ? dOs : doh; const size_t dst_ = ROWLDS ? LDR : (size_t)lddo;
     // ---------------- pass A: x = queries, y = keys -> dQ -----------------------------
     for (int xt = wid; xt < ntile; xt += 4) {
         const int xq = 16 * xt + c16;
         const int xs = xq < N ? xq : N - 1;
         bf16x8 x1[2], x2[2];
-        x1[0] = rowfrag(qh, 64, xs, 0, g);  x1[1] = rowfrag(qh, 64, xs, 1, g);
-        x2[0] = rowfrag(doh, lddo, xs, 0, g); x2[1] = rowfrag(doh, lddo, xs, 1, g);
+        x1[0] = rowfrag(Qr, qst, xs, 0, g);  x1[1] = rowfrag(Qr, qst, xs, 1, g);
+        x2[0] = rowfrag(Dr, dst_, xs, 0, g); x2[1] = rowfrag(Dr, dst_, xs, 1, g);
         const float lse_x = lse_s[xs], del_x = del_s[xs];
         f32x4 o[4];
 #pragma unroll
@@ -216,10 +253,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
                 const int yt = 2 * s + half;
                 int yr = 16 * yt + c16; yr = yr < N ? yr : N - 1;
                 f32x4 z1 = {0.f, 0.f, 0.f, 0.f}, z2 = {0.f, 0.f, 0.f, 0.f};
-                z1 = mfma16(rowfrag(kh, 64, yr, 0, g), x1[0], z1);
-                z1 = mfma16(rowfrag(kh, 64, yr, 1, g), x1[1], z1);
-                z2 = mfma16(rowfrag(vh, 64, yr, 0, g), x2[0], z2);
-                z2 = mfma16(rowfrag(vh, 64, yr, 1, g), x2[1], z2);
+                z1 = mfma16(rowfrag(Kr, kst, yr, 0, g), x1[0], z1);
+                z1 = mfma16(rowfrag(Kr, kst, yr, 1, g), x1[1], z1);
+                z2 = mfma16(rowfrag(Vr, vst, yr, 0, g), x2[0], z2);
+                z2 = mfma16(rowfrag(Vr, vst, yr, 1, g), x2[1], z2);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = 16 * yt + 4 * g + r;
@@ -237,8 +274,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
         const int xk = 16 * xt + c16;
         const int xs = xk < N ? xk : N - 1;
         bf16x8 x1[2], x2[2];
-        x1[0] = rowfrag(kh, 64, xs, 0, g); x1[1] = rowfrag(kh, 64, xs, 1, g);
-        x2[0] = rowfrag(vh, 64, xs, 0, g); x2[1] = rowfrag(vh, 64, xs, 1, g);
+        x1[0] = rowfrag(Kr, kst, xs, 0, g); x1[1] = rowfrag(Kr, kst, xs, 1, g);
+        x2[0] = rowfrag(Vr, vst, xs, 0, g); x2[1] = rowfrag(Vr, vst, xs, 1, g);
         f32x4 ok[4], ov[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) { ok[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; ov[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -250,10 +287,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
                 const int yt = 2 * s + half;
                 int yr = 16 * yt + c16; yr = yr < N ? yr : N - 1;
                 f32x4 z1 = {0.f, 0.f, 0.f, 0.f}, z2 = {0.f, 0.f, 0.f, 0.f};
-                z1 = mfma16(rowfrag(qh, 64, yr, 0, g), x1[0], z1);
-                z1 = mfma16(rowfrag(qh, 64, yr, 1, g), x1[1], z1);
-                z2 = mfma16(rowfrag(doh, lddo, yr, 0, g), x2[0], z2);
-                z2 = mfma16(rowfrag(doh, lddo, yr, 1, g), x2[1], z2);
+                z1 = mfma16(rowfrag(Qr, qst, yr, 0, g), x1[0], z1);
+                z1 = mfma16(rowfrag(Qr, qst, yr, 1, g), x1[1], z1);
+                z2 = mfma16(rowfrag(Dr, dst_, yr, 0, g), x2[0], z2);
+                z2 = mfma16(rowfrag(Dr, dst_, yr, 1, g), x2[1], z2);
                 const f32x4 lse_y = *reinterpret_cast<const f32x4*>(lse_s + 16 * yt + 4 * g);
                 const f32x4 del_y = *reinterpret_cast<const f32x4*>(del_s + 16 * yt + 4 * g);
 #pragma unroll
@@ -299,7 +336,7 @@ template <int KT32>
 int launch_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* out, int ldo, const bf16* dout, int lddo,
                const float* lse, bf16* dqkv, int ld, int B, int H, int N, hipStream_t s) {
     constexpr int NPAD = 32 * KT32;
-    const int bytes = 3 * 64 * (NPAD + 4) * 2 + 2 * NPAD * 4;
+    const int bytes = 3 * 64 * (NPAD + 4) * 2 + 2 * NPAD * 4 + (KT32 == 2 ? 4 * NPAD * 72 * 2 : 0);
     static bool attr = false;
     if (!attr && bytes > 48 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<KT32>),

@@ -68,18 +68,38 @@ __global__ void prep_lora_kernel(const float* __restrict__ a1q, const float* __r
 }
 
 // ---------------------------------------------------------------------------------
-// delta-add: one wave = 128 consecutive e of ROWS_PER_WAVE reference rows; each lane keeps the
-// 2 x 32 panel entries of its two columns in registers, t[row] is wave-uniform (scalar loads).
-constexpr int DA_ROWS = 32;
+// delta-add: one wave = 128 consecutive e of DA_ROWS reference rows.  Each lane keeps the 2 x 32
+// panel entries of its two columns in registers; the wave stages its DA_ROWS x 32 slice of t in
+// LDS once (coalesced) and then reads it back with broadcast ds_read_b128 (no bank conflicts:
+// all lanes read the same address).  Rows are processed four at a time so that the four
+// read-modify-write loads of q are in flight together.
+constexpr int DA_ROWS = 64;
 __global__ __launch_bounds__(256) void delta_add_kernel(bf16* qbuf, bf16* vbuf, const float* __restrict__ t,
                                                         const float* __restrict__ q32, const float* __restrict__ bias,
                                                         float ascale, int B, int N, int E) {
-    const int lane = threadIdx.x & 63;
-    const int wg = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    __shared__ __attribute__((aligned(16))) float ts[4][DA_ROWS][32];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int wg = blockIdx.x * 4 + wid;
     const int which = blockIdx.y;                  // 0: q, 1: v
     const int slabs = E / 128;
     const int slab = wg % slabs, rg = wg / slabs;
     const int T = B * N;
+    const int r0 = rg * DA_ROWS;
+    if (r0 >= T) return;                           // whole wave exits together
+    const int nrows = min(DA_ROWS, T - r0);
+    // stage t: lane l loads 16 floats of row (l>>1) + 32*pass, half l&1
+    {
+        const int hf = lane & 1;
+#pragma unroll
+        for (int ps = 0; ps < DA_ROWS / 32; ++ps) {
+            const int rl = (lane >> 1) + 32 * ps;
+            const int rr = r0 + (rl < nrows ? rl : nrows - 1);
+            const float* src = t + (size_t)row_of_ref(rr, B, N) * 64 + which * 32 + hf * 16;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                *reinterpret_cast<float4*>(&ts[wid][rl][hf * 16 + 4 * i]) = *reinterpret_cast<const float4*>(src + 4 * i);
+        }
+    }
     const int e = slab * 128 + lane * 2;
     float q0[32], q1[32];
 #pragma unroll
@@ -90,22 +110,32 @@ __global__ __launch_bounds__(256) void delta_add_kernel(bf16* qbuf, bf16* vbuf, 
         q1[j] = b.x; q1[j + 1] = b.y; q1[j + 2] = b.z; q1[j + 3] = b.w;
     }
     const float b0 = bias ? bias[e] : 0.f, b1 = bias ? bias[e + 1] : 0.f;
-    bf16* buf = which ? vbuf : qbuf;
-    const int rr_end = min((rg + 1) * DA_ROWS, T);
-    for (int rr = rg * DA_ROWS; rr < rr_end; ++rr) {
-        const float* tr = t + (size_t)row_of_ref(rr, B, N) * 64 + which * 32;
-        float d0 = 0.f, d1 = 0.f;
+    bf16* buf = (which ? vbuf : qbuf) + (size_t)r0 * E + e;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int r = 0; r < nrows; r += 4) {
+        bf16x2 cur[4];
 #pragma unroll
-        for (int j = 0; j < 32; ++j) {
-            const float tv = tr[j];
-            d0 = fmaf(tv, q0[j], d0);
-            d1 = fmaf(tv, q1[j], d1);
+        for (int u = 0; u < 4; ++u)
+            if (r + u < nrows) cur[u] = *reinterpret_cast<const bf16x2*>(buf + (size_t)(r + u) * E);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (r + u >= nrows) break;
+            float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 32; j += 4) {
+                const float4 tv = *reinterpret_cast<const float4*>(&ts[wid][r + u][j]);
+                d0 = fmaf(tv.x, q0[j], d0);     d1 = fmaf(tv.x, q1[j], d1);
+                d0 = fmaf(tv.y, q0[j + 1], d0); d1 = fmaf(tv.y, q1[j + 1], d1);
+                d0 = fmaf(tv.z, q0[j + 2], d0); d1 = fmaf(tv.z, q1[j + 2], d1);
+                d0 = fmaf(tv.w, q0[j + 3], d0); d1 = fmaf(tv.w, q1[j + 3], d1);
+            }
+            bf16x2 o;
+            o[0] = f2bf(bf2f(cur[u][0]) + ascale * d0 + b0);
+            o[1] = f2bf(bf2f(cur[u][1]) + ascale * d1 + b1);
+            *reinterpret_cast<bf16x2*>(buf + (size_t)(r + u) * E) = o;
         }
-        bf16x2* p = reinterpret_cast<bf16x2*>(buf + (size_t)rr * E + e);
-        bf16x2 cur = *p;
-        cur[0] = f2bf(bf2f(cur[0]) + ascale * d0 + b0);
-        cur[1] = f2bf(bf2f(cur[1]) + ascale * d1 + b1);
-        *p = cur;
     }
 }
 
@@ -168,72 +198,137 @@ __global__ __launch_bounds__(256) void lowrank_u_kernel(const bf16* __restrict__
 }
 
 // ---------------------------------------------------------------------------------
-// Token-contracted products on the f32 matrix core (v_mfma_f32_32x32x2_f32): both operands
-// are read "down the rows" with lanes along the contiguous dimension, so no transposes.
-//   kind 0: G0 = xn^T u_q, G1 = xn^T u_v      kind 1: G2 = dDq^T t_q (+db)   kind 2: G3 = dDv^T t_v (+db)
-constexpr int LG_ROWS = 256;   // rows per chunk
+// Token-contracted products  G = X^T Y  (contraction over the token rows):
+//   kind 0: X = xn,  Y = [u_q | u_v]  -> G0 = dP_q, G1 = dP_v
+//   kind 1: X = dDelta_q (flat view), Y = t_q  -> G2 = dQ_q  (+ column sums -> d bias)
+//   kind 2: X = dDelta_v,             Y = t_v  -> G3 = dQ_v  (+ column sums)
+// The MFMA wants the contraction index contiguous per lane, but both operands are stored
+// token-major.  One workgroup = (chunk of LG_ROWS tokens, 64 columns e, kind): it reads its
+// X / Y panels with 16-byte coalesced loads, writes them TRANSPOSED into LDS (Xt[e][token],
+// Yt[j][token], bf16, 8-token groups XOR-swizzled by e>>3 so that the scattered 2-byte writes
+// spread over all banks), and then runs 16x16x32 bf16 MFMAs whose fragments are plain
+// ds_read_b128.  One deterministic partial per chunk goes to HBM.
+constexpr int LG_ROWS = 256;
+constexpr int LG_LDT = LG_ROWS + 8;
+__device__ __forceinline__ int lg_col(int row_e, int y) { return y ^ (((row_e >> 3) & 7) << 3); }
+
 __global__ __launch_bounds__(256) void lowrank_grad_kernel(const bf16* __restrict__ xn, int ldx,
                                                            const float* __restrict__ u32,
                                                            const bf16* __restrict__ dqkv, int ld,
                                                            const float* __restrict__ t, float* __restrict__ partial,
                                                            float* __restrict__ dbias_partial, int B, int H, int N,
                                                            int E) {
-    const int lane = threadIdx.x & 63;
-    const int wg = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    const int etiles = E / 32;
-    const int per_chunk = etiles * 3;
-    const int chunk = wg / per_chunk, rem = wg - chunk * per_chunk;
-    const int kind = rem / etiles, et = rem - kind * etiles;
-    const int T = B * N;
-    const int r_begin = chunk * LG_ROWS;
-    if (r_begin >= T) return;
-    const int r_end = min(r_begin + LG_ROWS, T);
-    const int li = lane & 31, lk = lane >> 5;
-    const int e = et * 32 + li;
-    f32x16 acc0, acc1;
+    __shared__ __attribute__((aligned(16))) bf16 Xt[64 * LG_LDT];
+    __shared__ __attribute__((aligned(16))) bf16 Yt[64 * LG_LDT];
+    __shared__ float cs[4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, c16 = lane & 15;
+    const int epairs = E / 64;
+    const int per_chunk = epairs * 3;
+    const int chunk = blockIdx.x / per_chunk, rem = blockIdx.x - chunk * per_chunk;
+    const int kind = rem / epairs, ep = rem - kind * epairs;
+    const int T = B * N, e0 = ep * 64;
+    const int r0 = chunk * LG_ROWS;
+    const int col0 = (kind == 1) ? 0 : 2 * E;
+    const int toff = (kind == 1) ? 0 : 32;
+
+    // ---- issue every global load of the two panels first (the kernel is latency-bound) ------
+    const int c = tid & 7;
+    bf16x8 xv[LG_ROWS / 32];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
-    float colsum = 0.f;
-    if (kind == 0) {
-#pragma unroll 4
-        for (int r = r_begin; r < r_end; r += 2) {
-            const int row = r + lk;
-            const bool ok = row < r_end;
-            const int rs = ok ? row : r_end - 1;
-            const float a = ok ? bf2f(xn[(size_t)rs * ldx + e]) : 0.f;
-            const float bq = u32[(size_t)rs * 64 + li];
-            const float bv = u32[(size_t)rs * 64 + 32 + li];
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc1, 0, 0, 0);
-        }
-    } else {
-        const int col0 = (kind == 1) ? 0 : 2 * E;
-        const int toff = (kind == 1) ? 0 : 32;
-        const int e0 = (e >> 6) << 6, d = e & 63;
-#pragma unroll 4
-        for (int r = r_begin; r < r_end; r += 2) {
-            const int rr = r + lk;
-            const bool ok = rr < r_end;
-            const int rs = ok ? rr : r_end - 1;
-            const float a = ok ? bf2f(ddelta_slab(dqkv, ld, col0, rs, e0, E, H, N)[d]) : 0.f;
-            const float bt = t[(size_t)row_of_ref(rs, B, N) * 64 + toff + li];
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bt, acc0, 0, 0, 0);
-            colsum += a;
+    for (int it = 0; it < LG_ROWS / 32; ++it) {
+        const int r = r0 + (tid >> 3) + 32 * it;
+        xv[it] = zero_bf16x8();
+        if (r < T) {
+            const bf16* src = (kind == 0) ? xn + (size_t)r * ldx + e0 : ddelta_slab(dqkv, ld, col0, r, e0, E, H, N);
+            xv[it] = load_bf16x8(src + 8 * c);
         }
     }
-    // C layout: col j = lane&31, row i = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // Y (f32): kind 0 -> 64 columns of u (16 float4 per row); else 32 columns of t (8 float4 per row)
+    const int sh = (kind == 0) ? 4 : 3;                     // log2(float4 groups per row)
+    const int nY = (kind == 0) ? 16 : 8;                    // loads per thread
+    float4 yv[16];
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        yv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (it < nY) {
+            const int idx = tid + 256 * it;
+            const int y = idx >> sh, c4 = idx & ((1 << sh) - 1);
+            const int r = r0 + y;
+            if (r < T) {
+                const float* src = (kind == 0) ? u32 + (size_t)r * 64 : t + (size_t)row_of_ref(r, B, N) * 64 + toff;
+                yv[it] = *reinterpret_cast<const float4*>(src + 4 * c4);
+            }
+        }
+    }
+    // ---- transposed LDS writes ---------------------------------------------------------------
+    {
+        float colsum[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) colsum[i] = 0.f;
+#pragma unroll
+        for (int it = 0; it < LG_ROWS / 32; ++it) {
+            const int y = (tid >> 3) + 32 * it;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                Xt[(8 * c + i) * LG_LDT + lg_col(8 * c + i, y)] = xv[it][i];
+                colsum[i] += bf2f(xv[it][i]);
+            }
+        }
+        if (kind != 0) {     // column sums: reduce over the 8 row-lanes of this wave, then over waves
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float a = colsum[i];
+                a += __shfl_xor(a, 8, 64); a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+                if ((lane >> 3) == 0) cs[wid][8 * c + i] = a;
+            }
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        if (it < nY) {
+            const int idx = tid + 256 * it;
+            const int y = idx >> sh, j = 4 * (idx & ((1 << sh) - 1));
+            Yt[(j + 0) * LG_LDT + lg_col(j + 0, y)] = f2bf(yv[it].x);
+            Yt[(j + 1) * LG_LDT + lg_col(j + 1, y)] = f2bf(yv[it].y);
+            Yt[(j + 2) * LG_LDT + lg_col(j + 2, y)] = f2bf(yv[it].z);
+            Yt[(j + 3) * LG_LDT + lg_col(j + 3, y)] = f2bf(yv[it].w);
+        }
+    }
+    __syncthreads();
+
+    // ---- MFMA: wave w owns rows e = 16w..16w+15 of the 64 x (64|32) tile
+    const int NT = (kind == 0) ? 4 : 2;
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ea = 16 * wid + c16;
+#pragma unroll
+    for (int ks = 0; ks < LG_ROWS / 32; ++ks) {
+        const int y0 = 32 * ks + 8 * g;
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(Xt + ea * LG_LDT + lg_col(ea, y0));
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            if (nt < NT) {
+                const int jb = 16 * nt + c16;
+                const bf16x8 b = *reinterpret_cast<const bf16x8*>(Yt + jb * LG_LDT + lg_col(jb, y0));
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[nt], 0, 0, 0);
+            }
+        }
+    }
+    // C layout: col j = 16nt + c16, rows e = 16w + 4g + reg
     const size_t plane = (size_t)E * 32;
-    float* out0 = partial + ((size_t)chunk * 4 + (kind == 0 ? 0 : kind + 1)) * plane;
+    float* base = partial + ((size_t)chunk * 4 + (kind == 0 ? 0 : kind + 1)) * plane;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int i = (r & 3) + 8 * (r >> 2) + 4 * lk;
-        out0[(size_t)(et * 32 + i) * 32 + li] = acc0[r];
-        if (kind == 0) out0[plane + (size_t)(et * 32 + i) * 32 + li] = acc1[r];
+    for (int nt = 0; nt < 4; ++nt) {
+        if (nt < NT) {
+            float* out = base + (nt >> 1) * plane;           // kind 0: j-tiles 2,3 are the u_v plane
+            const int j = 16 * (nt & 1) + c16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(size_t)(e0 + 16 * wid + 4 * g + r) * 32 + j] = acc[nt][r];
+        }
     }
-    if (kind != 0) {
-        colsum += __shfl_xor(colsum, 32, 64);
-        if (lk == 0) dbias_partial[((size_t)chunk * 2 + (kind - 1)) * E + e] = colsum;
-    }
+    if (kind != 0 && tid < 64)
+        dbias_partial[((size_t)chunk * 2 + (kind - 1)) * E + e0 + tid] = cs[0][tid] + cs[1][tid] + cs[2][tid] + cs[3][tid];
 }
 
 // sum the per-chunk partials: G[4][E][32], and the bias gradient
@@ -242,9 +337,16 @@ __global__ void lowrank_reduce_kernel(const float* __restrict__ partial, const f
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int total = 4 * E * 32;
     if (idx < total) {
-        float s = 0.f;
-        for (int c = 0; c < chunks; ++c) s += partial[(size_t)c * total + idx];
-        G[idx] = s;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;     // fixed summation tree: deterministic
+        int c = 0;
+        for (; c + 3 < chunks; c += 4) {
+            s0 += partial[(size_t)c * total + idx];
+            s1 += partial[(size_t)(c + 1) * total + idx];
+            s2 += partial[(size_t)(c + 2) * total + idx];
+            s3 += partial[(size_t)(c + 3) * total + idx];
+        }
+        for (; c < chunks; ++c) s0 += partial[(size_t)c * total + idx];
+        G[idx] = (s0 + s1) + (s2 + s3);
     }
     if (g_b && idx < E) {
         float s = 0.f;
@@ -349,8 +451,8 @@ int pevit_launch_lowrank_grad(const bf16* xn, int ldx, const float* u32, const b
                               hipStream_t s) {
     const int T = B * N;
     if (chunks != ceil_div(T, LG_ROWS)) { pevit_set_error("lowrank_grad: chunks mismatch"); return -1; }
-    const int waves = chunks * (E / 32) * 3;
-    hipLaunchKernelGGL(lowrank_grad_kernel, dim3(ceil_div(waves, 4)), dim3(256), 0, s, xn, ldx, u32, dqkv, ld, t,
+    if (E % 64) { pevit_set_error("lowrank_grad: width %d must be a multiple of 64", E); return -1; }
+    hipLaunchKernelGGL(lowrank_grad_kernel, dim3(chunks * (E / 64) * 3), dim3(256), 0, s, xn, ldx, u32, dqkv, ld, t,
                        partial, dbias_partial, B, H, N, E);
     return 0;
 }

@@ -53,112 +53,162 @@ __global__ void cls_row_kernel(const float* __restrict__ cls, const float* __res
 }
 
 // ---- head -------------------------------------------------------------------------
-// one thread per feature d: batch statistics (training) or running statistics (eval)
-__global__ void bn_fwd_kernel(const float* __restrict__ feat, float* __restrict__ y, float* __restrict__ rstd_out,
-                              float* running_mean, float* running_var, int training, int B, int D) {
-    const int d = blockIdx.x * blockDim.x + threadIdx.x;
-    if (d >= D) return;
+// BatchNorm1d(D, affine=False): one workgroup per 64 features, lanes = features (coalesced rows),
+// the 4 waves split the batch and combine through LDS.
+__global__ __launch_bounds__(256) void bn_fwd_kernel(const float* __restrict__ feat, float* __restrict__ y,
+                                                     float* __restrict__ rstd_out, float* running_mean,
+                                                     float* running_var, int training, int B, int D) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int d = blockIdx.x * 64 + lane;
+    const bool ok = d < D;
     float mean, var;
     if (training) {
         float s = 0.f;
-        for (int b = 0; b < B; ++b) s += feat[(size_t)b * D + d];
-        mean = s / (float)B;
+        for (int b = wid; b < B; b += 4) s += ok ? feat[(size_t)b * D + d] : 0.f;
+        red[wid][lane] = s;
+        __syncthreads();
+        mean = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)B;
+        __syncthreads();
         float q = 0.f;
-        for (int b = 0; b < B; ++b) { const float t = feat[(size_t)b * D + d] - mean; q += t * t; }
-        var = q / (float)B;                                   // biased: used for normalisation
-        const float unbiased = B > 1 ? q / (float)(B - 1) : var;
-        running_mean[d] = 0.9f * running_mean[d] + 0.1f * mean;
-        running_var[d] = 0.9f * running_var[d] + 0.1f * unbiased;
+        for (int b = wid; b < B; b += 4) { const float t = ok ? feat[(size_t)b * D + d] - mean : 0.f; q += t * t; }
+        red[wid][lane] = q;
+        __syncthreads();
+        const float qq = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+        var = qq / (float)B;                                   // biased: used for normalisation
+        if (wid == 0 && ok) {
+            const float unbiased = B > 1 ? qq / (float)(B - 1) : var;
+            running_mean[d] = 0.9f * running_mean[d] + 0.1f * mean;
+            running_var[d] = 0.9f * running_var[d] + 0.1f * unbiased;
+        }
     } else {
-        mean = running_mean[d]; var = running_var[d];
+        mean = ok ? running_mean[d] : 0.f; var = ok ? running_var[d] : 1.f;
     }
     const float rstd = rsqrtf(var + 1e-5f);
-    rstd_out[d] = rstd;
-    for (int b = 0; b < B; ++b) y[(size_t)b * D + d] = (feat[(size_t)b * D + d] - mean) * rstd;
-}
-
-// logits[b][c] = y[b] . W[c] + bias[c]
-__global__ void linear_fwd_kernel(const float* __restrict__ y, const float* __restrict__ W, const float* __restrict__ bias,
-                                  float* __restrict__ logits, int B, int D, int Cc) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= B * Cc) return;
-    const int b = idx / Cc, c = idx - b * Cc;
-    const float* yr = y + (size_t)b * D; const float* wr = W + (size_t)c * D;
-    float acc = 0.f;
-    for (int d = 0; d < D; ++d) acc = fmaf(yr[d], wr[d], acc);
-    logits[idx] = acc + bias[c];
-}
-
-// single block: per-row log-softmax, mean loss, dlogits = (softmax - onehot)/B
-__global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
-                                                 float* __restrict__ dlogits, float* __restrict__ loss, int B, int Cc) {
-    __shared__ float part[4];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    float acc = 0.f;
-    for (int b = wid; b < B; b += 4) {
-        const float* lr = logits + (size_t)b * Cc;
-        float m = -3.0e38f;
-        for (int c = lane; c < Cc; c += 64) m = fmaxf(m, lr[c]);
-        m = wave_max(m);
-        float s = 0.f;
-        for (int c = lane; c < Cc; c += 64) s += __expf(lr[c] - m);
-        s = wave_sum(s);
-        const float lse = m + __logf(s);
-        const int lab = (int)labels[b];
-        for (int c = lane; c < Cc; c += 64) {
-            const float p = __expf(lr[c] - lse);
-            dlogits[(size_t)b * Cc + c] = (p - (c == lab ? 1.f : 0.f)) / (float)B;
-        }
-        if (lane == 0) acc += lse - lr[lab];
-    }
-    if (lane == 0) part[wid] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) loss[0] = (part[0] + part[1] + part[2] + part[3]) / (float)B;
-}
-
-// gW[c][d] += sum_b dl[b][c] y[b][d] ; gb[c] += sum_b dl[b][c]
-__global__ void linear_wgrad_kernel(const float* __restrict__ dl, const float* __restrict__ y, float* gW, float* gb,
-                                    int B, int D, int Cc) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < Cc * D) {
-        const int c = idx / D, d = idx - c * D;
-        float acc = 0.f;
-        for (int b = 0; b < B; ++b) acc = fmaf(dl[(size_t)b * Cc + c], y[(size_t)b * D + d], acc);
-        gW[idx] += acc;
-    }
-    if (idx < Cc) {
-        float acc = 0.f;
-        for (int b = 0; b < B; ++b) acc += dl[(size_t)b * Cc + idx];
-        gb[idx] += acc;
-    }
-}
-
-// dy[b][d] = sum_c dl[b][c] W[c][d]
-__global__ void linear_dgrad_kernel(const float* __restrict__ dl, const float* __restrict__ W, float* __restrict__ dy,
-                                    int B, int D, int Cc) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= B * D) return;
-    const int b = idx / D, d = idx - b * D;
-    float acc = 0.f;
-    for (int c = 0; c < Cc; ++c) acc = fmaf(dl[(size_t)b * Cc + c], W[(size_t)c * D + d], acc);
-    dy[idx] = acc;
+    if (wid == 0 && ok) rstd_out[d] = rstd;
+    if (ok) for (int b = wid; b < B; b += 4) y[(size_t)b * D + d] = (feat[(size_t)b * D + d] - mean) * rstd;
 }
 
 // dfeat = rstd * (dy - mean_b(dy) - yhat * mean_b(dy*yhat))   (training) ;  rstd * dy (eval)
-__global__ void bn_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ yhat, const float* __restrict__ rstd,
-                              float* __restrict__ dfeat, int training, int B, int D) {
-    const int d = blockIdx.x * blockDim.x + threadIdx.x;
-    if (d >= D) return;
-    const float r = rstd[d];
+__global__ __launch_bounds__(256) void bn_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ yhat,
+                                                     const float* __restrict__ rstd, float* __restrict__ dfeat,
+                                                     int training, int B, int D) {
+    __shared__ float red[2][4][64];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int d = blockIdx.x * 64 + lane;
+    const bool ok = d < D;
     float m1 = 0.f, m2 = 0.f;
     if (training) {
-        for (int b = 0; b < B; ++b) { const float g = dy[(size_t)b * D + d]; m1 += g; m2 += g * yhat[(size_t)b * D + d]; }
-        m1 /= (float)B; m2 /= (float)B;
+        float a = 0.f, c = 0.f;
+        for (int b = wid; b < B; b += 4)
+            if (ok) { const float g = dy[(size_t)b * D + d]; a += g; c += g * yhat[(size_t)b * D + d]; }
+        red[0][wid][lane] = a; red[1][wid][lane] = c;
+        __syncthreads();
+        m1 = (red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane]) / (float)B;
+        m2 = (red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane]) / (float)B;
     }
-    for (int b = 0; b < B; ++b) {
+    if (!ok) return;
+    const float r = rstd[d];
+    for (int b = wid; b < B; b += 4) {
         const float g = dy[(size_t)b * D + d];
         dfeat[(size_t)b * D + d] = training ? r * (g - m1 - yhat[(size_t)b * D + d] * m2) : r * g;
     }
+}
+
+// Small dense products of the head on the f32 matrix core (exact f32, like the reference's head):
+//   C[i][j] (+)= sum_k A[i*sAi + k*sAk] * B[k*sBk + j*sBj]  (+ bias[j]) ; optional colsum of A.
+// One workgroup per 32x32 output tile; its 4 waves split K and combine through LDS.
+struct SmallGemm {
+    const float* A; long sAi, sAk;
+    const float* B; long sBk, sBj;
+    float* C; long ldc;
+    const float* bias;       // per column j, or null
+    float* rowsumA;          // rowsumA[i] += sum_k A(i,k)   (written by the j-tile 0 workgroups), or null
+    int M, N, K, accumulate;
+};
+__global__ __launch_bounds__(256) void small_gemm_kernel(SmallGemm p) {
+    __shared__ float red[3][64][17];
+    __shared__ float rs[3][64];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, li = lane & 31, lk = lane >> 5;
+    const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+    const int i = i0 + li, j = j0 + li;
+    const bool iok = i < p.M, jok = j < p.N;
+    const float* ap = p.A + (long)(iok ? i : 0) * p.sAi;
+    const float* bp = p.B + (long)(jok ? j : 0) * p.sBj;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float rsum = 0.f;
+    // wave w takes k-pairs w, w+4, ... ; 8 pairs are loaded ahead of their MFMAs
+    const int npairs = (p.K + 1) / 2;
+    for (int pb = wid; pb < npairs; pb += 32) {
+        float a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = 2 * (pb + 4 * u) + lk;
+            const bool kok = (pb + 4 * u) < npairs && k < p.K;
+            a[u] = (kok && iok) ? ap[(long)k * p.sAk] : 0.f;
+            b[u] = (kok && jok) ? bp[(long)k * p.sBk] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+            rsum += a[u];
+        }
+    }
+    if (wid > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wid - 1][lane][r] = acc[r];
+        rs[wid - 1][lane] = rsum;
+    }
+    __syncthreads();
+    if (wid != 0) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float v = acc[r] + red[0][lane][r] + red[1][lane][r] + red[2][lane][r];
+        const int oi = i0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (oi < p.M && jok) {
+            float* c = p.C + (long)oi * p.ldc + j;
+            const float bv = p.bias ? p.bias[j] : 0.f;
+            *c = (p.accumulate ? *c : 0.f) + v + bv;
+        }
+    }
+    if (p.rowsumA && blockIdx.x == 0) {
+        rsum += rs[0][lane] + rs[1][lane] + rs[2][lane];
+        rsum += __shfl_xor(rsum, 32, 64);
+        if (lk == 0 && iok) p.rowsumA[i] += rsum;
+    }
+}
+
+// one wave per row: log-softmax, row loss, dlogits = (softmax - onehot)/B
+__global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                 float* __restrict__ dlogits, float* __restrict__ rowloss, int B,
+                                                 int Cc) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const float* lr = logits + (size_t)b * Cc;
+    float m = -3.0e38f;
+    for (int c = lane; c < Cc; c += 64) m = fmaxf(m, lr[c]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int c = lane; c < Cc; c += 64) s += __expf(lr[c] - m);
+    s = wave_sum(s);
+    const float lse = m + __logf(s);
+    const int lab = (int)labels[b];
+    for (int c = lane; c < Cc; c += 64) {
+        const float pr = __expf(lr[c] - lse);
+        dlogits[(size_t)b * Cc + c] = (pr - (c == lab ? 1.f : 0.f)) / (float)B;
+    }
+    if (lane == 0) rowloss[b] = lse - lr[lab];
+}
+
+// loss = mean(rowloss): one wave, fixed summation order
+__global__ void loss_mean_kernel(const float* __restrict__ rowloss, float* __restrict__ loss, int B) {
+    float s = 0.f;
+    for (int b = threadIdx.x; b < B; b += 64) s += rowloss[b];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) loss[0] = s / (float)B;
 }
 
 }  // namespace
@@ -180,15 +230,24 @@ int pevit_launch_cls_row(const float* cls, const float* pos, float* x, int B, in
 int pevit_launch_head(const float* feat, const int64_t* labels, const float* W, const float* bias, float* gW, float* gb,
                       float* running_mean, float* running_var, int training, float* ybn, float* rstd, float* logits,
                       float* dlogits, float* dybn, float* loss, float* dfeat, int B, int D, int Cc, hipStream_t s) {
-    hipLaunchKernelGGL(bn_fwd_kernel, dim3(ceil_div(D, 64)), dim3(64), 0, s, feat, ybn, rstd, running_mean, running_var,
+    hipLaunchKernelGGL(bn_fwd_kernel, dim3(ceil_div(D, 64)), dim3(256), 0, s, feat, ybn, rstd, running_mean, running_var,
                        training, B, D);
-    hipLaunchKernelGGL(linear_fwd_kernel, dim3(ceil_div(B * Cc, 256)), dim3(256), 0, s, ybn, W, bias, logits, B, D, Cc);
+    {   // logits[b][c] = ybn[b] . W[c] + bias[c]
+        SmallGemm g{ybn, D, 1, W, 1, D, logits, Cc, bias, nullptr, B, Cc, D, 0};
+        hipLaunchKernelGGL(small_gemm_kernel, dim3(ceil_div(Cc, 32), ceil_div(B, 32)), dim3(256), 0, s, g);
+    }
     if (!labels) return 0;
-    hipLaunchKernelGGL(ce_kernel, dim3(1), dim3(256), 0, s, logits, labels, dlogits, loss, B, Cc);
-    if (gW) hipLaunchKernelGGL(linear_wgrad_kernel, dim3(ceil_div(Cc * D, 256)), dim3(256), 0, s, dlogits, ybn, gW, gb, B, D, Cc);
-    if (dfeat) {
-        hipLaunchKernelGGL(linear_dgrad_kernel, dim3(ceil_div(B * D, 256)), dim3(256), 0, s, dlogits, W, dybn, B, D, Cc);
-        hipLaunchKernelGGL(bn_bwd_kernel, dim3(ceil_div(D, 64)), dim3(64), 0, s, dybn, ybn, rstd, dfeat, training, B, D);
+    float* rowloss = dybn;      // dybn is written later (by the dgrad product); reuse its head as scratch
+    hipLaunchKernelGGL(ce_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, s, logits, labels, dlogits, rowloss, B, Cc);
+    hipLaunchKernelGGL(loss_mean_kernel, dim3(1), dim3(64), 0, s, rowloss, loss, B);
+    if (gW) {   // gW[c][d] += sum_b dl[b][c] ybn[b][d] ; gb[c] += sum_b dl[b][c]
+        SmallGemm g{dlogits, 1, Cc, ybn, D, 1, gW, D, nullptr, gb, Cc, D, B, 1};
+        hipLaunchKernelGGL(small_gemm_kernel, dim3(ceil_div(D, 32), ceil_div(Cc, 32)), dim3(256), 0, s, g);
+    }
+    if (dfeat) {   // dybn[b][d] = sum_c dl[b][c] W[c][d]
+        SmallGemm g{dlogits, Cc, 1, W, D, 1, dybn, D, nullptr, nullptr, B, D, Cc, 0};
+        hipLaunchKernelGGL(small_gemm_kernel, dim3(ceil_div(D, 32), ceil_div(B, 32)), dim3(256), 0, s, g);
+        hipLaunchKernelGGL(bn_bwd_kernel, dim3(ceil_div(D, 64)), dim3(256), 0, s, dybn, ybn, rstd, dfeat, training, B, D);
     }
     return 0;
 }

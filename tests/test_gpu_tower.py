@@ -87,8 +87,8 @@ def test_sgd_trajectory_matches_reference_fixture(case):
         if name in none:      # never updated: torch skips params without grad, even with weight decay
             assert torch.equal(p.cpu(), t["adapter/" + name]), name
             continue
-        assert rel_err(p.cpu(), t[key]) < 5e-2, (name, rel_err(p.cpu(), t[key]))
-    assert rel_err(eng.running_mean.cpu(), t["bn_mean"]) < 2e-2
+        assert rel_err(p.cpu(), t[key]) < 8e-2, (name, rel_err(p.cpu(), t[key]))
+    assert rel_err(eng.running_mean.cpu(), t["bn_mean"]) < 3e-2
     assert rel_err(eng.running_var.cpu(), t["bn_var"]) < 5e-2
 
 
