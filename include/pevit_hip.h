@@ -119,6 +119,11 @@ int pevit_train_forward_backward(pevit_ctx* ctx, void* stream, const float* imag
                                  float* running_mean, float* running_var, int bn_training, float* logits,
                                  float* loss, int batch);
 
+/* ---- measurement: HIP events around every MFMA GEMM launch of the context (the dominant kernel
+ * family); totals over the launches recorded between begin and end ---------------------------- */
+int pevit_profile_begin(pevit_ctx* ctx, int max_launches);
+int pevit_profile_end(pevit_ctx* ctx, double* total_ms, double* total_flops, int* launches);
+
 /* ---- single kernels, exposed for parity tests and profiling ------------------------- */
 int pevit_op_gemm(void* stream, int epilogue, const void* A_bf16, int lda, const void* B_bf16, int ldb, int b_rows,
                   int M, int N, int K, const float* bias, const float* resid, int ldr, float* out_f32, int ldo,
@@ -140,6 +145,9 @@ int pevit_op_lowrank_u(void* stream, const void* dqkv, int ld, const void* qT, f
 int pevit_op_lowrank_grad(void* stream, const void* xn, int ldx, const float* u32, const void* dqkv, int ld,
                           const float* t, float* partial, float* dbias_partial, int B, int H, int N, int E);
 int pevit_op_lowrank_chunks(int T);
+/* tuning knobs for A/B measurements ("gemm_config": -1 = per-problem heuristic, 0..4 = force a tile shape);
+ * returns the previous value, or a negative value for an unknown key */
+int pevit_tune(const char* key, int value);
 
 #ifdef __cplusplus
 }

@@ -62,6 +62,7 @@ struct pevit_ctx {
     // workspace
     LayerSaved* sav = nullptr;
     size_t w_xfinal, w_xn2, w_g, w_dqkv, w_u32, w_dO, w_dh, w_dxn, w_dxa, w_dxb, w_dyb, w_partial, w_dbias;
+    size_t w_G, w_rule, partial_layer, dbias_layer;
     size_t w_patches, w_xpost, w_feat, w_pmean, w_prstd, w_ybn, w_bnrstd, w_logits, w_dlogits, w_dybn, w_dfeat,
         w_dfeatb, w_dxpost;
     size_t ws_bytes_for_max = 0;
@@ -74,6 +75,11 @@ struct pevit_ctx {
     size_t p_layer0 = 0, p_layer_stride = 0;     // offsets in floats
     size_t p_head_w = 0, p_head_b = 0;
     int saved_batch = 0;
+    // optional per-GEMM timing (HIP events on the caller's stream), see pevit_profile_begin
+    bool prof_on = false;
+    int prof_n = 0, prof_cap = 0;
+    hipEvent_t* prof_ev = nullptr;      // 2 per launch
+    double* prof_flops = nullptr;
 };
 
 namespace {
@@ -112,8 +118,12 @@ void layout_workspace(pevit_ctx* c, int B, LayerSaved* sav, size_t* total, pevit
     o = cv.take(T * E * 4);                 if (fill) fill->w_dxa = o;
     o = cv.take(T * E * 4);                 if (fill) fill->w_dxb = o;
     o = cv.take(T * E * 2);                 if (fill) fill->w_dyb = o;
-    o = cv.take((size_t)(chunks + 1) * 4 * E * 32 * 4);  if (fill) fill->w_partial = o;
-    o = cv.take((size_t)chunks * 2 * E * 4);             if (fill) fill->w_dbias = o;
+    // adapter-gradient partials of every layer (reduced once per step, after the layer loop)
+    const size_t part_layer = align_up((size_t)chunks * 4 * E * 32 * 4, 256), db_layer = align_up((size_t)chunks * 2 * E * 4, 256);
+    o = cv.take(part_layer * c->L);                      if (fill) { fill->w_partial = o; fill->partial_layer = part_layer; }
+    o = cv.take(db_layer * c->L);                        if (fill) { fill->w_dbias = o; fill->dbias_layer = db_layer; }
+    o = cv.take((size_t)c->L * 4 * E * 32 * 4);          if (fill) fill->w_G = o;
+    o = cv.take((size_t)c->L * 4096 * 4);                if (fill) fill->w_rule = o;
     const size_t Bz = (size_t)B, D = c->D, Cc = c->C;
     o = cv.take(Bz * c->G2 * (size_t)c->Kpatch * 2);      if (fill) fill->w_patches = o;
     o = cv.take(Bz * E * 2);      if (fill) fill->w_xpost = o;
@@ -209,6 +219,9 @@ extern "C" int pevit_ctx_create(const pevit_dims* dims, pevit_ctx** out) {
 
 extern "C" void pevit_ctx_destroy(pevit_ctx* c) {
     if (!c) return;
+    for (int i = 0; i < 2 * c->prof_cap; ++i) (void)hipEventDestroy(c->prof_ev[i]);
+    delete[] c->prof_ev;
+    delete[] c->prof_flops;
     delete[] c->blk;
     delete[] c->sav;
     delete c;
@@ -313,21 +326,35 @@ AdapterPanels panels(pevit_ctx* c, int l) {
     return p;
 }
 
-// rebuild the bf16 adapter panels of every layer from the f32 master parameters
+// rebuild the bf16 adapter panels of every layer from the f32 master parameters (one launch)
 int prep_adapters(pevit_ctx* c, hipStream_t s) {
     const size_t E = c->E;
-    for (int l = 0; l < c->L; ++l) {
-        const float* lp = c->params + c->p_layer0 + c->p_layer_stride * l;
-        if (c->d.method == PEVIT_KADAPTATION) {
-            const float* r = c->params;
-            CHECK(pevit_launch_prep_kadapt(r, r + 1024, r + 2048, r + 3072, lp, lp + E, panels(c, l), c->E, c->ascale, s));
-        } else if (c->d.method == PEVIT_LORA) {
-            const size_t rE = (size_t)c->d.lora_rank * E;
-            CHECK(pevit_launch_prep_lora(lp, lp + rE, lp + 2 * rE, lp + 3 * rE, c->d.lora_rank, panels(c, l), c->E,
-                                         c->ascale, s));
-        }
+    LayerStrides st;
+    st.arena_bytes = c->L > 1 ? c->blk[1].wqkv - c->blk[0].wqkv : 0;
+    st.param_floats = c->p_layer_stride;
+    const float* lp = c->params + c->p_layer0;
+    if (c->d.method == PEVIT_KADAPTATION) {
+        const float* r = c->params;
+        CHECK(pevit_launch_prep_kadapt(r, r + 1024, r + 2048, r + 3072, lp, lp + E, panels(c, 0), c->E, c->ascale, c->L, st, s));
+    } else if (c->d.method == PEVIT_LORA) {
+        const size_t rE = (size_t)c->d.lora_rank * E;
+        CHECK(pevit_launch_prep_lora(lp, lp + rE, lp + 2 * rE, lp + 3 * rE, c->d.lora_rank, panels(c, 0), c->E, c->ascale,
+                                     c->L, st, s));
     }
     return 0;
+}
+
+// every GEMM of the step goes through here so that it can be bracketed with HIP events
+int gemm(pevit_ctx* c, int epi, const GemmParams& p, hipStream_t s) {
+    const bool rec = c->prof_on && c->prof_n < c->prof_cap;
+    if (rec) (void)hipEventRecord(c->prof_ev[2 * c->prof_n], s);
+    const int rc = pevit_launch_gemm(epi, p, s);
+    if (rec) {
+        (void)hipEventRecord(c->prof_ev[2 * c->prof_n + 1], s);
+        c->prof_flops[c->prof_n] = 2.0 * (double)p.M * (double)p.N * (double)p.K;
+        ++c->prof_n;
+    }
+    return rc;
 }
 
 GemmParams gp(const bf16* A, int lda, const bf16* B, int ldb, int Nb, int M, int N, int K) {
@@ -359,7 +386,7 @@ int blocks_forward(pevit_ctx* c, hipStream_t s, int B) {
             GemmParams p = gp(at<bf16>(W, v.xn1), E, at<bf16>(A, b.wqkv), E, c->NQpad, T, site ? c->NQ : 3 * E, E);
             p.bias = at<float>(A, b.bqkv); p.outb = qkv; p.head_stride = plane; p.outf = at<float>(W, v.t); p.ldo = 64;
             p.E = E; p.H = H; p.Ntok = N;
-            CHECK(pevit_launch_gemm(EPI_QKV_HEADS, p, s));
+            CHECK(gemm(c, EPI_QKV_HEADS, p, s));
         }
         if (site) {
             const float* bias = nullptr;
@@ -372,7 +399,7 @@ int blocks_forward(pevit_ctx* c, hipStream_t s, int B) {
         {
             GemmParams p = gp(at<bf16>(W, v.attn_out), E, at<bf16>(A, b.wo), E, E, T, E, E);
             p.bias = at<float>(A, b.bo); p.resid = x_in; p.ldr = E; p.outf = x_mid; p.ldo = E;
-            CHECK(pevit_launch_gemm(EPI_BIAS_RESID_F32, p, s));
+            CHECK(gemm(c, EPI_BIAS_RESID_F32, p, s));
         }
         // x = x + mlp(ln_2(x))                                          model.py:974
         CHECK(pevit_launch_ln_fwd(x_mid, at<float>(A, b.ln2w), at<float>(A, b.ln2b), T, E, at<bf16>(W, c->w_xn2), nullptr,
@@ -381,12 +408,12 @@ int blocks_forward(pevit_ctx* c, hipStream_t s, int B) {
             GemmParams p = gp(at<bf16>(W, c->w_xn2), E, at<bf16>(A, b.wfc), E, 4 * E, T, 4 * E, E);
             p.bias = at<float>(A, b.bfc); p.outb = at<bf16>(W, v.h); p.ldob = 4 * E; p.outb2 = at<bf16>(W, c->w_g);
             p.ldob2 = 4 * E;
-            CHECK(pevit_launch_gemm(EPI_BIAS_GELU, p, s));
+            CHECK(gemm(c, EPI_BIAS_GELU, p, s));
         }
         {
             GemmParams p = gp(at<bf16>(W, c->w_g), 4 * E, at<bf16>(A, b.wpr), 4 * E, E, T, E, 4 * E);
             p.bias = at<float>(A, b.bpr); p.resid = x_mid; p.ldr = E; p.outf = x_out; p.ldo = E;
-            CHECK(pevit_launch_gemm(EPI_BIAS_RESID_F32, p, s));
+            CHECK(gemm(c, EPI_BIAS_RESID_F32, p, s));
         }
     }
     return 0;
@@ -413,12 +440,12 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0) {
         {
             GemmParams p = gp(dyb, E, at<bf16>(A, b.wprT), E, 4 * E, T, 4 * E, E);
             p.aux = at<bf16>(W, v.h); p.ldaux = 4 * E; p.outb = at<bf16>(W, c->w_dh); p.ldob = 4 * E;
-            CHECK(pevit_launch_gemm(EPI_DGELU_BF16, p, s));
+            CHECK(gemm(c, EPI_DGELU_BF16, p, s));
         }
         {
             GemmParams p = gp(at<bf16>(W, c->w_dh), 4 * E, at<bf16>(A, b.wfcT), 4 * E, E, T, E, 4 * E);
             p.outf = dxn; p.ldo = E;
-            CHECK(pevit_launch_gemm(EPI_F32, p, s));
+            CHECK(gemm(c, EPI_F32, p, s));
         }
         CHECK(pevit_launch_ln_bwd(dxn, at<float>(W, v.x_mid), at<float>(W, v.mean2), at<float>(W, v.rstd2),
                                   at<float>(A, b.ln2w), dxa, dxb, dyb, T, E, s));
@@ -426,34 +453,32 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0) {
         {
             GemmParams p = gp(dyb, E, at<bf16>(A, b.woT), E, E, T, E, E);
             p.outb = at<bf16>(W, c->w_dO); p.ldob = E;
-            CHECK(pevit_launch_gemm(EPI_BF16, p, s));
+            CHECK(gemm(c, EPI_BF16, p, s));
         }
         CHECK(pevit_launch_attn_bwd(qkv, qkv + plane, qkv + 2 * plane, at<bf16>(W, v.attn_out), E, at<bf16>(W, c->w_dO), E,
                                     at<float>(W, v.lse), dqkv, c->NQ, B, H, N, s));
         if (site) {
             CHECK(pevit_launch_lowrank_u(dqkv, c->NQ, at<bf16>(A, b.qT), at<float>(W, c->w_u32), dqkv + 3 * E, B, H, N, E, s));
             CHECK(pevit_launch_lowrank_grad(at<bf16>(W, v.xn1), E, at<float>(W, c->w_u32), dqkv, c->NQ, at<float>(W, v.t),
-                                            at<float>(W, c->w_partial), at<float>(W, c->w_dbias), chunks, B, H, N, E, s));
-            float* lg = c->grads + c->p_layer0 + c->p_layer_stride * l;
-            const float* lp = c->params + c->p_layer0 + c->p_layer_stride * l;
-            if (c->d.method == PEVIT_KADAPTATION) {
-                const float* r = c->params; float* g = c->grads;
-                CHECK(pevit_launch_chain_kadapt(at<float>(W, c->w_partial), at<float>(W, c->w_dbias), chunks, c->ascale, r,
-                                                r + 1024, r + 2048, r + 3072, lp, lp + E, g, g + 1024, g + 2048, g + 3072,
-                                                lg, lg + E, lg + 4 * (size_t)E, E, s));
-            } else {
-                const size_t rE = (size_t)c->d.lora_rank * E;
-                CHECK(pevit_launch_chain_lora(at<float>(W, c->w_partial), chunks, c->ascale, c->d.lora_rank, lg, lg + rE,
-                                              lg + 2 * rE, lg + 3 * rE, E, s));
-            }
+                                            at<float>(W, c->w_partial + (size_t)l * c->partial_layer),
+                                            at<float>(W, c->w_dbias + (size_t)l * c->dbias_layer), chunks, B, H, N, E, s));
         }
         if (l > 0 || need_dx0) {
             GemmParams p = gp(dqkv, c->NQ, at<bf16>(A, b.wqkvT), c->NQ, E, T, E, site ? c->NQ : 3 * E);
             p.outf = dxn; p.ldo = E;
-            CHECK(pevit_launch_gemm(EPI_F32, p, s));
+            CHECK(gemm(c, EPI_F32, p, s));
             CHECK(pevit_launch_ln_bwd(dxn, at<float>(W, v.x_in), at<float>(W, v.mean1), at<float>(W, v.rstd1),
                                       at<float>(A, b.ln1w), dxb, dxa, dyb, T, E, s));
         }
+    }
+    // adapter gradients of all layers: reduce the partials and chain onto the reference's tensors
+    if (c->d.method == PEVIT_KADAPTATION) {
+        CHECK(pevit_launch_chain_kadapt(at<float>(W, c->w_partial), c->partial_layer / 4, at<float>(W, c->w_dbias),
+                                        c->dbias_layer / 4, chunks, c->ascale, c->L, at<float>(W, c->w_G),
+                                        at<float>(W, c->w_rule), c->params, c->grads, c->p_layer0, c->p_layer_stride, E, s));
+    } else if (c->d.method == PEVIT_LORA) {
+        CHECK(pevit_launch_chain_lora(at<float>(W, c->w_partial), c->partial_layer / 4, chunks, c->ascale, c->d.lora_rank,
+                                      c->L, at<float>(W, c->w_G), c->grads, c->p_layer0, c->p_layer_stride, E, s));
     }
     return 0;
 }
@@ -544,7 +569,7 @@ extern "C" int pevit_visual_forward(pevit_ctx* c, void* stream, const float* ima
     {
         GemmParams p = gp(at<bf16>(W, c->w_patches), c->Kpatch, at<bf16>(A, c->a_conv), c->Kpatch, E, B * c->G2, E, c->Kpatch);
         p.resid = at<float>(A, c->a_pos); p.ldr = E; p.outf = xpre; p.ldo = E; p.Ntok = N;
-        CHECK(pevit_launch_gemm(EPI_PATCH_EMBED, p, s));
+        CHECK(gemm(c, EPI_PATCH_EMBED, p, s));
     }
     CHECK(pevit_launch_ln_fwd(xpre, at<float>(A, c->a_lnpre_w), at<float>(A, c->a_lnpre_b), T, E, nullptr,
                               at<float>(W, c->sav[0].x_in), nullptr, nullptr, s));
@@ -556,7 +581,7 @@ extern "C" int pevit_visual_forward(pevit_ctx* c, void* stream, const float* ima
     {
         GemmParams p = gp(at<bf16>(W, c->w_xpost), E, at<bf16>(A, c->a_proj), E, c->D, B, c->D, E);
         p.outf = feat ? feat : at<float>(W, c->w_feat); p.ldo = c->D;
-        CHECK(pevit_launch_gemm(EPI_F32, p, s));
+        CHECK(gemm(c, EPI_F32, p, s));
     }
     c->saved_batch = save_for_backward ? B : 0;
     return 0;
@@ -574,7 +599,7 @@ extern "C" int pevit_visual_backward(pevit_ctx* c, void* stream, const float* df
     {
         GemmParams p = gp(at<bf16>(W, c->w_dfeatb), c->D, at<bf16>(A, c->a_projT), c->D, E, B, E, c->D);
         p.outf = at<float>(W, c->w_dxpost); p.ldo = E;
-        CHECK(pevit_launch_gemm(EPI_F32, p, s));
+        CHECK(gemm(c, EPI_F32, p, s));
     }
     // dL/dx_final is zero except on the class-token rows
     HIP_OK(hipMemsetAsync(W + c->w_dxa, 0, (size_t)T * E * 4, s));
@@ -613,6 +638,41 @@ extern "C" int pevit_train_forward_backward(pevit_ctx* c, void* stream, const fl
     CHECK(pevit_head_forward_backward(c, stream, feat, labels, running_mean, running_var, bn_training, logits, loss,
                                       dfeat, B));
     CHECK(pevit_visual_backward(c, stream, dfeat, B));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// Per-launch timing of the dominant kernel family (the MFMA GEMMs) with HIP events recorded on
+// the caller's stream around every GEMM launch of the context.  Events are created here, not in
+// the hot path.  pevit_profile_end synchronises the events and returns the totals.
+extern "C" int pevit_profile_begin(pevit_ctx* c, int max_launches) {
+    if (!c || max_launches <= 0) { pevit_set_error("profile_begin: bad argument"); return -1; }
+    if (c->prof_cap < max_launches) {
+        for (int i = 0; i < 2 * c->prof_cap; ++i) (void)hipEventDestroy(c->prof_ev[i]);
+        delete[] c->prof_ev; delete[] c->prof_flops;
+        c->prof_ev = new (std::nothrow) hipEvent_t[2 * max_launches];
+        c->prof_flops = new (std::nothrow) double[max_launches];
+        if (!c->prof_ev || !c->prof_flops) { pevit_set_error("profile_begin: out of host memory"); return -1; }
+        for (int i = 0; i < 2 * max_launches; ++i) HIP_OK(hipEventCreate(&c->prof_ev[i]));
+        c->prof_cap = max_launches;
+    }
+    c->prof_n = 0; c->prof_on = true;
+    return 0;
+}
+
+extern "C" int pevit_profile_end(pevit_ctx* c, double* total_ms, double* total_flops, int* launches) {
+    if (!c || !c->prof_on) { pevit_set_error("profile_end: profiling is not active"); return -1; }
+    c->prof_on = false;
+    double ms = 0.0, fl = 0.0;
+    for (int i = 0; i < c->prof_n; ++i) {
+        HIP_OK(hipEventSynchronize(c->prof_ev[2 * i + 1]));
+        float t = 0.f;
+        HIP_OK(hipEventElapsedTime(&t, c->prof_ev[2 * i], c->prof_ev[2 * i + 1]));
+        ms += t; fl += c->prof_flops[i];
+    }
+    if (total_ms) *total_ms = ms;
+    if (total_flops) *total_flops = fl;
+    if (launches) *launches = c->prof_n;
     return 0;
 }
 
@@ -664,3 +724,8 @@ extern "C" int pevit_op_lowrank_grad(void* stream, const void* xn, int ldx, cons
                                      pevit_lowrank_chunks(B * N), B, H, N, E, (hipStream_t)stream);
 }
 extern "C" int pevit_op_lowrank_chunks(int T) { return pevit_lowrank_chunks(T); }
+extern "C" int pevit_tune(const char* key, int value) {
+    if (key && !strcmp(key, "gemm_config")) return pevit_gemm_set_variant(value);
+    pevit_set_error("tune: unknown key %s", key ? key : "(null)");
+    return -1;
+}

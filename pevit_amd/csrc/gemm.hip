@@ -9,20 +9,25 @@
 // as the OpenAI checkpoint has them, which is already the K-contiguous "B^T" layout the
 // MFMA B-fragment wants; the backward GEMMs use a transposed copy made once at load.
 //
-// Tile: 128x128x64 per 256-thread workgroup (4 waves as 2x2, 64x64 per wave, built from
-// v_mfma_f32_32x32x16_bf16).  Operands are staged HBM->LDS with 16-byte LDS-DMA
+// Workgroup = 256 threads = 4 waves as 2x2; a BM x BN x BK tile is built from
+// v_mfma_f32_32x32x16_bf16.  Operands are staged HBM->LDS with 16-byte LDS-DMA
 // (global_load_lds), double buffered, XOR-swizzled on the *source* side so that the
 // ds_read_b128 fragment reads are bank-conflict free (cdna guide T2 / rule 21).
-// Epilogue: accumulators are transposed through LDS so that every global access is a
-// full 16-byte-per-lane row segment.
+// Epilogue: accumulators are transposed through LDS, one 32x32 fragment per wave at a time, so
+// that global accesses are 16/32-byte-per-lane row segments.
+//
+// The fine-tune step's GEMMs are SMALL (M = B*N = 6400 rows): a 128x128 tiling gives only 300
+// workgroups for the N=768 products, fewer than the 512 slots of 256 CUs x 2, and measured
+// per-workgroup speed does not depend on how many workgroups share a CU (one wave per SIMD is
+// latency-bound on its own ds_read -> MFMA chain).  So the tile shape is chosen per problem to
+// put >= ~3 workgroups on every CU: see pick_config().
 #include "common.h"
 #include "kernels.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int STAGE_BYTES = (BM + BN) * BK * 2;   // 32 KiB
-constexpr int A_BYTES = BM * BK * 2;              // 16 KiB
+constexpr int TILE_BAND = 6;
+int g_gemm_config = -1;    // -1: heuristic ; >= 0: force a tile configuration (A/B measurements)
 
 __device__ __forceinline__ float sigmoidf_fast(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
@@ -125,62 +130,78 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int row, int
     }
 }
 
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmParams p) {
+// tile coordinates of this workgroup.  Order: XCD-contiguous (xcd_remap), and inside that a band
+// of TILE_BAND m-tiles is walked n-major, so the tiles an XCD has in flight share TILE_BAND
+// A-panels and only a few B-panels (a 128x768 bf16 panel is 192 KiB; the XCD's L2 is 4 MiB).
+template <int BM, int BN>
+__device__ __forceinline__ void tile_origin(const GemmParams& p, int& m0, int& n0) {
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int band = t / (TILE_BAND * tiles_n), within = t - band * (TILE_BAND * tiles_n);
+    const int mb = min(TILE_BAND, tiles_m - band * TILE_BAND);
+    const int tn = within / mb, tm = band * TILE_BAND + (within - tn * mb);
+    m0 = tm * BM; n0 = tn * BN;
+}
+
+template <int EPI, int BM, int BN, int BK, int MINB>
+__global__ __launch_bounds__(256, MINB) void gemm_bf16_nt_kernel(GemmParams p) {
+    constexpr int WM = BM / 64, WN = BN / 64;           // 32x32 fragments per wave (m, n)
+    constexpr int ROWB = BK * 2;                        // bytes per tile row
+    constexpr int CH = BK / 8;                          // 16-byte chunks per row
+    constexpr int RPP = 1024 / ROWB;                    // rows per 1 KiB LDS-DMA piece
+    constexpr int SWZ_SHIFT = (ROWB == 128) ? 1 : 2;    // rows per 256-byte LDS bank row: 2 or 4
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int PA = BM / RPP / 4, PB = BN / RPP / 4; // pieces per wave
+    constexpr int KS = BK / 16;                         // MFMA k-steps per k-tile
+    static_assert(PA >= 1 && PB >= 1, "tile too small for 4 loader waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wid >> 1, wn = wid & 1;
+    int m0, n0;
+    tile_origin<BM, BN>(p, m0, n0);
 
-    const int tiles_n = (p.N + BN - 1) / BN;
-    const int tiles_m = (p.M + BM - 1) / BM;
-    const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    const int tm = t / tiles_n, tn = t - tm * tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
-
-    // ---- LDS-DMA loader addressing --------------------------------------------------
-    // Wave w, piece i (0..3) fills rows R = (w*4+i)*8 .. +7 of the 128x64 tile, one 1 KiB
-    // lane-linear block; lane l lands at row R+(l>>3), physical 16-byte chunk l&7, and
-    // fetches the logical chunk (l&7) ^ swz(row) of that row from HBM.
-    const bf16* a_src[4];
-    const bf16* b_src[4];
+    // LDS-DMA: a piece is RPP rows x ROWB bytes = 1 KiB, lane-linear; lane l lands at row
+    // R + l/CH, physical chunk l%CH, and fetches the logical chunk (l%CH) ^ swz(row) from HBM.
+    const bf16* a_src[PA];
+    const bf16* b_src[PB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (wid * 4 + i) * 8 + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    for (int i = 0; i < PA; ++i) {
+        const int row = (wid * PA + i) * RPP + lane / CH;
+        const int chunk = (lane % CH) ^ ((row >> SWZ_SHIFT) & (CH - 1));
         int ar = m0 + row; ar = ar < p.M ? ar : p.M - 1;
-        int br = n0 + row; br = br < p.Nb ? br : p.Nb - 1;
         a_src[i] = p.A + (size_t)ar * p.lda + chunk * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+        const int row = (wid * PB + i) * RPP + lane / CH;
+        const int chunk = (lane % CH) ^ ((row >> SWZ_SHIFT) & (CH - 1));
+        int br = n0 + row; br = br < p.Nb ? br : p.Nb - 1;
         b_src[i] = p.B + (size_t)br * p.ldb + chunk * 8;
     }
     auto issue_tile = [&](int kt, int stage) {
-        char* sa = smem + stage * STAGE_BYTES + (wid * 4) * 1024;
-        char* sb = sa + A_BYTES;
+        char* sa = smem + stage * STAGE_BYTES + (wid * PA) * 1024;
+        char* sb = smem + stage * STAGE_BYTES + A_BYTES + (wid * PB) * 1024;
         const int koff = kt * BK;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            glds16(a_src[i] + koff, sa + i * 1024);
-            glds16(b_src[i] + koff, sb + i * 1024);
-        }
+        for (int i = 0; i < PA; ++i) glds16(a_src[i] + koff, sa + i * 1024);
+#pragma unroll
+        for (int i = 0; i < PB; ++i) glds16(b_src[i] + koff, sb + i * 1024);
     };
+    // 32x32x16 bf16 fragment: lane l holds row (l&31), k = 8*(l>>5)..+7 of the 16-wide k-step.
+    const int frow = lane & 31, fswz = (frow >> SWZ_SHIFT) & (CH - 1), fhalf = lane >> 5;
+    int a_off[WM], b_off[WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) a_off[i] = (wm * (BM / 2) + i * 32 + frow) * ROWB;
+#pragma unroll
+    for (int i = 0; i < WN; ++i) b_off[i] = A_BYTES + (wn * (BN / 2) + i * 32 + frow) * ROWB;
 
-    // ---- fragment read addressing ---------------------------------------------------
-    // 32x32x16 bf16: lane l holds row (l&31), k = 8*(l>>5)..+7 of the 16-wide k-step.
-    const int frow = lane & 31;
-    const int fswz = (frow >> 1) & 7;
-    const int fhalf = lane >> 5;
-    int a_off[2], b_off[2];
+    f32x16 acc[WM][WN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        a_off[i] = (wm * 64 + i * 32 + frow) * 128;
-        b_off[i] = A_BYTES + (wn * 64 + i * 32 + frow) * 128;
-    }
-
-    f32x16 acc[2][2];
+    for (int i = 0; i < WM; ++i)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < WN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
@@ -192,76 +213,108 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmParams p) {
         if (kt + 1 < nk) issue_tile(kt + 1, (kt + 1) & 1);
         const char* st = smem + (kt & 1) * STAGE_BYTES;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
             const int coff = (((ks * 2 + fhalf) ^ fswz) << 4);
-            bf16x8 af[2], bfr[2];
+            bf16x8 af[WM], bfr[WN];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                af[i] = *reinterpret_cast<const bf16x8*>(st + a_off[i] + coff);
-                bfr[i] = *reinterpret_cast<const bf16x8*>(st + b_off[i] + coff);
-            }
+            for (int i = 0; i < WM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(st + a_off[i] + coff);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < WN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(st + b_off[j] + coff);
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
     }
 
-    // ---- epilogue: C fragment -> LDS (per-wave 64x64 f32) -> row segments ----------
+    // ---- epilogue: one 32x32 fragment at a time through this wave's 4 KiB of LDS ------------
     __syncthreads();
-    float* cw = reinterpret_cast<float*>(smem + wid * 16384);
+    float* cw = reinterpret_cast<float*>(smem + wid * 4096);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < WN; ++j) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int col = j * 32 + (lane & 31);
-                cw[row * 64 + col] = acc[i][j][r];
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                cw[row * 32 + (lane & 31)] = acc[i][j][r];
             }
-    // same-wave LDS ops are ordered; make the compiler wait for the writes.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int ncols = (EPI == EPI_QKV_HEADS) ? p.N : p.N;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-    for (int pass = 0; pass < 8; ++pass) {
-        const int lr = pass * 8 + (lane >> 3);
-        const int lc = (lane & 7) * 8;
-        const int row = m0 + wm * 64 + lr;
-        const int col = n0 + wn * 64 + lc;
-        if (row < p.M && col < ncols) {
-            float v[8];
-            const float4 x0 = *reinterpret_cast<const float4*>(cw + lr * 64 + lc);
-            const float4 x1 = *reinterpret_cast<const float4*>(cw + lr * 64 + lc + 4);
-            v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w;
-            v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
-            epilogue_store<EPI>(p, row, col, v);
+            for (int pass = 0; pass < 2; ++pass) {
+                const int lr = pass * 16 + (lane >> 2);
+                const int lc = (lane & 3) * 8;
+                const int row = m0 + wm * (BM / 2) + i * 32 + lr;
+                const int col = n0 + wn * (BN / 2) + j * 32 + lc;
+                const float4 x0 = *reinterpret_cast<const float4*>(cw + lr * 32 + lc);
+                const float4 x1 = *reinterpret_cast<const float4*>(cw + lr * 32 + lc + 4);
+                if (row < p.M && col < p.N) {
+                    float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                    epilogue_store<EPI>(p, row, col, v);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-    }
 }
 
-template <int EPI>
-int launch_epi(const GemmParams& p, hipStream_t stream) {
-    const int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
+struct TileConfig { int bm, bn, bk, minb; };
+constexpr TileConfig kConfigs[] = {
+    {128, 128, 64, 2},   // 0: 64 KiB LDS, 2 workgroups / CU
+    {128, 128, 32, 4},   // 1: 32 KiB LDS, 4 workgroups / CU
+    {128, 64, 64, 3},    // 2: 48 KiB LDS, 3 workgroups / CU
+    {64, 64, 64, 4},     // 3: 32 KiB LDS, 4 workgroups / CU
+    {128, 64, 32, 4},    // 4: 24 KiB LDS
+};
+constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
+
+template <int EPI, int CFG>
+int launch_cfg(const GemmParams& p, hipStream_t stream) {
+    constexpr TileConfig c = kConfigs[CFG];
+    constexpr int stage = (c.bm + c.bn) * c.bk * 2;
+    constexpr int lds = 2 * stage > 16384 ? 2 * stage : 16384;
+    auto kern = gemm_bf16_nt_kernel<EPI, c.bm, c.bn, c.bk, c.minb>;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_nt_kernel<EPI>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES) != hipSuccess) {
-            pevit_set_error("hipFuncSetAttribute(gemm, %d) failed", EPI);
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
+            hipSuccess) {
+            pevit_set_error("hipFuncSetAttribute(gemm epi %d cfg %d) failed", EPI, CFG);
             return -1;
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_bf16_nt_kernel<EPI>, dim3(tiles), dim3(256), 2 * STAGE_BYTES, stream, p);
+    const int tiles = ceil_div(p.M, c.bm) * ceil_div(p.N, c.bn);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, stream, p);
     return 0;
+}
+
+// Tile shape per problem.  Measured on MI355X (scripts/bench_gemm.py): with M = 6400 the large-N
+// products want the 128x128 tile, the N = 768 products want 4x as many, smaller workgroups.
+int pick_config(const GemmParams& p) {
+    if (g_gemm_config >= 0 && g_gemm_config < kNumConfigs) return g_gemm_config;
+    const long t128 = (long)ceil_div(p.M, 128) * ceil_div(p.N, 128);
+    return t128 >= 700 ? 0 : 2;
+}
+
+template <int EPI>
+int launch_epi(const GemmParams& p, hipStream_t stream) {
+    switch (pick_config(p)) {
+        case 0: return launch_cfg<EPI, 0>(p, stream);
+        case 1: return launch_cfg<EPI, 1>(p, stream);
+        case 2: return launch_cfg<EPI, 2>(p, stream);
+        case 3: return launch_cfg<EPI, 3>(p, stream);
+        default: return launch_cfg<EPI, 4>(p, stream);
+    }
 }
 
 }  // namespace
 
+int pevit_gemm_set_variant(int v) { const int old = g_gemm_config; g_gemm_config = v; return old; }
+
 int pevit_launch_gemm(int epi, const GemmParams& p, hipStream_t stream) {
-    if (p.K % BK != 0 || p.K <= 0) { pevit_set_error("gemm: K=%d must be a positive multiple of %d", p.K, BK); return -1; }
+    if (p.K % 64 != 0 || p.K <= 0) { pevit_set_error("gemm: K=%d must be a positive multiple of 64", p.K); return -1; }
     if (p.N % 8 != 0) { pevit_set_error("gemm: N=%d must be a multiple of 8", p.N); return -1; }
     if (p.M <= 0 || p.N <= 0) { pevit_set_error("gemm: empty problem M=%d N=%d", p.M, p.N); return -1; }
     if ((p.lda % 8) || (p.ldb % 8)) { pevit_set_error("gemm: lda/ldb must be multiples of 8"); return -1; }

@@ -30,6 +30,7 @@ struct GemmParams {
 };
 
 int pevit_launch_gemm(int epi, const GemmParams& p, hipStream_t stream);
+int pevit_gemm_set_variant(int v);   // -1: heuristic, >= 0: forced tile configuration; returns the previous value
 
 // ---- norm.hip --------------------------------------------------------------------
 // y = LN(x) * gamma + beta over the last dim (eps 1e-5, f32 statistics: model.py:154-160)
@@ -59,13 +60,14 @@ struct AdapterPanels {      // per layer, rewritten every step from the f32 mast
     float* q32;             // [E][64] f32 : Q_q | Q_v
     bf16* qT;               // [64][E] bf16: Q_q^T ; Q_v^T
 };
-// KAdaptation: P[:,j] = s_j (x) l_j , Q[:,j] = t_j (x) r_j   (model.py:567-580)
+struct LayerStrides { size_t arena_bytes; size_t param_floats; };   // per-layer pointer advance
+// KAdaptation: P[:,j] = s_j (x) l_j , Q[:,j] = t_j (x) r_j   (model.py:567-580); all layers
 int pevit_launch_prep_kadapt(const float* rule1_l, const float* rule1_r, const float* rule2_l,
                              const float* rule2_r, const float* q_left, const float* q_right,
-                             AdapterPanels pan, int E, float ascale, hipStream_t s);
-// LoRA: P_q = A1q^T, Q_q = A2q (rank r zero-padded to 32)   (lora_model.py:490-514)
+                             AdapterPanels pan, int E, float ascale, int layers, LayerStrides st, hipStream_t s);
+// LoRA: P_q = A1q^T, Q_q = A2q (rank r zero-padded to 32)   (lora_model.py:490-514); all layers
 int pevit_launch_prep_lora(const float* a1q, const float* a2q, const float* a1v, const float* a2v,
-                           int r, AdapterPanels pan, int E, float ascale, hipStream_t s);
+                           int r, AdapterPanels pan, int E, float ascale, int layers, LayerStrides st, hipStream_t s);
 // q_buf_flat[rr*E+e] += ascale * t[row(rr)][0:32] . Q_q[e] + bias[e]   (and v with cols 32:64)
 // rr is the reference's (n*B+b) row index of the raw reshape (model.py:796-799); row(rr)=b*N+n.
 int pevit_launch_delta_add(bf16* qbuf, bf16* vbuf, const float* t, const float* q32,
@@ -79,14 +81,13 @@ int pevit_launch_lowrank_grad(const bf16* xn, int ldx, const float* u32, const b
                               const float* t, float* partial, float* dbias_partial, int chunks,
                               int B, int H, int N, int E, hipStream_t s);
 int pevit_lowrank_chunks(int T);
-// chain rule onto the reference's parameters; g_* point into the flat gradient buffer
-int pevit_launch_chain_kadapt(const float* partial, const float* dbias_partial, int chunks, float ascale,
-                              const float* rule1_l, const float* rule1_r, const float* rule2_l,
-                              const float* rule2_r, const float* q_left, const float* q_right,
-                              float* g_rule1_l, float* g_rule1_r, float* g_rule2_l, float* g_rule2_r,
-                              float* g_q_left, float* g_q_right, float* g_b, int E, hipStream_t s);
-int pevit_launch_chain_lora(const float* partial, int chunks, float ascale, int r,
-                            float* g_a1q, float* g_a2q, float* g_a1v, float* g_a2v, int E, hipStream_t s);
+// reduce the per-chunk partials of all layers and apply the chain rule onto the reference's
+// parameter tensors (flat gradient buffer, accumulating)
+int pevit_launch_chain_kadapt(const float* partial, size_t partial_layer, const float* dbias_partial, size_t dbias_layer,
+                              int chunks, float ascale, int layers, float* G, float* rule_scratch, const float* params,
+                              float* grads, size_t p_layer0, size_t p_layer_stride, int E, hipStream_t s);
+int pevit_launch_chain_lora(const float* partial, size_t partial_layer, int chunks, float ascale, int r, int layers,
+                            float* G, float* grads, size_t p_layer0, size_t p_layer_stride, int E, hipStream_t s);
 
 // ---- misc.hip --------------------------------------------------------------------
 int pevit_launch_cast_bf16(const float* src, bf16* dst, size_t n, float scale, hipStream_t s);

@@ -28,12 +28,23 @@ __device__ __forceinline__ int row_of_ref(int rr, int B, int N) {
 }
 
 // ---------------------------------------------------------------------------------
+// blockIdx.y = layer: every per-layer pointer advances by a constant stride (LayerStrides)
+__device__ __forceinline__ AdapterPanels layer_panels(AdapterPanels pan, LayerStrides st, int l) {
+    pan.w_aug_rows = reinterpret_cast<bf16*>(reinterpret_cast<char*>(pan.w_aug_rows) + (size_t)l * st.arena_bytes);
+    pan.wT_aug_cols = reinterpret_cast<bf16*>(reinterpret_cast<char*>(pan.wT_aug_cols) + (size_t)l * st.arena_bytes);
+    pan.q32 = reinterpret_cast<float*>(reinterpret_cast<char*>(pan.q32) + (size_t)l * st.arena_bytes);
+    pan.qT = reinterpret_cast<bf16*>(reinterpret_cast<char*>(pan.qT) + (size_t)l * st.arena_bytes);
+    return pan;
+}
+
 __global__ void prep_kadapt_kernel(const float* __restrict__ rule1_l, const float* __restrict__ rule1_r,
                                    const float* __restrict__ rule2_l, const float* __restrict__ rule2_r,
                                    const float* __restrict__ q_left, const float* __restrict__ q_right,
-                                   AdapterPanels pan, int E, float ascale) {
+                                   AdapterPanels pan, int E, float ascale, LayerStrides st) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= E * 32) return;
+    pan = layer_panels(pan, st, blockIdx.y);
+    q_left += (size_t)blockIdx.y * st.param_floats; q_right += (size_t)blockIdx.y * st.param_floats;
     const int j = idx / E, e = idx - j * E;     // e fastest: coalesced row writes
     const int F = E / 32, a = e / F, kk = e - a * F;
     const float l = q_left[j * F + kk], r = q_right[j * F + kk];
@@ -51,9 +62,11 @@ __global__ void prep_kadapt_kernel(const float* __restrict__ rule1_l, const floa
 
 __global__ void prep_lora_kernel(const float* __restrict__ a1q, const float* __restrict__ a2q,
                                  const float* __restrict__ a1v, const float* __restrict__ a2v, int r,
-                                 AdapterPanels pan, int E, float ascale) {
+                                 AdapterPanels pan, int E, float ascale, LayerStrides st) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= E * 32) return;
+    pan = layer_panels(pan, st, blockIdx.y);
+    { const size_t o = (size_t)blockIdx.y * st.param_floats; a1q += o; a2q += o; a1v += o; a2v += o; }
     const int j = idx / E, e = idx - j * E;
     const float pq = j < r ? a1q[(size_t)j * E + e] : 0.f, pv = j < r ? a1v[(size_t)j * E + e] : 0.f;
     const float qq = j < r ? a2q[(size_t)e * r + j] : 0.f, qv = j < r ? a2v[(size_t)e * r + j] : 0.f;
@@ -331,11 +344,13 @@ __global__ __launch_bounds__(256) void lowrank_grad_kernel(const bf16* __restric
         dbias_partial[((size_t)chunk * 2 + (kind - 1)) * E + e0 + tid] = cs[0][tid] + cs[1][tid] + cs[2][tid] + cs[3][tid];
 }
 
-// sum the per-chunk partials: G[4][E][32], and the bias gradient
+// sum the per-chunk partials of every layer (blockIdx.y): G[l][4][E][32], and the bias gradient
 __global__ void lowrank_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ dbias_partial,
-                                      int chunks, float* __restrict__ G, float* g_b, int E) {
+                                      int chunks, float* __restrict__ G, float* g_b, int E, size_t partial_layer,
+                                      size_t dbias_layer, size_t gb_layer) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int total = 4 * E * 32;
+    const int total = 4 * E * 32, l = blockIdx.y;
+    partial += (size_t)l * partial_layer;
     if (idx < total) {
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;     // fixed summation tree: deterministic
         int c = 0;
@@ -346,42 +361,49 @@ __global__ void lowrank_reduce_kernel(const float* __restrict__ partial, const f
             s3 += partial[(size_t)(c + 3) * total + idx];
         }
         for (; c < chunks; ++c) s0 += partial[(size_t)c * total + idx];
-        G[idx] = (s0 + s1) + (s2 + s3);
+        G[(size_t)l * total + idx] = (s0 + s1) + (s2 + s3);
     }
     if (g_b && idx < E) {
+        const float* db = dbias_partial + (size_t)l * dbias_layer;
         float s = 0.f;
-        for (int c = 0; c < chunks; ++c)
-            s += dbias_partial[((size_t)c * 2) * E + idx] + dbias_partial[((size_t)c * 2 + 1) * E + idx];
-        g_b[idx] += s;
+        for (int c = 0; c < chunks; ++c) s += db[((size_t)c * 2) * E + idx] + db[((size_t)c * 2 + 1) * E + idx];
+        g_b[(size_t)l * gb_layer + idx] += s;
     }
 }
 
-// KAdaptation chain rule, one block per rank index j
+// KAdaptation chain rule, one block per (rank index j, layer).  The per-layer factors
+// are written straight into the flat gradient buffer; the contributions to the shared phm_rule
+// factors go to rule_scratch[l][4][32][32] and are summed over layers by rule_sum_kernel (a
+// fixed-order, deterministic sum).
 __global__ __launch_bounds__(256) void chain_kadapt_kernel(const float* __restrict__ G, float ascale,
                                                            const float* __restrict__ rule1_l, const float* __restrict__ rule1_r,
                                                            const float* __restrict__ rule2_l, const float* __restrict__ rule2_r,
                                                            const float* __restrict__ q_left, const float* __restrict__ q_right,
-                                                           float* g_rule1_l, float* g_rule1_r, float* g_rule2_l,
-                                                           float* g_rule2_r, float* g_q_left, float* g_q_right, int E) {
+                                                           float* __restrict__ rule_scratch, float* g_q_left,
+                                                           float* g_q_right, int E, size_t param_layer) {
     extern __shared__ float gs[];      // [4][E]
-    const int j = blockIdx.x, F = E / 32, tid = threadIdx.x;
+    const int j = blockIdx.x, l = blockIdx.y, F = E / 32, tid = threadIdx.x;
+    G += (size_t)l * 4 * E * 32;
+    q_left += (size_t)l * param_layer; q_right += (size_t)l * param_layer;
+    g_q_left += (size_t)l * param_layer; g_q_right += (size_t)l * param_layer;
+    float* rs = rule_scratch + (size_t)l * 4096;
     for (int i = tid; i < 4 * E; i += blockDim.x) gs[i] = G[(size_t)i * 32 + j];
     __syncthreads();
     const float* G0 = gs; const float* G1 = gs + E; const float* G2 = gs + 2 * E; const float* G3 = gs + 3 * E;
-    const float* l = q_left + j * F; const float* r = q_right + j * F;
+    const float* lf = q_left + j * F; const float* r = q_right + j * F;
     const float* s1 = rule1_l + j * 32; const float* t1 = rule1_r + j * 32;
     const float* s2 = rule2_l + j * 32; const float* t2 = rule2_r + j * 32;
     if (tid < 32) {                                  // d s1[a], d s2[a]
         float a1 = 0.f, a2 = 0.f;
-        for (int k = 0; k < F; ++k) { a1 += G0[tid * F + k] * l[k]; a2 += G1[tid * F + k] * l[k]; }
-        g_rule1_l[j * 32 + tid] += ascale * a1;
-        g_rule2_l[j * 32 + tid] += ascale * a2;
+        for (int k = 0; k < F; ++k) { a1 += G0[tid * F + k] * lf[k]; a2 += G1[tid * F + k] * lf[k]; }
+        rs[0 * 1024 + j * 32 + tid] = ascale * a1;    // rule1_left
+        rs[2 * 1024 + j * 32 + tid] = ascale * a2;    // rule2_left
     } else if (tid < 64) {                           // d t1[c], d t2[c]
         const int c = tid - 32;
         float a1 = 0.f, a2 = 0.f;
         for (int p = 0; p < F; ++p) { a1 += G2[c * F + p] * r[p]; a2 += G3[c * F + p] * r[p]; }
-        g_rule1_r[j * 32 + c] += ascale * a1;
-        g_rule2_r[j * 32 + c] += ascale * a2;
+        rs[1 * 1024 + j * 32 + c] = ascale * a1;      // rule1_right
+        rs[3 * 1024 + j * 32 + c] = ascale * a2;      // rule2_right
     } else if (tid < 64 + F) {                       // d l[k]  (q and v paths share Wq: SURVEY 9.1)
         const int k = tid - 64;
         float a = 0.f;
@@ -395,10 +417,21 @@ __global__ __launch_bounds__(256) void chain_kadapt_kernel(const float* __restri
     }
 }
 
+// g_rule[0:4096] += sum_l rule_scratch[l][0:4096]   (rule1_left | rule1_right | rule2_left | rule2_right)
+__global__ void rule_sum_kernel(const float* __restrict__ rule_scratch, float* g_rule, int L) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 4096) return;
+    float s = 0.f;
+    for (int l = 0; l < L; ++l) s += rule_scratch[(size_t)l * 4096 + i];
+    g_rule[i] += s;
+}
+
 __global__ void chain_lora_kernel(const float* __restrict__ G, float ascale, int r, float* g_a1q, float* g_a2q,
-                                  float* g_a1v, float* g_a2v, int E) {
+                                  float* g_a1v, float* g_a2v, int E, size_t param_layer) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= E * r) return;
+    G += (size_t)blockIdx.y * 4 * E * 32;
+    { const size_t o = (size_t)blockIdx.y * param_layer; g_a1q += o; g_a2q += o; g_a1v += o; g_a2v += o; }
     const int e = idx / r, j = idx - e * r;
     const size_t plane = (size_t)E * 32;
     g_a1q[(size_t)j * E + e] += ascale * G[(size_t)e * 32 + j];
@@ -411,18 +444,18 @@ __global__ void chain_lora_kernel(const float* __restrict__ G, float ascale, int
 
 int pevit_launch_prep_kadapt(const float* rule1_l, const float* rule1_r, const float* rule2_l, const float* rule2_r,
                              const float* q_left, const float* q_right, AdapterPanels pan, int E, float ascale,
-                             hipStream_t s) {
+                             int layers, LayerStrides st, hipStream_t s) {
     if (E % 32) { pevit_set_error("prep_kadapt: width %d not divisible by phm_dim 32", E); return -1; }
-    hipLaunchKernelGGL(prep_kadapt_kernel, dim3(ceil_div(E * 32, 256)), dim3(256), 0, s, rule1_l, rule1_r, rule2_l,
-                       rule2_r, q_left, q_right, pan, E, ascale);
+    hipLaunchKernelGGL(prep_kadapt_kernel, dim3(ceil_div(E * 32, 256), layers), dim3(256), 0, s, rule1_l, rule1_r,
+                       rule2_l, rule2_r, q_left, q_right, pan, E, ascale, st);
     return 0;
 }
 
 int pevit_launch_prep_lora(const float* a1q, const float* a2q, const float* a1v, const float* a2v, int r,
-                           AdapterPanels pan, int E, float ascale, hipStream_t s) {
+                           AdapterPanels pan, int E, float ascale, int layers, LayerStrides st, hipStream_t s) {
     if (r < 1 || r > 32) { pevit_set_error("prep_lora: rank %d outside [1,32]", r); return -1; }
-    hipLaunchKernelGGL(prep_lora_kernel, dim3(ceil_div(E * 32, 256)), dim3(256), 0, s, a1q, a2q, a1v, a2v, r, pan, E,
-                       ascale);
+    hipLaunchKernelGGL(prep_lora_kernel, dim3(ceil_div(E * 32, 256), layers), dim3(256), 0, s, a1q, a2q, a1v, a2v, r,
+                       pan, E, ascale, st);
     return 0;
 }
 
@@ -457,28 +490,30 @@ int pevit_launch_lowrank_grad(const bf16* xn, int ldx, const float* u32, const b
     return 0;
 }
 
-int pevit_launch_chain_kadapt(const float* partial, const float* dbias_partial, int chunks, float ascale,
-                              const float* rule1_l, const float* rule1_r, const float* rule2_l, const float* rule2_r,
-                              const float* q_left, const float* q_right, float* g_rule1_l, float* g_rule1_r,
-                              float* g_rule2_l, float* g_rule2_r, float* g_q_left, float* g_q_right, float* g_b, int E,
-                              hipStream_t s) {
-    // G lives right behind the partials (the caller sizes the buffer for chunks+1 planes)
-    float* G = const_cast<float*>(partial) + (size_t)chunks * 4 * E * 32;
-    hipLaunchKernelGGL(lowrank_reduce_kernel, dim3(ceil_div(4 * E * 32, 256)), dim3(256), 0, s, partial, dbias_partial,
-                       chunks, G, g_b, E);
+// partial: [layers][chunks+? ...] see capi.hip; G: [layers][4][E][32]; rule_scratch: [layers][4096]
+int pevit_launch_chain_kadapt(const float* partial, size_t partial_layer, const float* dbias_partial, size_t dbias_layer,
+                              int chunks, float ascale, int layers, float* G, float* rule_scratch, const float* params,
+                              float* grads, size_t p_layer0, size_t p_layer_stride, int E, hipStream_t s) {
     if (64 + 2 * (E / 32) > 256) { pevit_set_error("chain_kadapt: width %d too large", E); return -1; }
-    hipLaunchKernelGGL(chain_kadapt_kernel, dim3(32), dim3(256), 4 * E * sizeof(float), s, G, ascale, rule1_l, rule1_r,
-                       rule2_l, rule2_r, q_left, q_right, g_rule1_l, g_rule1_r, g_rule2_l, g_rule2_r, g_q_left,
-                       g_q_right, E);
+    float* g_b = grads + p_layer0 + 4 * (size_t)E;
+    hipLaunchKernelGGL(lowrank_reduce_kernel, dim3(ceil_div(4 * E * 32, 256), layers), dim3(256), 0, s, partial,
+                       dbias_partial, chunks, G, g_b, E, partial_layer, dbias_layer, p_layer_stride);
+    const float* r = params;
+    const float* lp = params + p_layer0;
+    float* lg = grads + p_layer0;
+    hipLaunchKernelGGL(chain_kadapt_kernel, dim3(32, layers), dim3(256), 4 * E * sizeof(float), s, G, ascale, r, r + 1024,
+                       r + 2048, r + 3072, lp, lp + E, rule_scratch, lg, lg + E, E, p_layer_stride);
+    hipLaunchKernelGGL(rule_sum_kernel, dim3(16), dim3(256), 0, s, rule_scratch, grads, layers);
     return 0;
 }
 
-int pevit_launch_chain_lora(const float* partial, int chunks, float ascale, int r, float* g_a1q, float* g_a2q,
-                            float* g_a1v, float* g_a2v, int E, hipStream_t s) {
-    float* G = const_cast<float*>(partial) + (size_t)chunks * 4 * E * 32;
-    hipLaunchKernelGGL(lowrank_reduce_kernel, dim3(ceil_div(4 * E * 32, 256)), dim3(256), 0, s, partial,
-                       (const float*)nullptr, chunks, G, (float*)nullptr, E);
-    hipLaunchKernelGGL(chain_lora_kernel, dim3(ceil_div(E * r, 256)), dim3(256), 0, s, G, ascale, r, g_a1q, g_a2q,
-                       g_a1v, g_a2v, E);
+int pevit_launch_chain_lora(const float* partial, size_t partial_layer, int chunks, float ascale, int r, int layers,
+                            float* G, float* grads, size_t p_layer0, size_t p_layer_stride, int E, hipStream_t s) {
+    hipLaunchKernelGGL(lowrank_reduce_kernel, dim3(ceil_div(4 * E * 32, 256), layers), dim3(256), 0, s, partial,
+                       (const float*)nullptr, chunks, G, (float*)nullptr, E, partial_layer, (size_t)0, (size_t)0);
+    const size_t rE = (size_t)r * E;
+    float* lg = grads + p_layer0;
+    hipLaunchKernelGGL(chain_lora_kernel, dim3(ceil_div(E * r, 256), layers), dim3(256), 0, s, G, ascale, r, lg, lg + rE,
+                       lg + 2 * rE, lg + 3 * rE, E, p_layer_stride);
     return 0;
 }

@@ -16,7 +16,7 @@ from collections import OrderedDict
 
 import torch
 
-from . import _lib
+from . import _lib, dp
 from .synth import VitArch
 
 PHM_DIM_KADAPT = 32     # model.py:485
@@ -233,6 +233,14 @@ class HipEngine:
                                            int(self._steps == 0)), "pevit_sgd_step")
         self._steps += 1
 
+    def profile_gemms(self, fn, max_launches=4096):
+        """Run ``fn()`` with HIP events around every GEMM launch; returns (ms, flops, launches)."""
+        _lib.check(self.lib.pevit_profile_begin(self._ctx, max_launches), "pevit_profile_begin")
+        fn()
+        ms, fl, n = C.c_double(), C.c_double(), C.c_int()
+        _lib.check(self.lib.pevit_profile_end(self._ctx, C.byref(ms), C.byref(fl), C.byref(n)), "pevit_profile_end")
+        return ms.value, fl.value, n.value
+
     def reset_optimizer(self):
         self._steps = 0
         self.momentum.zero_()
@@ -242,7 +250,6 @@ class HipEngine:
         """One reference ``train_one`` iteration (kadaptation_clip.py:347-353).  With DP the flat
         adapter-gradient buffer is the only thing that crosses xGMI (frozen backbone never does)."""
         logits, loss = self.forward_backward(images, labels, bn_training)
-        if world_size > 1:
-            torch.distributed.all_reduce(self.grads, group=process_group)
-        self.sgd_step(lr, momentum, weight_decay, 1.0 / world_size)
+        scale = dp.all_reduce_flat(self.grads, process_group) if world_size > 1 else 1.0
+        self.sgd_step(lr, momentum, weight_decay, scale)
         return logits, loss

@@ -44,6 +44,14 @@ def run(name, epi, M, N, K, iters=30):
 
 
 def main():
+    names = {-1: "heuristic", 0: "128x128x64", 1: "128x128x32", 2: "128x64x64", 3: "64x64x64", 4: "128x64x32"}
+    for cfg in (0, 1, 2, 3, 4, -1):
+        lib.pevit_tune(b"gemm_config", cfg)
+        print(f"---- gemm_config {cfg} ({names[cfg]})")
+        shapes(big=(cfg in (0, 1)))
+
+
+def shapes(big=False):
     M = 6400
     tot = 0
     tot += run("qkv fwd (+t)", EPI["QKV"], M, 2368, 768)
@@ -55,8 +63,8 @@ def main():
     tot += run("out_proj bwd", EPI["BF16"], M, 768, 768)
     tot += run("qkv bwd (+u)", EPI["F32"], M, 768, 2368)
     print(f"sum per layer {tot:.1f} us -> x12 = {tot * 12 / 1e3:.2f} ms")
-    run("square 4096", EPI["BF16"], 4096, 4096, 4096, iters=10)
-    run("square 8192", EPI["BF16"], 8192, 8192, 8192, iters=5)
+    if big:
+        run("square 4096", EPI["BF16"], 4096, 4096, 4096, iters=10)
 
 
 if __name__ == "__main__":
