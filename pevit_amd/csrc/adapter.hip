@@ -1,0 +1,367 @@
+// Post-MLP bottleneck adapters: Adapter (adapter_model.py:204-336) and Compacter
+// (compacter_model.py:196-308,356-503).
+//
+//   x <- x + [ h + up(act(down(LN_a(h)))) ]          h = mlp(ln_2(x))
+//
+// (the reference's Adapter evaluates mlp(ln_2(x)) twice -- adapter_model.py:333 -- with identical
+// values; here h is computed once and its gradient is the sum of both uses).
+// Adapter : down = Linear(E,64), act = ReLU,      up = Linear(64,E)
+// Compacter: down/up = PHMLinear, H = sum_{i<4} kron(rule_i (4x4), Wl_i Wr_i), act = gelu_new; the
+//            shared rule (4,4,4) is frozen (its name lacks "compacter": compacter_clip.py:122).
+// Both reduce to two dense E x 64 panels, so they share every kernel: the contractions are the MFMA
+// GEMM (gemm.hip, epilogues BIAS_RELU / BIAS_GELUNEW / DRELU / DGELUNEW), and this file holds
+//   * the panel builders (f32 master parameters -> bf16 panels in both orientations, every step),
+//   * the token-contracted weight gradients  G = X^T Y  (LDS-transposed panels + bf16 MFMA),
+//   * LayerNorm backward with gradients for the trainable affine (adapter_norm_before),
+//   * the chain rule from the dense panels back to the reference's parameter tensors.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int TG_ROWS = 256;
+constexpr int TG_LDT = TG_ROWS + 8;
+__device__ __forceinline__ int tg_col(int row_e, int y) { return y ^ (((row_e >> 3) & 7) << 3); }
+
+// ---------------------------------------------------------------------------------------------
+// panels: wd [64][E] (B operand of the down GEMM), wdT [E][64] (d z GEMM), wu [E][64] (up GEMM),
+// wuT [64][E] (d act GEMM).  blockIdx.y = layer.
+__global__ void prep_adapter_kernel(const float* __restrict__ w_down, const float* __restrict__ w_up, BottleneckPanels pan,
+                                    int E, LayerStrides st) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 64 * E) return;
+    const size_t lo = (size_t)blockIdx.y;
+    w_down += lo * st.param_floats; w_up += lo * st.param_floats;
+    char* base = reinterpret_cast<char*>(pan.wd) + lo * st.arena_bytes;
+    bf16* wd = reinterpret_cast<bf16*>(base);
+    bf16* wdT = reinterpret_cast<bf16*>(base + ((char*)pan.wdT - (char*)pan.wd));
+    bf16* wu = reinterpret_cast<bf16*>(base + ((char*)pan.wu - (char*)pan.wd));
+    bf16* wuT = reinterpret_cast<bf16*>(base + ((char*)pan.wuT - (char*)pan.wd));
+    const int j = idx / E, e = idx - j * E;
+    const float d = w_down[(size_t)j * E + e];        // (64, E)
+    const float u = w_up[(size_t)e * 64 + j];         // (E, 64)
+    wd[(size_t)j * E + e] = f2bf(d);
+    wdT[(size_t)e * 64 + j] = f2bf(d);
+    wu[(size_t)e * 64 + j] = f2bf(u);
+    wuT[(size_t)j * E + e] = f2bf(u);
+}
+
+// Compacter: H_down[a*Fi+k][c*16+p] = sum_i rule[i][a][c] Wl[i][k] Wr[i][p]   (Fi = E/4)
+//            H_up  [a*16+k][c*Fi+p] = sum_i rule[i][a][c] Ul[i][k] Ur[i][p]
+// effective dense weights: w_down[j][e] = H_down[e][j], w_up[e][j] = H_up[j][e].
+__global__ void prep_compacter_kernel(const float* __restrict__ rule, const float* __restrict__ dWl,
+                                      const float* __restrict__ dWr, const float* __restrict__ uWl,
+                                      const float* __restrict__ uWr, BottleneckPanels pan, int E, LayerStrides st) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 64 * E) return;
+    const size_t lo = (size_t)blockIdx.y;
+    dWl += lo * st.param_floats; dWr += lo * st.param_floats; uWl += lo * st.param_floats; uWr += lo * st.param_floats;
+    char* base = reinterpret_cast<char*>(pan.wd) + lo * st.arena_bytes;
+    bf16* wd = reinterpret_cast<bf16*>(base);
+    bf16* wdT = reinterpret_cast<bf16*>(base + ((char*)pan.wdT - (char*)pan.wd));
+    bf16* wu = reinterpret_cast<bf16*>(base + ((char*)pan.wu - (char*)pan.wd));
+    bf16* wuT = reinterpret_cast<bf16*>(base + ((char*)pan.wuT - (char*)pan.wd));
+    const int Fi = E / 4;
+    const int j = idx / E, e = idx - j * E;
+    {   // down: e = a*Fi + k, j = c*16 + p
+        const int a = e / Fi, k = e - a * Fi, c = j >> 4, p = j & 15;
+        float h = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) h += rule[i * 16 + a * 4 + c] * dWl[i * Fi + k] * dWr[i * 16 + p];
+        wd[(size_t)j * E + e] = f2bf(h);
+        wdT[(size_t)e * 64 + j] = f2bf(h);
+    }
+    {   // up: j = a*16 + k, e = c*Fi + p
+        const int a = j >> 4, k = j & 15, c = e / Fi, p = e - c * Fi;
+        float h = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) h += rule[i * 16 + a * 4 + c] * uWl[i * 16 + k] * uWr[i * Fi + p];
+        wu[(size_t)e * 64 + j] = f2bf(h);
+        wuT[(size_t)j * E + e] = f2bf(h);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// G[e][j] = sum_r X[r][e] Y[r][j]   X: bf16 [T][ldx] (64-column slab per workgroup), Y: bf16 [T][ldy]
+// (64 columns).  Workgroup = (chunk of TG_ROWS rows, 64 columns e).  Same structure as
+// lowrank_grad_kernel: coalesced 16-byte loads, transposed LDS images, bf16 MFMA.
+// partial[chunk][E][64]; optional column sums of X -> csx[chunk][E], of Y -> csy[chunk][64].
+__global__ __launch_bounds__(256) void tn_gemm64_kernel(const bf16* __restrict__ X, int ldx, const bf16* __restrict__ Y,
+                                                        int ldy, float* __restrict__ partial, float* __restrict__ csx,
+                                                        float* __restrict__ csy, int T, int E) {
+    __shared__ __attribute__((aligned(16))) bf16 Xt[64 * TG_LDT];
+    __shared__ __attribute__((aligned(16))) bf16 Yt[64 * TG_LDT];
+    __shared__ float cs[2][4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, c16 = lane & 15;
+    const int eslabs = E / 64;
+    const int chunk = blockIdx.x / eslabs, e0 = (blockIdx.x - chunk * eslabs) * 64;
+    const int r0 = chunk * TG_ROWS;
+    const int c = tid & 7;
+    bf16x8 xv[TG_ROWS / 32], yv[TG_ROWS / 32];
+#pragma unroll
+    for (int it = 0; it < TG_ROWS / 32; ++it) {
+        const int r = r0 + (tid >> 3) + 32 * it;
+        xv[it] = zero_bf16x8(); yv[it] = zero_bf16x8();
+        if (r < T) {
+            xv[it] = load_bf16x8(X + (size_t)r * ldx + e0 + 8 * c);
+            yv[it] = load_bf16x8(Y + (size_t)r * ldy + 8 * c);
+        }
+    }
+    float sx[8], sy[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { sx[i] = 0.f; sy[i] = 0.f; }
+#pragma unroll
+    for (int it = 0; it < TG_ROWS / 32; ++it) {
+        const int y = (tid >> 3) + 32 * it;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            Xt[(8 * c + i) * TG_LDT + tg_col(8 * c + i, y)] = xv[it][i];
+            Yt[(8 * c + i) * TG_LDT + tg_col(8 * c + i, y)] = yv[it][i];
+            sx[i] += bf2f(xv[it][i]); sy[i] += bf2f(yv[it][i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float a = sx[i], b = sy[i];
+        a += __shfl_xor(a, 8, 64); a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+        b += __shfl_xor(b, 8, 64); b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+        if ((lane >> 3) == 0) { cs[0][wid][8 * c + i] = a; cs[1][wid][8 * c + i] = b; }
+    }
+    __syncthreads();
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ea = 16 * wid + c16;
+#pragma unroll
+    for (int ks = 0; ks < TG_ROWS / 32; ++ks) {
+        const int y0 = 32 * ks + 8 * g;
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(Xt + ea * TG_LDT + tg_col(ea, y0));
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int jb = 16 * nt + c16;
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(Yt + jb * TG_LDT + tg_col(jb, y0));
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[nt], 0, 0, 0);
+        }
+    }
+    float* out = partial + (size_t)chunk * E * 64;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[(size_t)(e0 + 16 * wid + 4 * g + r) * 64 + 16 * nt + c16] = acc[nt][r];
+    if (tid < 64) {
+        if (csx) csx[(size_t)chunk * E + e0 + tid] = cs[0][0][tid] + cs[0][1][tid] + cs[0][2][tid] + cs[0][3][tid];
+        if (csy && e0 == 0) csy[(size_t)chunk * 64 + tid] = cs[1][0][tid] + cs[1][1][tid] + cs[1][2][tid] + cs[1][3][tid];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm backward with trainable affine: dx (+ dres) as ln_bwd, plus per-block partial sums of
+// d gamma = sum_r dy*xhat and d beta = sum_r dy.   Block = 64 rows (16 per wave).
+constexpr int LNA_ROWS = 64;
+constexpr int LNA_MAXV = 4;
+__global__ __launch_bounds__(256) void ln_bwd_affine_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                            const float* __restrict__ gamma, const float* dres, float* dx,
+                                                            bf16* __restrict__ dx_bf16, float* __restrict__ partial, int rows,
+                                                            int E) {
+    extern __shared__ float red[];     // [3 waves][2][E]
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    float4 ag[LNA_MAXV], ab[LNA_MAXV];
+#pragma unroll
+    for (int i = 0; i < LNA_MAXV; ++i) { ag[i] = make_float4(0.f, 0.f, 0.f, 0.f); ab[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    for (int rr = wid; rr < LNA_ROWS; rr += 4) {
+        const int row = blockIdx.x * LNA_ROWS + rr;
+        if (row >= rows) break;
+        const float mean = mean_in[row], rstd = rstd_in[row];
+        const size_t base = (size_t)row * E;
+        float4 gd[LNA_MAXV], xh[LNA_MAXV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LNA_MAXV; ++i) {
+            const int c = lane * 4 + i * 256;
+            if (c < E) {
+                const float4 d = *reinterpret_cast<const float4*>(dy + base + c);
+                const float4 xv = *reinterpret_cast<const float4*>(x + base + c);
+                const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+                xh[i] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+                ag[i].x += d.x * xh[i].x; ag[i].y += d.y * xh[i].y; ag[i].z += d.z * xh[i].z; ag[i].w += d.w * xh[i].w;
+                ab[i].x += d.x; ab[i].y += d.y; ab[i].z += d.z; ab[i].w += d.w;
+                gd[i] = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
+                s1 += gd[i].x + gd[i].y + gd[i].z + gd[i].w;
+                s2 += gd[i].x * xh[i].x + gd[i].y * xh[i].y + gd[i].z * xh[i].z + gd[i].w * xh[i].w;
+            }
+        }
+        const float m1 = wave_sum(s1) / (float)E, m2 = wave_sum(s2) / (float)E;
+#pragma unroll
+        for (int i = 0; i < LNA_MAXV; ++i) {
+            const int c = lane * 4 + i * 256;
+            if (c < E) {
+                float4 o;
+                o.x = rstd * (gd[i].x - m1 - xh[i].x * m2); o.y = rstd * (gd[i].y - m1 - xh[i].y * m2);
+                o.z = rstd * (gd[i].z - m1 - xh[i].z * m2); o.w = rstd * (gd[i].w - m1 - xh[i].w * m2);
+                if (dres) {
+                    const float4 r = *reinterpret_cast<const float4*>(dres + base + c);
+                    o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+                }
+                *reinterpret_cast<float4*>(dx + base + c) = o;
+                if (dx_bf16) {
+                    bf16x4 ob;
+                    ob[0] = f2bf(o.x); ob[1] = f2bf(o.y); ob[2] = f2bf(o.z); ob[3] = f2bf(o.w);
+                    *reinterpret_cast<bf16x4*>(dx_bf16 + base + c) = ob;
+                }
+            }
+        }
+    }
+    // combine the 4 waves' column sums, write this block's partial [2][E]
+    if (wid > 0) {
+#pragma unroll
+        for (int i = 0; i < LNA_MAXV; ++i) {
+            const int c = lane * 4 + i * 256;
+            if (c < E) {
+                *reinterpret_cast<float4*>(red + ((size_t)(wid - 1) * 2 + 0) * E + c) = ag[i];
+                *reinterpret_cast<float4*>(red + ((size_t)(wid - 1) * 2 + 1) * E + c) = ab[i];
+            }
+        }
+    }
+    __syncthreads();
+    if (wid == 0) {
+#pragma unroll
+        for (int i = 0; i < LNA_MAXV; ++i) {
+            const int c = lane * 4 + i * 256;
+            if (c < E) {
+                float4 g = ag[i], b = ab[i];
+                for (int w = 0; w < 3; ++w) {
+                    const float4 g2 = *reinterpret_cast<const float4*>(red + ((size_t)w * 2 + 0) * E + c);
+                    const float4 b2 = *reinterpret_cast<const float4*>(red + ((size_t)w * 2 + 1) * E + c);
+                    g.x += g2.x; g.y += g2.y; g.z += g2.z; g.w += g2.w;
+                    b.x += b2.x; b.y += b2.y; b.z += b2.z; b.w += b2.w;
+                }
+                *reinterpret_cast<float4*>(partial + ((size_t)blockIdx.x * 2 + 0) * E + c) = g;
+                *reinterpret_cast<float4*>(partial + ((size_t)blockIdx.x * 2 + 1) * E + c) = b;
+            }
+        }
+    }
+}
+
+// out[l*out_layer + i] += sum_c partial[l*partial_layer + c*n + i]     (fixed order: deterministic)
+__global__ void colsum_reduce_kernel(const float* __restrict__ partial, int chunks, int n, float* out, size_t partial_layer,
+                                     size_t out_layer) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* p = partial + (size_t)blockIdx.y * partial_layer;
+    float s0 = 0.f, s1 = 0.f;
+    int c = 0;
+    for (; c + 1 < chunks; c += 2) { s0 += p[(size_t)c * n + i]; s1 += p[(size_t)(c + 1) * n + i]; }
+    if (c < chunks) s0 += p[(size_t)c * n + i];
+    out[(size_t)blockIdx.y * out_layer + i] += s0 + s1;
+}
+
+// Adapter chain: g_down[j][e] += G_down[e][j] ; g_up[e][j] += G_up[e][j]   (G already chunk-reduced)
+__global__ void chain_adapter_kernel(const float* __restrict__ Gd, const float* __restrict__ Gu, float* g_down, float* g_up,
+                                     int E, size_t g_layer, size_t param_layer) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 64 * E) return;
+    const size_t l = blockIdx.y;
+    const int e = idx >> 6, j = idx & 63;
+    g_down[l * param_layer + (size_t)j * E + e] += Gd[l * g_layer + idx];
+    g_up[l * param_layer + idx] += Gu[l * g_layer + idx];
+}
+
+// Compacter chain: dH -> d W_left / d W_right of both PHM layers.  One block per (layer, which of
+// the 4 small tensors); every output element is a deterministic serial sum.
+//   dH_down[e][j] = Gd[e][j]  (e = a*Fi+k, j = c*16+p) ; dH_up[j][e] = Gu[e][j] (j = a*16+k, e = c*Fi+p)
+__global__ __launch_bounds__(256) void chain_compacter_kernel(const float* __restrict__ Gd, const float* __restrict__ Gu,
+                                                              const float* __restrict__ rule, const float* __restrict__ params,
+                                                              float* grads, int E, size_t g_layer, size_t param_layer,
+                                                              size_t off_dWl, size_t off_dWr, size_t off_uWl, size_t off_uWr) {
+    const size_t l = blockIdx.y;
+    const int which = blockIdx.x;          // 0: d down.W_left, 1: d down.W_right, 2: d up.W_left, 3: d up.W_right
+    const int Fi = E / 4;
+    const float* gd = Gd + l * g_layer; const float* gu = Gu + l * g_layer;
+    const float* P = params + l * param_layer; float* Gp = grads + l * param_layer;
+    const float* dWl = P + off_dWl; const float* dWr = P + off_dWr; const float* uWl = P + off_uWl; const float* uWr = P + off_uWr;
+    const int n = (which == 0 || which == 3) ? 4 * Fi : 64;
+    for (int o = threadIdx.x; o < n; o += blockDim.x) {
+        float s = 0.f;
+        if (which == 0) {            // d dWl[i][k] = sum_{a,c,p} dHd[a*Fi+k][c*16+p] rule[i][a][c] dWr[i][p]
+            const int i = o / Fi, k = o - i * Fi;
+            for (int a = 0; a < 4; ++a) for (int c = 0; c < 4; ++c) {
+                const float rl = rule[i * 16 + a * 4 + c];
+                for (int p = 0; p < 16; ++p) s += gd[(size_t)(a * Fi + k) * 64 + c * 16 + p] * rl * dWr[i * 16 + p];
+            }
+            Gp[off_dWl + o] += s;
+        } else if (which == 1) {     // d dWr[i][p] = sum_{a,c,k} dHd[a*Fi+k][c*16+p] rule[i][a][c] dWl[i][k]
+            const int i = o >> 4, p = o & 15;
+            for (int a = 0; a < 4; ++a) for (int c = 0; c < 4; ++c) {
+                const float rl = rule[i * 16 + a * 4 + c];
+                for (int k = 0; k < Fi; ++k) s += gd[(size_t)(a * Fi + k) * 64 + c * 16 + p] * rl * dWl[i * Fi + k];
+            }
+            Gp[off_dWr + o] += s;
+        } else if (which == 2) {     // d uWl[i][k] = sum_{a,c,p} dHu[a*16+k][c*Fi+p] rule[i][a][c] uWr[i][p]
+            const int i = o >> 4, k = o & 15;
+            for (int a = 0; a < 4; ++a) for (int c = 0; c < 4; ++c) {
+                const float rl = rule[i * 16 + a * 4 + c];
+                for (int p = 0; p < Fi; ++p) s += gu[(size_t)(c * Fi + p) * 64 + a * 16 + k] * rl * uWr[i * Fi + p];
+            }
+            Gp[off_uWl + o] += s;
+        } else {                     // d uWr[i][p] = sum_{a,c,k} dHu[a*16+k][c*Fi+p] rule[i][a][c] uWl[i][k]
+            const int i = o / Fi, p = o - i * Fi;
+            for (int a = 0; a < 4; ++a) for (int c = 0; c < 4; ++c) {
+                const float rl = rule[i * 16 + a * 4 + c];
+                for (int k = 0; k < 16; ++k) s += gu[(size_t)(c * Fi + p) * 64 + a * 16 + k] * rl * uWl[i * 16 + k];
+            }
+            Gp[off_uWr + o] += s;
+        }
+    }
+}
+
+}  // namespace
+
+int pevit_tn_chunks(int T) { return ceil_div(T, TG_ROWS); }
+int pevit_lna_blocks(int rows) { return ceil_div(rows, LNA_ROWS); }
+
+int pevit_launch_prep_adapter(const float* w_down, const float* w_up, BottleneckPanels pan, int E, int layers, LayerStrides st,
+                              hipStream_t s) {
+    hipLaunchKernelGGL(prep_adapter_kernel, dim3(ceil_div(64 * E, 256), layers), dim3(256), 0, s, w_down, w_up, pan, E, st);
+    return 0;
+}
+int pevit_launch_prep_compacter(const float* rule, const float* dWl, const float* dWr, const float* uWl, const float* uWr,
+                                BottleneckPanels pan, int E, int layers, LayerStrides st, hipStream_t s) {
+    if (E % 4) { pevit_set_error("prep_compacter: width %d not divisible by 4", E); return -1; }
+    hipLaunchKernelGGL(prep_compacter_kernel, dim3(ceil_div(64 * E, 256), layers), dim3(256), 0, s, rule, dWl, dWr, uWl, uWr,
+                       pan, E, st);
+    return 0;
+}
+int pevit_launch_tn_gemm64(const bf16* X, int ldx, const bf16* Y, int ldy, float* partial, float* csx, float* csy, int T, int E,
+                           hipStream_t s) {
+    if (E % 64 || (ldx % 8) || (ldy % 8)) { pevit_set_error("tn_gemm64: bad shape E=%d ldx=%d ldy=%d", E, ldx, ldy); return -1; }
+    hipLaunchKernelGGL(tn_gemm64_kernel, dim3(ceil_div(T, TG_ROWS) * (E / 64)), dim3(256), 0, s, X, ldx, Y, ldy, partial, csx,
+                       csy, T, E);
+    return 0;
+}
+int pevit_launch_ln_bwd_affine(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                               const float* dres, float* dx, bf16* dx_bf16, float* partial, int rows, int E, hipStream_t s) {
+    if (E % 4 || E > 256 * LNA_MAXV) { pevit_set_error("ln_bwd_affine: unsupported width %d", E); return -1; }
+    hipLaunchKernelGGL(ln_bwd_affine_kernel, dim3(ceil_div(rows, LNA_ROWS)), dim3(256), 3 * 2 * E * sizeof(float), s, dy, x, mean,
+                       rstd, gamma, dres, dx, dx_bf16, partial, rows, E);
+    return 0;
+}
+int pevit_launch_colsum_reduce(const float* partial, int chunks, int n, float* out, int layers, size_t partial_layer,
+                               size_t out_layer, hipStream_t s) {
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3(ceil_div(n, 256), layers), dim3(256), 0, s, partial, chunks, n, out,
+                       partial_layer, out_layer);
+    return 0;
+}
+int pevit_launch_chain_adapter(const float* Gd, const float* Gu, float* g_down, float* g_up, int E, int layers, size_t g_layer,
+                               size_t param_layer, hipStream_t s) {
+    hipLaunchKernelGGL(chain_adapter_kernel, dim3(ceil_div(64 * E, 256), layers), dim3(256), 0, s, Gd, Gu, g_down, g_up, E,
+                       g_layer, param_layer);
+    return 0;
+}
+int pevit_launch_chain_compacter(const float* Gd, const float* Gu, const float* rule, const float* params, float* grads, int E,
+                                 int layers, size_t g_layer, size_t param_layer, size_t off_dWl, size_t off_dWr, size_t off_uWl,
+                                 size_t off_uWr, hipStream_t s) {
+    hipLaunchKernelGGL(chain_compacter_kernel, dim3(4, layers), dim3(256), 0, s, Gd, Gu, rule, params, grads, E, g_layer,
+                       param_layer, off_dWl, off_dWr, off_uWl, off_uWr);
+    return 0;
+}

@@ -41,10 +41,12 @@ struct BlockArena {        // byte offsets inside the weight arena, one per laye
     size_t wqkv, wqkvT, wo, woT, wfc, wfcT, wpr, wprT;
     size_t bqkv, bo, bfc, bpr, ln1w, ln1b, ln2w, ln2b;
     size_t q32, qT;
+    size_t wd, wdT, wu, wuT;      // post-MLP adapter panels (bf16), rewritten every step
 };
 
 struct LayerSaved {        // byte offsets inside the workspace, one per layer (kept for backward)
     size_t x_in, x_mid, mean1, rstd1, mean2, rstd2, xn1, qkv, t, lse, attn_out, h;
+    size_t hf32, mean_a, rstd_a, z, apre, act;     // post-MLP adapters
 };
 
 }  // namespace
@@ -63,6 +65,9 @@ struct pevit_ctx {
     LayerSaved* sav = nullptr;
     size_t w_xfinal, w_xn2, w_g, w_dqkv, w_u32, w_dO, w_dh, w_dxn, w_dxa, w_dxb, w_dyb, w_partial, w_dbias;
     size_t w_G, w_rule, partial_layer, dbias_layer;
+    size_t w_dpre, w_dht, w_dhb, w_tnU, w_tnD, w_csx, w_csy, w_lnp, w_Gd, w_Gu, tn_layer, csx_layer, csy_layer, lnp_layer;
+    // post-MLP adapter parameter offsets inside one layer's block of the flat buffer (floats)
+    size_t o_nw, o_nb, o_dw, o_db, o_uw, o_ub, o_dWl, o_dWr, o_uWl, o_uWr;
     size_t w_patches, w_xpost, w_feat, w_pmean, w_prstd, w_ybn, w_bnrstd, w_logits, w_dlogits, w_dybn, w_dfeat,
         w_dfeatb, w_dxpost;
     size_t ws_bytes_for_max = 0;
@@ -87,6 +92,7 @@ namespace {
 inline bool attention_site(const pevit_ctx* c) {
     return c->d.method == PEVIT_KADAPTATION || c->d.method == PEVIT_LORA;
 }
+inline bool post_mlp(const pevit_ctx* c) { return c->d.method == PEVIT_ADAPTER || c->d.method == PEVIT_COMPACTER; }
 
 void layout_workspace(pevit_ctx* c, int B, LayerSaved* sav, size_t* total, pevit_ctx* fill) {
     Carver cv;
@@ -103,6 +109,11 @@ void layout_workspace(pevit_ctx* c, int B, LayerSaved* sav, size_t* total, pevit
         s.lse = cv.take((size_t)B * c->H * c->N * 4);
         s.attn_out = cv.take(T * E * 2);
         s.h = cv.take(T * 4 * E * 2);
+        s.hf32 = s.mean_a = s.rstd_a = s.z = s.apre = s.act = 0;
+        if (post_mlp(c)) {
+            s.hf32 = cv.take(T * E * 4); s.mean_a = cv.take(T * 4); s.rstd_a = cv.take(T * 4);
+            s.z = cv.take(T * E * 2); s.apre = cv.take(T * 64 * 2); s.act = cv.take(T * 64 * 2);
+        }
         if (sav) sav[l] = s;
     }
     const int chunks = pevit_lowrank_chunks((int)T);
@@ -124,6 +135,21 @@ void layout_workspace(pevit_ctx* c, int B, LayerSaved* sav, size_t* total, pevit
     o = cv.take(db_layer * c->L);                        if (fill) { fill->w_dbias = o; fill->dbias_layer = db_layer; }
     o = cv.take((size_t)c->L * 4 * E * 32 * 4);          if (fill) fill->w_G = o;
     o = cv.take((size_t)c->L * 4096 * 4);                if (fill) fill->w_rule = o;
+    if (post_mlp(c)) {
+        const int tch = pevit_tn_chunks((int)T), lnb = pevit_lna_blocks((int)T);
+        const size_t tn_layer = (size_t)tch * E * 64 * 4, csx_layer = (size_t)tch * E * 4, csy_layer = (size_t)tch * 64 * 4,
+                     lnp_layer = (size_t)lnb * 2 * E * 4;
+        o = cv.take(T * 64 * 2);            if (fill) fill->w_dpre = o;
+        o = cv.take(T * E * 4);             if (fill) fill->w_dht = o;
+        o = cv.take(T * E * 2);             if (fill) fill->w_dhb = o;
+        o = cv.take(tn_layer * c->L);       if (fill) { fill->w_tnU = o; fill->tn_layer = tn_layer; }
+        o = cv.take(tn_layer * c->L);       if (fill) fill->w_tnD = o;
+        o = cv.take(csx_layer * c->L);      if (fill) { fill->w_csx = o; fill->csx_layer = csx_layer; }
+        o = cv.take(csy_layer * c->L);      if (fill) { fill->w_csy = o; fill->csy_layer = csy_layer; }
+        o = cv.take(lnp_layer * c->L);      if (fill) { fill->w_lnp = o; fill->lnp_layer = lnp_layer; }
+        o = cv.take((size_t)c->L * E * 64 * 4);  if (fill) fill->w_Gd = o;
+        o = cv.take((size_t)c->L * E * 64 * 4);  if (fill) fill->w_Gu = o;
+    }
     const size_t Bz = (size_t)B, D = c->D, Cc = c->C;
     o = cv.take(Bz * c->G2 * (size_t)c->Kpatch * 2);      if (fill) fill->w_patches = o;
     o = cv.take(Bz * E * 2);      if (fill) fill->w_xpost = o;
@@ -190,6 +216,7 @@ extern "C" int pevit_ctx_create(const pevit_dims* dims, pevit_ctx** out) {
         b.bqkv = cv.take(3 * E * 4); b.bo = cv.take(E * 4); b.bfc = cv.take(4 * E * 4); b.bpr = cv.take(E * 4);
         b.ln1w = cv.take(E * 4); b.ln1b = cv.take(E * 4); b.ln2w = cv.take(E * 4); b.ln2b = cv.take(E * 4);
         b.q32 = cv.take(E * 64 * 4); b.qT = cv.take(64 * E * 2);
+        b.wd = cv.take(64 * E * 2); b.wdT = cv.take(64 * E * 2); b.wu = cv.take(64 * E * 2); b.wuT = cv.take(64 * E * 2);
     }
     c->a_conv = cv.take(align_up(E, 128) * (size_t)c->Kpatch * 2);
     c->a_cls = cv.take(E * 4);
@@ -206,8 +233,19 @@ extern "C" int pevit_ctx_create(const pevit_dims* dims, pevit_ctx** out) {
         c->p_layer0 = 4 * 32 * 32; c->p_layer_stride = 5 * E;
     } else if (d.method == PEVIT_LORA) {
         c->p_layer0 = 0; c->p_layer_stride = 4 * (size_t)d.lora_rank * E;
+    } else if (d.method == PEVIT_ADAPTER) {
+        // adapter_norm_before.{weight,bias}, adapter_down.1.{weight (64,E), bias}, adapter_up.{weight (E,64), bias}
+        c->o_nw = 0; c->o_nb = E; c->o_dw = 2 * E; c->o_db = c->o_dw + 64 * E; c->o_uw = c->o_db + 64;
+        c->o_ub = c->o_uw + 64 * E;
+        c->p_layer0 = 0; c->p_layer_stride = c->o_ub + E;
+    } else if (d.method == PEVIT_COMPACTER) {
+        // adapter_norm_before.{weight,bias}, adapter_down.1.{W_left (4,E/4,1), W_right (4,1,16), b (64)},
+        // adapter_up.{W_left (4,16,1), W_right (4,1,E/4), b (E)}
+        c->o_nw = 0; c->o_nb = E; c->o_dWl = 2 * E; c->o_dWr = c->o_dWl + E; c->o_db = c->o_dWr + 64;
+        c->o_uWl = c->o_db + 64; c->o_uWr = c->o_uWl + 64; c->o_ub = c->o_uWr + E;
+        c->p_layer0 = 0; c->p_layer_stride = c->o_ub + E;
     } else {
-        c->p_layer0 = 0; c->p_layer_stride = 0;      // post-MLP adapters: added in adapter.hip
+        c->p_layer0 = 0; c->p_layer_stride = 0;
     }
     c->n_tower = c->p_layer0 + c->p_layer_stride * c->L;
     c->p_head_w = c->n_tower;
@@ -340,6 +378,15 @@ int prep_adapters(pevit_ctx* c, hipStream_t s) {
         const size_t rE = (size_t)c->d.lora_rank * E;
         CHECK(pevit_launch_prep_lora(lp, lp + rE, lp + 2 * rE, lp + 3 * rE, c->d.lora_rank, panels(c, 0), c->E, c->ascale,
                                      c->L, st, s));
+    } else if (post_mlp(c)) {
+        const BlockArena& b0 = c->blk[0];
+        BottleneckPanels bp{at<bf16>(c->arena, b0.wd), at<bf16>(c->arena, b0.wdT), at<bf16>(c->arena, b0.wu),
+                            at<bf16>(c->arena, b0.wuT)};
+        if (c->d.method == PEVIT_ADAPTER)
+            CHECK(pevit_launch_prep_adapter(lp + c->o_dw, lp + c->o_uw, bp, c->E, c->L, st, s));
+        else
+            CHECK(pevit_launch_prep_compacter(at<float>(c->arena, c->a_phm), lp + c->o_dWl, lp + c->o_dWr, lp + c->o_uWl,
+                                              lp + c->o_uWr, bp, c->E, c->L, st, s));
     }
     return 0;
 }
@@ -370,7 +417,7 @@ int blocks_forward(pevit_ctx* c, hipStream_t s, int B) {
     const int E = c->E, T = B * c->N, H = c->H, N = c->N;
     char* W = c->ws; char* A = c->arena;
     const bool site = attention_site(c);
-    if (site) CHECK(prep_adapters(c, s));
+    if (site || post_mlp(c)) CHECK(prep_adapters(c, s));
     for (int l = 0; l < c->L; ++l) {
         const BlockArena& b = c->blk[l];
         const LayerSaved& v = c->sav[l];
@@ -410,10 +457,38 @@ int blocks_forward(pevit_ctx* c, hipStream_t s, int B) {
             p.ldob2 = 4 * E;
             CHECK(gemm(c, EPI_BIAS_GELU, p, s));
         }
-        {
+        if (!post_mlp(c)) {
             GemmParams p = gp(at<bf16>(W, c->w_g), 4 * E, at<bf16>(A, b.wpr), 4 * E, E, T, E, 4 * E);
             p.bias = at<float>(A, b.bpr); p.resid = x_mid; p.ldr = E; p.outf = x_out; p.ldo = E;
             CHECK(gemm(c, EPI_BIAS_RESID_F32, p, s));
+        } else {
+            // x = x + [h + up(act(down(LN_a(h))))]         adapter_model.py:330-336 / compacter_model.py:497-503
+            const float* lp = c->params + c->p_layer0 + c->p_layer_stride * l;
+            float* ytmp = at<float>(W, c->w_dxn);           // x_mid + h ; scratch that is free during the forward pass
+            {
+                GemmParams p = gp(at<bf16>(W, c->w_g), 4 * E, at<bf16>(A, b.wpr), 4 * E, E, T, E, 4 * E);
+                p.bias = at<float>(A, b.bpr); p.resid = x_mid; p.ldr = E; p.outf = ytmp; p.ldo = E;
+                p.outf2 = at<float>(W, v.hf32); p.ldo2 = E;
+                CHECK(gemm(c, EPI_BIAS_RESID_KEEP, p, s));
+            }
+            CHECK(pevit_launch_ln_fwd(at<float>(W, v.hf32), lp + c->o_nw, lp + c->o_nb, T, E, at<bf16>(W, v.z), nullptr,
+                                      at<float>(W, v.mean_a), at<float>(W, v.rstd_a), s));
+            {
+                GemmParams p = gp(at<bf16>(W, v.z), E, at<bf16>(A, b.wd), E, 64, T, 64, E);
+                p.bias = lp + c->o_db;
+                if (c->d.method == PEVIT_ADAPTER) {
+                    p.outb = at<bf16>(W, v.act); p.ldob = 64;
+                    CHECK(gemm(c, EPI_BIAS_RELU_BF16, p, s));
+                } else {
+                    p.outb = at<bf16>(W, v.apre); p.ldob = 64; p.outb2 = at<bf16>(W, v.act); p.ldob2 = 64;
+                    CHECK(gemm(c, EPI_BIAS_GELUNEW, p, s));
+                }
+            }
+            {
+                GemmParams p = gp(at<bf16>(W, v.act), 64, at<bf16>(A, b.wu), 64, E, T, E, 64);
+                p.bias = lp + c->o_ub; p.resid = ytmp; p.ldr = E; p.outf = x_out; p.ldo = E;
+                CHECK(gemm(c, EPI_BIAS_RESID_F32, p, s));
+            }
         }
     }
     return 0;
@@ -436,9 +511,38 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0) {
         const LayerSaved& v = c->sav[l];
         bf16* qkv = at<bf16>(W, v.qkv);
         const size_t plane = (size_t)T * E;
+        const bf16* mlp_dy = dyb;          // upstream gradient of the MLP output (bf16)
+        if (post_mlp(c)) {
+            // out = x_mid + h + up(act(down(LN_a(h)))) :  dx_out (dxa, dyb) flows to x_mid, to h, and into the adapter
+            const float* lp = c->params + c->p_layer0 + c->p_layer_stride * l;
+            bf16* dpre = at<bf16>(W, c->w_dpre);
+            // d W_up[e][j] = sum_r dx_out[r][e] act[r][j] ; d b_up = colsum(dx_out)
+            CHECK(pevit_launch_tn_gemm64(dyb, E, at<bf16>(W, v.act), 64, at<float>(W, c->w_tnU + (size_t)l * c->tn_layer),
+                                         at<float>(W, c->w_csx + (size_t)l * c->csx_layer), nullptr, T, E, s));
+            {   // d act = dx_out W_up ; d pre = d act * act'(pre)
+                GemmParams p = gp(dyb, E, at<bf16>(A, b.wuT), E, 64, T, 64, E);
+                p.outb = dpre; p.ldob = 64; p.ldaux = 64;
+                if (c->d.method == PEVIT_ADAPTER) { p.aux = at<bf16>(W, v.act); CHECK(gemm(c, EPI_DRELU_BF16, p, s)); }
+                else { p.aux = at<bf16>(W, v.apre); CHECK(gemm(c, EPI_DGELUNEW_BF16, p, s)); }
+            }
+            // d W_down[j][e] = sum_r d pre[r][j] z[r][e] ; d b_down = colsum(d pre)
+            CHECK(pevit_launch_tn_gemm64(at<bf16>(W, v.z), E, dpre, 64, at<float>(W, c->w_tnD + (size_t)l * c->tn_layer), nullptr,
+                                         at<float>(W, c->w_csy + (size_t)l * c->csy_layer), T, E, s));
+            {   // d z = d pre W_down
+                GemmParams p = gp(dpre, 64, at<bf16>(A, b.wdT), 64, E, T, E, 64);
+                p.outf = dxn; p.ldo = E;
+                CHECK(gemm(c, EPI_F32, p, s));
+            }
+            // d h = dx_out + LN_a-backward(d z) ; partial sums for d gamma_a, d beta_a
+            CHECK(pevit_launch_ln_bwd_affine(dxn, at<float>(W, v.hf32), at<float>(W, v.mean_a), at<float>(W, v.rstd_a), lp + c->o_nw,
+                                             dxa, at<float>(W, c->w_dht), at<bf16>(W, c->w_dhb),
+                                             at<float>(W, c->w_lnp + (size_t)l * c->lnp_layer), T, E, s));
+            mlp_dy = at<bf16>(W, c->w_dhb);
+            if (l == 0 && !need_dx0) break;     // nothing trainable below the first block's adapter
+        }
         // ---- MLP branch: d h = (dy W_proj) * gelu'(h) ; d xn2 = d h W_fc
         {
-            GemmParams p = gp(dyb, E, at<bf16>(A, b.wprT), E, 4 * E, T, 4 * E, E);
+            GemmParams p = gp(mlp_dy, E, at<bf16>(A, b.wprT), E, 4 * E, T, 4 * E, E);
             p.aux = at<bf16>(W, v.h); p.ldaux = 4 * E; p.outb = at<bf16>(W, c->w_dh); p.ldob = 4 * E;
             CHECK(gemm(c, EPI_DGELU_BF16, p, s));
         }
@@ -479,6 +583,25 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0) {
     } else if (c->d.method == PEVIT_LORA) {
         CHECK(pevit_launch_chain_lora(at<float>(W, c->w_partial), c->partial_layer / 4, chunks, c->ascale, c->d.lora_rank,
                                       c->L, at<float>(W, c->w_G), c->grads, c->p_layer0, c->p_layer_stride, E, s));
+    } else if (post_mlp(c)) {
+        const int tch = pevit_tn_chunks(T), lnb = pevit_lna_blocks(T);
+        const size_t ps = c->p_layer_stride, gl = (size_t)E * 64;
+        float* g0 = c->grads + c->p_layer0;
+        HIP_OK(hipMemsetAsync(W + c->w_Gd, 0, (size_t)c->L * gl * 4 * 2, s));       // Gd and Gu are adjacent
+        CHECK(pevit_launch_colsum_reduce(at<float>(W, c->w_tnD), tch, (int)gl, at<float>(W, c->w_Gd), c->L, c->tn_layer / 4, gl, s));
+        CHECK(pevit_launch_colsum_reduce(at<float>(W, c->w_tnU), tch, (int)gl, at<float>(W, c->w_Gu), c->L, c->tn_layer / 4, gl, s));
+        // biases and LayerNorm affine: straight column sums into the flat gradient buffer
+        CHECK(pevit_launch_colsum_reduce(at<float>(W, c->w_csx), tch, E, g0 + c->o_ub, c->L, c->csx_layer / 4, ps, s));
+        CHECK(pevit_launch_colsum_reduce(at<float>(W, c->w_csy), tch, 64, g0 + c->o_db, c->L, c->csy_layer / 4, ps, s));
+        CHECK(pevit_launch_colsum_reduce(at<float>(W, c->w_lnp), lnb, 2 * E, g0 + c->o_nw, c->L, c->lnp_layer / 4, ps, s));
+        if (c->d.method == PEVIT_ADAPTER) {
+            CHECK(pevit_launch_chain_adapter(at<float>(W, c->w_Gd), at<float>(W, c->w_Gu), g0 + c->o_dw, g0 + c->o_uw, E, c->L, gl,
+                                             ps, s));
+        } else {
+            CHECK(pevit_launch_chain_compacter(at<float>(W, c->w_Gd), at<float>(W, c->w_Gu), at<float>(c->arena, c->a_phm),
+                                               c->params + c->p_layer0, g0, E, c->L, gl, ps, c->o_dWl, c->o_dWr, c->o_uWl,
+                                               c->o_uWr, s));
+        }
     }
     return 0;
 }
@@ -488,9 +611,6 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0) {
 extern "C" int pevit_transformer_forward(pevit_ctx* c, void* stream, const float* x_nbe, float* y_nbe, int B,
                                          int save_for_backward) {
     CHECK(check_ready(c, B, "transformer_forward"));
-    if (!attention_site(c) && c->d.method != PEVIT_NONE) {
-        pevit_set_error("transformer_forward: method %d not built into this library yet", c->d.method); return -1;
-    }
     hipStream_t s = (hipStream_t)stream;
     size_t total; layout_workspace(c, B, c->sav, &total, c);
     CHECK(pevit_launch_permute_rows(x_nbe, at<float>(c->ws, c->sav[0].x_in), c->N, B, c->E, 1, s));
@@ -556,9 +676,6 @@ extern "C" int pevit_load_phm_rule(pevit_ctx* c, void* stream, const float* phm_
 extern "C" int pevit_visual_forward(pevit_ctx* c, void* stream, const float* images, float* feat, int B,
                                     int save_for_backward) {
     CHECK(check_ready(c, B, "visual_forward"));
-    if (!attention_site(c) && c->d.method != PEVIT_NONE) {
-        pevit_set_error("visual_forward: method %d not built into this library yet", c->d.method); return -1;
-    }
     hipStream_t s = (hipStream_t)stream;
     size_t total; layout_workspace(c, B, c->sav, &total, c);
     char* W = c->ws; char* A = c->arena;

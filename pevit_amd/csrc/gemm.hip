@@ -30,6 +30,16 @@ constexpr int TILE_BAND = 6;
 int g_gemm_config = -1;    // -1: heuristic ; >= 0: force a tile configuration (A/B measurements)
 
 __device__ __forceinline__ float sigmoidf_fast(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// transformers' "gelu_new" (compacter_model.py:8,172): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+__device__ __forceinline__ float gelu_new_f(float x) {
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    return 0.5f * x * (1.0f + tanhf(u));
+}
+__device__ __forceinline__ float gelu_new_grad_f(float x) {
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    const float th = tanhf(u);
+    return 0.5f * (1.0f + th) + 0.5f * x * (1.0f - th * th) * 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * x * x);
+}
 
 template <int EPI>
 __device__ __forceinline__ void epilogue_store(const GemmParams& p, int row, int col, float v[8]) {
@@ -118,6 +128,45 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int row, int
         float* dst = p.outf + ((size_t)b * p.Ntok + 1 + g) * p.ldo + col;
         *reinterpret_cast<float4*>(dst) = make_float4(v[0] + r0.x, v[1] + r0.y, v[2] + r0.z, v[3] + r0.w);
         *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4] + r1.x, v[5] + r1.y, v[6] + r1.z, v[7] + r1.w);
+    } else if constexpr (EPI == EPI_BIAS_RESID_KEEP) {
+        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + col);
+        const float4 b1 = *reinterpret_cast<const float4*>(p.bias + col + 4);
+        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+        v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+        float* d2 = p.outf2 + (size_t)row * p.ldo2 + col;
+        *reinterpret_cast<float4*>(d2) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(d2 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        const float* r = p.resid + (size_t)row * p.ldr + col;
+        const float4 r0 = *reinterpret_cast<const float4*>(r);
+        const float4 r1 = *reinterpret_cast<const float4*>(r + 4);
+        float* dst = p.outf + (size_t)row * p.ldo + col;
+        *reinterpret_cast<float4*>(dst) = make_float4(v[0] + r0.x, v[1] + r0.y, v[2] + r0.z, v[3] + r0.w);
+        *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4] + r1.x, v[5] + r1.y, v[6] + r1.z, v[7] + r1.w);
+    } else if constexpr (EPI == EPI_BIAS_GELUNEW) {
+        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + col);
+        const float4 b1 = *reinterpret_cast<const float4*>(p.bias + col + 4);
+        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+        v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+        bf16x8 a, g;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            a[i] = f2bf(v[i]);
+            g[i] = f2bf(gelu_new_f(bf2f(a[i])));
+        }
+        store_bf16x8(p.outb + (size_t)row * p.ldob + col, a);
+        store_bf16x8(p.outb2 + (size_t)row * p.ldob2 + col, g);
+    } else if constexpr (EPI == EPI_DRELU_BF16) {
+        const bf16x8 a = load_bf16x8(p.aux + (size_t)row * p.ldaux + col);
+        bf16x8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = f2bf(bf2f(a[i]) > 0.f ? v[i] : 0.f);
+        store_bf16x8(p.outb + (size_t)row * p.ldob + col, o);
+    } else if constexpr (EPI == EPI_DGELUNEW_BF16) {
+        const bf16x8 a = load_bf16x8(p.aux + (size_t)row * p.ldaux + col);
+        bf16x8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = f2bf(v[i] * gelu_new_grad_f(bf2f(a[i])));
+        store_bf16x8(p.outb + (size_t)row * p.ldob + col, o);
     } else if constexpr (EPI == EPI_BIAS_RELU_BF16) {
         const float4 b0 = *reinterpret_cast<const float4*>(p.bias + col);
         const float4 b1 = *reinterpret_cast<const float4*>(p.bias + col + 4);
@@ -294,6 +343,7 @@ int launch_cfg(const GemmParams& p, hipStream_t stream) {
 // products want the 128x128 tile, the N = 768 products want 4x as many, smaller workgroups.
 int pick_config(const GemmParams& p) {
     if (g_gemm_config >= 0 && g_gemm_config < kNumConfigs) return g_gemm_config;
+    if (p.N <= 64) return 3;                      // bottleneck products: 64-wide tiles
     const long t128 = (long)ceil_div(p.M, 128) * ceil_div(p.N, 128);
     return t128 >= 700 ? 0 : 2;
 }
@@ -328,6 +378,10 @@ int pevit_launch_gemm(int epi, const GemmParams& p, hipStream_t stream) {
         case EPI_BIAS_BF16: return launch_epi<EPI_BIAS_BF16>(p, stream);
         case EPI_PATCH_EMBED: return launch_epi<EPI_PATCH_EMBED>(p, stream);
         case EPI_BIAS_RELU_BF16: return launch_epi<EPI_BIAS_RELU_BF16>(p, stream);
+        case EPI_BIAS_RESID_KEEP: return launch_epi<EPI_BIAS_RESID_KEEP>(p, stream);
+        case EPI_BIAS_GELUNEW: return launch_epi<EPI_BIAS_GELUNEW>(p, stream);
+        case EPI_DRELU_BF16: return launch_epi<EPI_DRELU_BF16>(p, stream);
+        case EPI_DGELUNEW_BF16: return launch_epi<EPI_DGELUNEW_BF16>(p, stream);
     }
     pevit_set_error("gemm: unknown epilogue %d", epi);
     return -1;

@@ -12,6 +12,10 @@ enum GemmEpilogue {
     EPI_BIAS_BF16 = 6,       // out_bf16 = acc + bias
     EPI_PATCH_EMBED = 7,     // out_f32[b*Ntok+1+g] = acc + pos[1+g]
     EPI_BIAS_RELU_BF16 = 8,  // out_bf16 = relu(acc + bias)
+    EPI_BIAS_RESID_KEEP = 9, // out_f32 = acc + bias + resid ; out2_f32 = acc + bias   (post-MLP adapters need h itself)
+    EPI_BIAS_GELUNEW = 10,   // a = acc + bias (bf16, saved) ; g = gelu_new(a) (bf16)
+    EPI_DRELU_BF16 = 11,     // out_bf16 = acc * (aux > 0)
+    EPI_DGELUNEW_BF16 = 12,  // out_bf16 = acc * gelu_new'(aux)
 };
 
 struct GemmParams {
@@ -21,6 +25,7 @@ struct GemmParams {
     const float* bias;
     const float* resid; int ldr;
     float* outf; int ldo;
+    float* outf2; int ldo2;
     bf16* outb; int ldob;
     bf16* outb2; int ldob2;
     const bf16* aux; int ldaux;
@@ -107,3 +112,24 @@ int pevit_launch_cls_row(const float* cls, const float* pos, float* x, int B, in
 int pevit_launch_head(const float* feat, const int64_t* labels, const float* W, const float* bias, float* gW, float* gb,
                       float* running_mean, float* running_var, int training, float* ybn, float* rstd, float* logits,
                       float* dlogits, float* dybn, float* loss, float* dfeat, int B, int D, int Cc, hipStream_t s);
+
+// ---- adapter.hip (post-MLP bottleneck adapters: Adapter, Compacter) -------------------------------
+struct BottleneckPanels { bf16* wd; bf16* wdT; bf16* wu; bf16* wuT; };   // [64][E], [E][64], [E][64], [64][E]
+int pevit_tn_chunks(int T);
+int pevit_lna_blocks(int rows);
+int pevit_launch_prep_adapter(const float* w_down, const float* w_up, BottleneckPanels pan, int E, int layers, LayerStrides st,
+                              hipStream_t s);
+int pevit_launch_prep_compacter(const float* rule, const float* dWl, const float* dWr, const float* uWl, const float* uWr,
+                                BottleneckPanels pan, int E, int layers, LayerStrides st, hipStream_t s);
+// G[e][j] = sum_r X[r][e] Y[r][j] (per-chunk partials [chunk][E][64]); optional column sums of X / Y
+int pevit_launch_tn_gemm64(const bf16* X, int ldx, const bf16* Y, int ldy, float* partial, float* csx, float* csy, int T, int E,
+                           hipStream_t s);
+int pevit_launch_ln_bwd_affine(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                               const float* dres, float* dx, bf16* dx_bf16, float* partial, int rows, int E, hipStream_t s);
+int pevit_launch_colsum_reduce(const float* partial, int chunks, int n, float* out, int layers, size_t partial_layer,
+                               size_t out_layer, hipStream_t s);
+int pevit_launch_chain_adapter(const float* Gd, const float* Gu, float* g_down, float* g_up, int E, int layers, size_t g_layer,
+                               size_t param_layer, hipStream_t s);
+int pevit_launch_chain_compacter(const float* Gd, const float* Gu, const float* rule, const float* params, float* grads, int E,
+                                 int layers, size_t g_layer, size_t param_layer, size_t off_dWl, size_t off_dWr, size_t off_uWl,
+                                 size_t off_uWr, hipStream_t s);
