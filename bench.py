@@ -97,21 +97,19 @@ def main():
         torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from pevit_amd.engine import HipEngine
-    from pevit_amd.synth import ARCHS, synth_batch, synth_state_dict
+    from pevit_amd.synth import ARCHS, reference_init_, synth_batch, synth_state_dict
     arch = ARCHS[args.arch]
     classes = 100
     sd = synth_state_dict(arch, seed=2, text_tower=False)
+    if args.method == "compacter":      # frozen shared rule ~ U(-1,1) (compacter_model.py:511-519)
+        sd["visual.transformer.phm_rule"] = torch.rand((4, 4, 4), generator=torch.Generator().manual_seed(4)) * 2 - 1
     eng = HipEngine(arch, args.method, classes, args.batch, lora_rank=8 if args.method == "lora" else 4, device=dev)
     eng.load_state_dict(sd)
     # adapters at the reference initialisation; head ~ nn.Linear default
     views = eng.param_views()
+    reference_init_(views.items(), args.method)
     g = torch.Generator().manual_seed(5)
     with torch.no_grad():
-        for name, v in views.items():
-            if "phm_rule" in name:
-                v.copy_(((torch.rand(v.shape, generator=g) * 2 - 1) * 0.01).to(dev))
-            elif name.endswith("adapter1.weight"):
-                v.copy_((torch.randn(v.shape, generator=g) * 0.02).to(dev))
         bound = arch.embed_dim ** -0.5
         views["layers.0.weight"].copy_(((torch.rand(views["layers.0.weight"].shape, generator=g) * 2 - 1) * bound).to(dev))
         views["layers.0.bias"].copy_(((torch.rand(views["layers.0.bias"].shape, generator=g) * 2 - 1) * bound).to(dev))

@@ -156,7 +156,9 @@ __global__ __launch_bounds__(256) void tn_gemm64_kernel(const bf16* __restrict__
 
 // ---------------------------------------------------------------------------------------------
 // LayerNorm backward with trainable affine: dx (+ dres) as ln_bwd, plus per-block partial sums of
-// d gamma = sum_r dy*xhat and d beta = sum_r dy.   Block = 64 rows (16 per wave).
+// d gamma = sum_r dy*xhat, d beta = sum_r dy, and the f32 column sums of dres (the gradient of the
+// adapter's up-projection bias: summing its bf16 copy instead loses the cancellation-heavy sum).
+// Block = 64 rows (16 per wave); partial[block][3][E].
 constexpr int LNA_ROWS = 64;
 constexpr int LNA_MAXV = 4;
 __global__ __launch_bounds__(256) void ln_bwd_affine_kernel(const float* __restrict__ dy, const float* __restrict__ x,
@@ -164,11 +166,13 @@ __global__ __launch_bounds__(256) void ln_bwd_affine_kernel(const float* __restr
                                                             const float* __restrict__ gamma, const float* dres, float* dx,
                                                             bf16* __restrict__ dx_bf16, float* __restrict__ partial, int rows,
                                                             int E) {
-    extern __shared__ float red[];     // [3 waves][2][E]
+    extern __shared__ float red[];     // [3 waves][3][E]
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    float4 ag[LNA_MAXV], ab[LNA_MAXV];
+    float4 ag[LNA_MAXV], ab[LNA_MAXV], ar[LNA_MAXV];      // sums of dy*xhat, dy, dres
 #pragma unroll
-    for (int i = 0; i < LNA_MAXV; ++i) { ag[i] = make_float4(0.f, 0.f, 0.f, 0.f); ab[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    for (int i = 0; i < LNA_MAXV; ++i) {
+        ag[i] = make_float4(0.f, 0.f, 0.f, 0.f); ab[i] = make_float4(0.f, 0.f, 0.f, 0.f); ar[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     for (int rr = wid; rr < LNA_ROWS; rr += 4) {
         const int row = blockIdx.x * LNA_ROWS + rr;
         if (row >= rows) break;
@@ -202,6 +206,7 @@ __global__ __launch_bounds__(256) void ln_bwd_affine_kernel(const float* __restr
                 if (dres) {
                     const float4 r = *reinterpret_cast<const float4*>(dres + base + c);
                     o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+                    ar[i].x += r.x; ar[i].y += r.y; ar[i].z += r.z; ar[i].w += r.w;
                 }
                 *reinterpret_cast<float4*>(dx + base + c) = o;
                 if (dx_bf16) {
@@ -218,8 +223,9 @@ __global__ __launch_bounds__(256) void ln_bwd_affine_kernel(const float* __restr
         for (int i = 0; i < LNA_MAXV; ++i) {
             const int c = lane * 4 + i * 256;
             if (c < E) {
-                *reinterpret_cast<float4*>(red + ((size_t)(wid - 1) * 2 + 0) * E + c) = ag[i];
-                *reinterpret_cast<float4*>(red + ((size_t)(wid - 1) * 2 + 1) * E + c) = ab[i];
+                *reinterpret_cast<float4*>(red + ((size_t)(wid - 1) * 3 + 0) * E + c) = ag[i];
+                *reinterpret_cast<float4*>(red + ((size_t)(wid - 1) * 3 + 1) * E + c) = ab[i];
+                *reinterpret_cast<float4*>(red + ((size_t)(wid - 1) * 3 + 2) * E + c) = ar[i];
             }
         }
     }
@@ -229,15 +235,18 @@ __global__ __launch_bounds__(256) void ln_bwd_affine_kernel(const float* __restr
         for (int i = 0; i < LNA_MAXV; ++i) {
             const int c = lane * 4 + i * 256;
             if (c < E) {
-                float4 g = ag[i], b = ab[i];
+                float4 g = ag[i], b = ab[i], r = ar[i];
                 for (int w = 0; w < 3; ++w) {
-                    const float4 g2 = *reinterpret_cast<const float4*>(red + ((size_t)w * 2 + 0) * E + c);
-                    const float4 b2 = *reinterpret_cast<const float4*>(red + ((size_t)w * 2 + 1) * E + c);
+                    const float4 g2 = *reinterpret_cast<const float4*>(red + ((size_t)w * 3 + 0) * E + c);
+                    const float4 b2 = *reinterpret_cast<const float4*>(red + ((size_t)w * 3 + 1) * E + c);
+                    const float4 r2 = *reinterpret_cast<const float4*>(red + ((size_t)w * 3 + 2) * E + c);
                     g.x += g2.x; g.y += g2.y; g.z += g2.z; g.w += g2.w;
                     b.x += b2.x; b.y += b2.y; b.z += b2.z; b.w += b2.w;
+                    r.x += r2.x; r.y += r2.y; r.z += r2.z; r.w += r2.w;
                 }
-                *reinterpret_cast<float4*>(partial + ((size_t)blockIdx.x * 2 + 0) * E + c) = g;
-                *reinterpret_cast<float4*>(partial + ((size_t)blockIdx.x * 2 + 1) * E + c) = b;
+                *reinterpret_cast<float4*>(partial + ((size_t)blockIdx.x * 3 + 0) * E + c) = g;
+                *reinterpret_cast<float4*>(partial + ((size_t)blockIdx.x * 3 + 1) * E + c) = b;
+                *reinterpret_cast<float4*>(partial + ((size_t)blockIdx.x * 3 + 2) * E + c) = r;
             }
         }
     }
@@ -254,6 +263,21 @@ __global__ void colsum_reduce_kernel(const float* __restrict__ partial, int chun
     for (; c + 1 < chunks; c += 2) { s0 += p[(size_t)c * n + i]; s1 += p[(size_t)(c + 1) * n + i]; }
     if (c < chunks) s0 += p[(size_t)c * n + i];
     out[(size_t)blockIdx.y * out_layer + i] += s0 + s1;
+}
+
+// partial[l][block][3][n] -> out0/out1/out2[l*out_layer + i] += sum over blocks
+__global__ void colsum_reduce3_kernel(const float* __restrict__ partial, int chunks, int n, float* o0, float* o1, float* o2,
+                                      size_t partial_layer, size_t out_layer) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * n) return;
+    const int which = i / n, e = i - which * n;
+    const float* p = partial + (size_t)blockIdx.y * partial_layer;
+    float s0 = 0.f, s1 = 0.f;
+    int c = 0;
+    for (; c + 1 < chunks; c += 2) { s0 += p[(size_t)c * 3 * n + i]; s1 += p[(size_t)(c + 1) * 3 * n + i]; }
+    if (c < chunks) s0 += p[(size_t)c * 3 * n + i];
+    float* o = which == 0 ? o0 : (which == 1 ? o1 : o2);
+    o[(size_t)blockIdx.y * out_layer + e] += s0 + s1;
 }
 
 // Adapter chain: g_down[j][e] += G_down[e][j] ; g_up[e][j] += G_up[e][j]   (G already chunk-reduced)
@@ -342,13 +366,19 @@ int pevit_launch_tn_gemm64(const bf16* X, int ldx, const bf16* Y, int ldy, float
 int pevit_launch_ln_bwd_affine(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                                const float* dres, float* dx, bf16* dx_bf16, float* partial, int rows, int E, hipStream_t s) {
     if (E % 4 || E > 256 * LNA_MAXV) { pevit_set_error("ln_bwd_affine: unsupported width %d", E); return -1; }
-    hipLaunchKernelGGL(ln_bwd_affine_kernel, dim3(ceil_div(rows, LNA_ROWS)), dim3(256), 3 * 2 * E * sizeof(float), s, dy, x, mean,
+    hipLaunchKernelGGL(ln_bwd_affine_kernel, dim3(ceil_div(rows, LNA_ROWS)), dim3(256), 3 * 3 * E * sizeof(float), s, dy, x, mean,
                        rstd, gamma, dres, dx, dx_bf16, partial, rows, E);
     return 0;
 }
 int pevit_launch_colsum_reduce(const float* partial, int chunks, int n, float* out, int layers, size_t partial_layer,
                                size_t out_layer, hipStream_t s) {
     hipLaunchKernelGGL(colsum_reduce_kernel, dim3(ceil_div(n, 256), layers), dim3(256), 0, s, partial, chunks, n, out,
+                       partial_layer, out_layer);
+    return 0;
+}
+int pevit_launch_colsum_reduce3(const float* partial, int chunks, int n, float* o0, float* o1, float* o2, int layers,
+                                size_t partial_layer, size_t out_layer, hipStream_t s) {
+    hipLaunchKernelGGL(colsum_reduce3_kernel, dim3(ceil_div(3 * n, 256), layers), dim3(256), 0, s, partial, chunks, n, o0, o1, o2,
                        partial_layer, out_layer);
     return 0;
 }

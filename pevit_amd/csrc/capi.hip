@@ -138,7 +138,7 @@ void layout_workspace(pevit_ctx* c, int B, LayerSaved* sav, size_t* total, pevit
     if (post_mlp(c)) {
         const int tch = pevit_tn_chunks((int)T), lnb = pevit_lna_blocks((int)T);
         const size_t tn_layer = (size_t)tch * E * 64 * 4, csx_layer = (size_t)tch * E * 4, csy_layer = (size_t)tch * 64 * 4,
-                     lnp_layer = (size_t)lnb * 2 * E * 4;
+                     lnp_layer = (size_t)lnb * 3 * E * 4;
         o = cv.take(T * 64 * 2);            if (fill) fill->w_dpre = o;
         o = cv.take(T * E * 4);             if (fill) fill->w_dht = o;
         o = cv.take(T * E * 2);             if (fill) fill->w_dhb = o;
@@ -518,7 +518,7 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0) {
             bf16* dpre = at<bf16>(W, c->w_dpre);
             // d W_up[e][j] = sum_r dx_out[r][e] act[r][j] ; d b_up = colsum(dx_out)
             CHECK(pevit_launch_tn_gemm64(dyb, E, at<bf16>(W, v.act), 64, at<float>(W, c->w_tnU + (size_t)l * c->tn_layer),
-                                         at<float>(W, c->w_csx + (size_t)l * c->csx_layer), nullptr, T, E, s));
+                                         nullptr, nullptr, T, E, s));
             {   // d act = dx_out W_up ; d pre = d act * act'(pre)
                 GemmParams p = gp(dyb, E, at<bf16>(A, b.wuT), E, 64, T, 64, E);
                 p.outb = dpre; p.ldob = 64; p.ldaux = 64;
@@ -591,9 +591,10 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0) {
         CHECK(pevit_launch_colsum_reduce(at<float>(W, c->w_tnD), tch, (int)gl, at<float>(W, c->w_Gd), c->L, c->tn_layer / 4, gl, s));
         CHECK(pevit_launch_colsum_reduce(at<float>(W, c->w_tnU), tch, (int)gl, at<float>(W, c->w_Gu), c->L, c->tn_layer / 4, gl, s));
         // biases and LayerNorm affine: straight column sums into the flat gradient buffer
-        CHECK(pevit_launch_colsum_reduce(at<float>(W, c->w_csx), tch, E, g0 + c->o_ub, c->L, c->csx_layer / 4, ps, s));
+        // d b_up from the f32 column sums of the upstream gradient (third plane of the LN partials)
         CHECK(pevit_launch_colsum_reduce(at<float>(W, c->w_csy), tch, 64, g0 + c->o_db, c->L, c->csy_layer / 4, ps, s));
-        CHECK(pevit_launch_colsum_reduce(at<float>(W, c->w_lnp), lnb, 2 * E, g0 + c->o_nw, c->L, c->lnp_layer / 4, ps, s));
+        CHECK(pevit_launch_colsum_reduce3(at<float>(W, c->w_lnp), lnb, E, g0 + c->o_nw, g0 + c->o_nb, g0 + c->o_ub, c->L,
+                                          c->lnp_layer / 4, ps, s));
         if (c->d.method == PEVIT_ADAPTER) {
             CHECK(pevit_launch_chain_adapter(at<float>(W, c->w_Gd), at<float>(W, c->w_Gu), g0 + c->o_dw, g0 + c->o_uw, E, c->L, gl,
                                              ps, s));

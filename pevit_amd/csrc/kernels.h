@@ -128,6 +128,8 @@ int pevit_launch_ln_bwd_affine(const float* dy, const float* x, const float* mea
                                const float* dres, float* dx, bf16* dx_bf16, float* partial, int rows, int E, hipStream_t s);
 int pevit_launch_colsum_reduce(const float* partial, int chunks, int n, float* out, int layers, size_t partial_layer,
                                size_t out_layer, hipStream_t s);
+int pevit_launch_colsum_reduce3(const float* partial, int chunks, int n, float* o0, float* o1, float* o2, int layers,
+                                size_t partial_layer, size_t out_layer, hipStream_t s);
 int pevit_launch_chain_adapter(const float* Gd, const float* Gu, float* g_down, float* g_up, int E, int layers, size_t g_layer,
                                size_t param_layer, hipStream_t s);
 int pevit_launch_chain_compacter(const float* Gd, const float* Gu, const float* rule, const float* params, float* grads, int E,

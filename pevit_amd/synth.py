@@ -49,6 +49,11 @@ ARCHS = {
                         context_length=8, vocab_size=32),
     "tiny-256": VitArch("tiny-256", 256, 3, 16, 64, 128, text_width=64, text_layers=1,
                         context_length=8, vocab_size=32),
+    # token counts of ViT-B/16 (197) and ViT-L/14 (257, patch 14 -> padded im2col K) at test width
+    "tiny-n197": VitArch("tiny-n197", 128, 2, 16, 224, 64, text_width=64, text_layers=1,
+                         context_length=8, vocab_size=32),
+    "tiny-n257": VitArch("tiny-n257", 128, 2, 14, 224, 64, text_width=64, text_layers=1,
+                         context_length=8, vocab_size=32),
 }
 
 
@@ -159,4 +164,33 @@ def randomize_adapters(named_params, seed: int = 3, scale: float = 1.0):
         else:
             std = 0.02                     # LoRA A/B, bottleneck down/up
         v = torch.randn(p.shape, generator=gen, dtype=torch.float32) * (std * scale)
+        p.data.copy_(v.to(p.dtype).to(p.device))
+
+
+def reference_init_(named_params, method: str, seed: int = 7):
+    """Adapter tensors at the reference's own initialisation, in place:
+    KAdaptation: Kronecker factors 0, phm_rule factors U(-0.01,0.01), b = 0 (model.py:533-554,987-999);
+    LoRA: A ~ N(0,0.02), B = 0 (lora_model.py:466-475); Adapter: N(0,0.02) weights, zero biases, LN (1,0)
+    (adapter_model.py:285-295); Compacter: glorot-uniform(gain sqrt 2) W_left/W_right, zero biases, LN (1,0)."""
+    g = torch.Generator(device="cpu"); g.manual_seed(seed)
+    for name, p in named_params:
+        shape = tuple(p.shape)
+        if name.startswith("layers."):
+            continue
+        if "phm_rule" in name and (name.endswith("_left") or name.endswith("_right")):
+            v = (torch.rand(shape, generator=g) * 2 - 1) * 0.01
+        elif "norm" in name and name.endswith("weight"):
+            v = torch.ones(shape)
+        elif name.endswith(".b") or name.endswith("bias"):
+            v = torch.zeros(shape)
+        elif method == "kadaptation":
+            v = torch.zeros(shape)
+        elif method == "lora":
+            v = torch.randn(shape, generator=g) * 0.02 if "adapter1" in name else torch.zeros(shape)
+        elif method == "adapter":
+            v = torch.randn(shape, generator=g) * 0.02
+        else:   # compacter W_left (n, in, 1) / W_right (n, 1, out): xavier-uniform, gain sqrt(2), per slice
+            fan_in, fan_out = shape[2], shape[1]
+            bound = math.sqrt(2.0) * math.sqrt(6.0 / (fan_in + fan_out))
+            v = (torch.rand(shape, generator=g) * 2 - 1) * bound
         p.data.copy_(v.to(p.dtype).to(p.device))

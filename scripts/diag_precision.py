@@ -54,7 +54,27 @@ def case(name, arch_name, method, p, classes, images, labels, head, lora_r=4):
     del eng
 
 
+def long_cases():
+    for method, arch_name, B in (("kadaptation", "tiny-n197", 8), ("lora", "tiny-n257", 8), ("compacter", "tiny-n197", 9),
+                                 ("adapter", "tiny-n257", 8)):
+        arch = ARCHS[arch_name]
+        sd = {k: v for k, v in synth_state_dict(arch, seed=21, text_tower=False).items() if k.startswith("visual.")}
+        ad = [(n, torch.zeros(s)) for n, s, tr in adapter_param_spec(method, arch.width, arch.layers)]
+        randomize_adapters(ad, seed=6)
+        for n, v in ad:
+            if n.endswith("phm_rule"):
+                v.copy_(torch.rand(v.shape, generator=torch.Generator().manual_seed(8)) * 2 - 1)
+        sd.update(dict(ad))
+        images, labels = synth_batch(B, arch.resolution, 10, seed_img=3, seed_lbl=4)
+        g = torch.Generator().manual_seed(5)
+        D = arch.embed_dim
+        head = ((torch.rand((10, D), generator=g) * 2 - 1) / D ** 0.5, (torch.rand((10,), generator=g) * 2 - 1) / D ** 0.5)
+        case(f"{method} {arch_name} B={B}", arch_name, method, sd, 10, images, labels, head)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "long":
+        return long_cases()
     for c in ("tiny_kadaptation", "tiny_lora_r8", "tiny_lora"):
         meta, t = load_golden(c)
         p = golden_param_dict(meta, t)
