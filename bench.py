@@ -82,6 +82,8 @@ def main():
     ap.add_argument("--method", default="kadaptation")
     ap.add_argument("--arch", default="ViT-B/32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=INT",
+                    help="library tuning knob for A/B runs, e.g. gemm_hoist=0 (see pevit_tune)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -105,6 +107,10 @@ def main():
         sd["visual.transformer.phm_rule"] = torch.rand((4, 4, 4), generator=torch.Generator().manual_seed(4)) * 2 - 1
     eng = HipEngine(arch, args.method, classes, args.batch, lora_rank=8 if args.method == "lora" else 4, device=dev)
     eng.load_state_dict(sd)
+    for kv in args.tune:
+        key, val = kv.split("=")
+        if eng.lib.pevit_tune(key.encode(), int(val)) < 0:
+            raise SystemExit(f"unknown tuning key {key}")
     # adapters at the reference initialisation; head ~ nn.Linear default
     views = eng.param_views()
     reference_init_(views.items(), args.method)

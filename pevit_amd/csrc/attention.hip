@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
                                                        const bf16* __restrict__ v, const bf16* __restrict__ out,
                                                        int ldo, const bf16* __restrict__ dout, int lddo,
                                                        const float* __restrict__ lse, bf16* __restrict__ dqkv, int ld,
-                                                       int H, int N) {
+                                                       int H, int N, int phase) {
     constexpr int NPAD = 32 * KT32, LDT = NPAD + 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* Kt = reinterpret_cast<bf16*>(smem);
@@ -228,6 +228,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
     }
     __syncthreads();
 
+    if (phase < 2) return;
     const int ntile = (N + 15) >> 4;
     // operand sources for the MFMA row fragments
     const bf16* Qr = ROWLDS ? Qs : qh;   const size_t qst = ROWLDS ? LDR : 64;
@@ -269,6 +270,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
         }
         if (xq < N) store16(dqkv + ((size_t)b * N + xq) * ld + h * 64 + 16 * g, o, 1.0f);
     }
+    if (phase < 3) return;
     // ---------------- pass B: x = keys, y = queries -> dK, dV -------------------------
     for (int xt = wid; xt < ntile; xt += 4) {
         const int xk = 16 * xt + c16;
@@ -315,6 +317,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
     }
 }
 
+int g_attn_bwd_phase = 3;   // debug knob: 1 = staging only, 2 = + pass A, 3 = full
+
 template <int KT32>
 int launch_fwd(const bf16* q, const bf16* k, const bf16* v, bf16* out, int ldo, float* lse, int B, int H, int N,
                hipStream_t s) {
@@ -346,11 +350,13 @@ int launch_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* out, int
         attr = true;
     }
     hipLaunchKernelGGL(attn_bwd_kernel<KT32>, dim3(B * H), dim3(256), bytes, s, q, k, v, out, ldo, dout, lddo, lse,
-                       dqkv, ld, H, N);
+                       dqkv, ld, H, N, g_attn_bwd_phase);
     return 0;
 }
 
 }  // namespace
+
+int pevit_attn_set_bwd_phase(int v) { const int o = g_attn_bwd_phase; g_attn_bwd_phase = v; return o; }
 
 int pevit_launch_attn_fwd(const bf16* q, const bf16* k, const bf16* v, bf16* out, int ldo, float* lse, int B, int H,
                           int N, hipStream_t s) {

@@ -28,6 +28,19 @@ namespace {
 
 constexpr int TILE_BAND = 6;
 int g_gemm_config = -1;    // -1: heuristic ; >= 0: force a tile configuration (A/B measurements)
+int g_gemm_persistent = 1;
+int g_gemm_hoist = 1;       // hoist all fragment reads of a k-tile ahead of its MFMAs
+
+int num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
 
 __device__ __forceinline__ float sigmoidf_fast(float x) { return 1.0f / (1.0f + __expf(-x)); }
 // transformers' "gelu_new" (compacter_model.py:8,172): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
@@ -183,18 +196,23 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int row, int
 // of TILE_BAND m-tiles is walked n-major, so the tiles an XCD has in flight share TILE_BAND
 // A-panels and only a few B-panels (a 128x768 bf16 panel is 192 KiB; the XCD's L2 is 4 MiB).
 template <int BM, int BN>
-__device__ __forceinline__ void tile_origin(const GemmParams& p, int& m0, int& n0) {
+__device__ __forceinline__ void tile_origin(const GemmParams& p, int tile, int& m0, int& n0) {
     const int tiles_n = (p.N + BN - 1) / BN;
     const int tiles_m = (p.M + BM - 1) / BM;
-    const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int t = xcd_remap(tile, tiles_m * tiles_n);
     const int band = t / (TILE_BAND * tiles_n), within = t - band * (TILE_BAND * tiles_n);
     const int mb = min(TILE_BAND, tiles_m - band * TILE_BAND);
     const int tn = within / mb, tm = band * TILE_BAND + (within - tn * mb);
     m0 = tm * BM; n0 = tn * BN;
 }
 
-template <int EPI, int BM, int BN, int BK, int MINB>
-__global__ __launch_bounds__(256, MINB) void gemm_bf16_nt_kernel(GemmParams p) {
+// Persistent form: gridDim.x workgroups walk the tiles (tile = blockIdx.x, += gridDim.x; gridDim.x
+// is a multiple of 8 so a workgroup's tiles stay on one XCD range).  The first k-tile of the NEXT
+// output tile is requested (LDS-DMA into stage 0) before the epilogue of the current one runs out of
+// stage 1, so the HBM/L2 latency of the prologue -- one of only 12 k-iterations when K = 768 -- is
+// hidden behind the epilogue's LDS transposes and global stores.
+template <int EPI, int BM, int BN, int BK, int MINB, int SCHED>
+__global__ __launch_bounds__(256, MINB) void gemm_bf16_nt_kernel(GemmParams p, int ntiles) {
     constexpr int WM = BM / 64, WN = BN / 64;           // 32x32 fragments per wave (m, n)
     constexpr int ROWB = BK * 2;                        // bytes per tile row
     constexpr int CH = BK / 8;                          // 16-byte chunks per row
@@ -204,31 +222,32 @@ __global__ __launch_bounds__(256, MINB) void gemm_bf16_nt_kernel(GemmParams p) {
     constexpr int PA = BM / RPP / 4, PB = BN / RPP / 4; // pieces per wave
     constexpr int KS = BK / 16;                         // MFMA k-steps per k-tile
     static_assert(PA >= 1 && PB >= 1, "tile too small for 4 loader waves");
+    static_assert(STAGE_BYTES >= 16384, "the epilogue borrows 16 KiB of stage 1");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wid >> 1, wn = wid & 1;
-    int m0, n0;
-    tile_origin<BM, BN>(p, m0, n0);
 
     // LDS-DMA: a piece is RPP rows x ROWB bytes = 1 KiB, lane-linear; lane l lands at row
     // R + l/CH, physical chunk l%CH, and fetches the logical chunk (l%CH) ^ swz(row) from HBM.
     const bf16* a_src[PA];
     const bf16* b_src[PB];
+    auto set_sources = [&](int m0, int n0) {
 #pragma unroll
-    for (int i = 0; i < PA; ++i) {
-        const int row = (wid * PA + i) * RPP + lane / CH;
-        const int chunk = (lane % CH) ^ ((row >> SWZ_SHIFT) & (CH - 1));
-        int ar = m0 + row; ar = ar < p.M ? ar : p.M - 1;
-        a_src[i] = p.A + (size_t)ar * p.lda + chunk * 8;
-    }
+        for (int i = 0; i < PA; ++i) {
+            const int row = (wid * PA + i) * RPP + lane / CH;
+            const int chunk = (lane % CH) ^ ((row >> SWZ_SHIFT) & (CH - 1));
+            int ar = m0 + row; ar = ar < p.M ? ar : p.M - 1;
+            a_src[i] = p.A + (size_t)ar * p.lda + chunk * 8;
+        }
 #pragma unroll
-    for (int i = 0; i < PB; ++i) {
-        const int row = (wid * PB + i) * RPP + lane / CH;
-        const int chunk = (lane % CH) ^ ((row >> SWZ_SHIFT) & (CH - 1));
-        int br = n0 + row; br = br < p.Nb ? br : p.Nb - 1;
-        b_src[i] = p.B + (size_t)br * p.ldb + chunk * 8;
-    }
+        for (int i = 0; i < PB; ++i) {
+            const int row = (wid * PB + i) * RPP + lane / CH;
+            const int chunk = (lane % CH) ^ ((row >> SWZ_SHIFT) & (CH - 1));
+            int br = n0 + row; br = br < p.Nb ? br : p.Nb - 1;
+            b_src[i] = p.B + (size_t)br * p.ldb + chunk * 8;
+        }
+    };
     auto issue_tile = [&](int kt, int stage) {
         char* sa = smem + stage * STAGE_BYTES + (wid * PA) * 1024;
         char* sb = smem + stage * STAGE_BYTES + A_BYTES + (wid * PB) * 1024;
@@ -246,76 +265,117 @@ __global__ __launch_bounds__(256, MINB) void gemm_bf16_nt_kernel(GemmParams p) {
 #pragma unroll
     for (int i = 0; i < WN; ++i) b_off[i] = A_BYTES + (wn * (BN / 2) + i * 32 + frow) * ROWB;
 
-    f32x16 acc[WM][WN];
-#pragma unroll
-    for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int j = 0; j < WN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
     const int nk = p.K / BK;
+    int tile = blockIdx.x;
+    int m0, n0;
+    tile_origin<BM, BN>(p, tile, m0, n0);
+    set_sources(m0, n0);
     issue_tile(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 1 < nk) issue_tile(kt + 1, (kt + 1) & 1);
-        const char* st = smem + (kt & 1) * STAGE_BYTES;
+    while (true) {
+        f32x16 acc[WM][WN];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int coff = (((ks * 2 + fhalf) ^ fswz) << 4);
-            bf16x8 af[WM], bfr[WN];
+        for (int i = 0; i < WM; ++i)
 #pragma unroll
-            for (int i = 0; i < WM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(st + a_off[i] + coff);
+            for (int j = 0; j < WN; ++j)
 #pragma unroll
-            for (int j = 0; j < WN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(st + b_off[j] + coff);
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int j = 0; j < WN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-        }
-    }
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    // ---- epilogue: one 32x32 fragment at a time through this wave's 4 KiB of LDS ------------
-    __syncthreads();
-    float* cw = reinterpret_cast<float*>(smem + wid * 4096);
+        for (int kt = 0; kt < nk; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (kt + 1 < nk) issue_tile(kt + 1, (kt + 1) & 1);
+            const char* st = smem + (kt & 1) * STAGE_BYTES;
+            if constexpr (SCHED == 0) {
 #pragma unroll
-    for (int i = 0; i < WM; ++i)
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int coff = (((ks * 2 + fhalf) ^ fswz) << 4);
+                    bf16x8 af[WM], bfr[WN];
 #pragma unroll
-        for (int j = 0; j < WN; ++j) {
+                    for (int i = 0; i < WM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(st + a_off[i] + coff);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                cw[row * 32 + (lane & 31)] = acc[i][j][r];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    for (int j = 0; j < WN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(st + b_off[j] + coff);
 #pragma unroll
-            for (int pass = 0; pass < 2; ++pass) {
-                const int lr = pass * 16 + (lane >> 2);
-                const int lc = (lane & 3) * 8;
-                const int row = m0 + wm * (BM / 2) + i * 32 + lr;
-                const int col = n0 + wn * (BN / 2) + j * 32 + lc;
-                const float4 x0 = *reinterpret_cast<const float4*>(cw + lr * 32 + lc);
-                const float4 x1 = *reinterpret_cast<const float4*>(cw + lr * 32 + lc + 4);
-                if (row < p.M && col < p.N) {
-                    float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-                    epilogue_store<EPI>(p, row, col, v);
+                    for (int i = 0; i < WM; ++i)
+#pragma unroll
+                        for (int j = 0; j < WN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
                 }
+            } else {
+                // all fragments of the k-tile are read up front (KS*(WM+WN) ds_read_b128), then the
+                // MFMAs run back to back; SCHED 2 additionally raises the wave priority for them.
+                bf16x8 af[KS][WM], bfr[KS][WN];
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int coff = (((ks * 2 + fhalf) ^ fswz) << 4);
+#pragma unroll
+                    for (int i = 0; i < WM; ++i) af[ks][i] = *reinterpret_cast<const bf16x8*>(st + a_off[i] + coff);
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) bfr[ks][j] = *reinterpret_cast<const bf16x8*>(st + b_off[j] + coff);
+                }
+                if constexpr (SCHED == 2) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int i = 0; i < WM; ++i)
+#pragma unroll
+                        for (int j = 0; j < WN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+                if constexpr (SCHED == 2) __builtin_amdgcn_s_setprio(0);
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
+        // both stages are idle after this barrier: stage 0 receives the next tile's first k-tile while
+        // the epilogue transposes through (this wave's 4 KiB of) stage 1
+        __syncthreads();
+        const int cm0 = m0, cn0 = n0;
+        const int next = tile + gridDim.x;
+        if (next < ntiles) {
+            tile_origin<BM, BN>(p, next, m0, n0);
+            set_sources(m0, n0);
+            issue_tile(0, 0);
+        }
+        float* cw = reinterpret_cast<float*>(smem + STAGE_BYTES + wid * 4096);
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    cw[row * 32 + (lane & 31)] = acc[i][j][r];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int pass = 0; pass < 2; ++pass) {
+                    const int lr = pass * 16 + (lane >> 2);
+                    const int lc = (lane & 3) * 8;
+                    const int row = cm0 + wm * (BM / 2) + i * 32 + lr;
+                    const int col = cn0 + wn * (BN / 2) + j * 32 + lc;
+                    const float4 x0 = *reinterpret_cast<const float4*>(cw + lr * 32 + lc);
+                    const float4 x1 = *reinterpret_cast<const float4*>(cw + lr * 32 + lc + 4);
+                    if (row < p.M && col < p.N) {
+                        float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                        epilogue_store<EPI>(p, row, col, v);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        if (next >= ntiles) break;
+        tile = next;
+    }
 }
 
-struct TileConfig { int bm, bn, bk, minb; };
+struct TileConfig { int bm, bn, bk, minb, sched; };
 constexpr TileConfig kConfigs[] = {
-    {128, 128, 64, 2},   // 0: 64 KiB LDS, 2 workgroups / CU
-    {128, 128, 32, 4},   // 1: 32 KiB LDS, 4 workgroups / CU
-    {128, 64, 64, 3},    // 2: 48 KiB LDS, 3 workgroups / CU
-    {64, 64, 64, 4},     // 3: 32 KiB LDS, 4 workgroups / CU
-    {128, 64, 32, 4},    // 4: 24 KiB LDS
+    {128, 128, 64, 2, 0},   // 0: 64 KiB LDS, 2 workgroups / CU
+    {128, 128, 32, 4, 0},   // 1: 32 KiB LDS, 4 workgroups / CU
+    {128, 64, 64, 3, 0},    // 2: 48 KiB LDS, 3 workgroups / CU
+    {64, 64, 64, 4, 0},     // 3: 32 KiB LDS, 4 workgroups / CU
+    {64, 128, 64, 3, 0},    // 4: 48 KiB LDS, 3 workgroups / CU
+    {128, 128, 64, 2, 1},   // 5: as 0, fragments hoisted
+    {128, 128, 64, 2, 2},   // 6: as 5 + s_setprio around the MFMA block
+    {64, 128, 64, 3, 1},    // 7: as 4, fragments hoisted
 };
 constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
@@ -324,7 +384,7 @@ int launch_cfg(const GemmParams& p, hipStream_t stream) {
     constexpr TileConfig c = kConfigs[CFG];
     constexpr int stage = (c.bm + c.bn) * c.bk * 2;
     constexpr int lds = 2 * stage > 16384 ? 2 * stage : 16384;
-    auto kern = gemm_bf16_nt_kernel<EPI, c.bm, c.bn, c.bk, c.minb>;
+    auto kern = gemm_bf16_nt_kernel<EPI, c.bm, c.bn, c.bk, c.minb, c.sched>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
@@ -335,7 +395,14 @@ int launch_cfg(const GemmParams& p, hipStream_t stream) {
         attr_set = true;
     }
     const int tiles = ceil_div(p.M, c.bm) * ceil_div(p.N, c.bn);
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, stream, p);
+    // persistent grid: one workgroup per residency slot (a multiple of 8 keeps XCD affinity), or one
+    // per tile when the tiles do not even fill the slots
+    int grid = tiles;
+    if (g_gemm_persistent) {
+        const int slots = num_cus() * c.minb;
+        if (tiles > slots) grid = slots;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p, tiles);
     return 0;
 }
 
@@ -345,7 +412,9 @@ int pick_config(const GemmParams& p) {
     if (g_gemm_config >= 0 && g_gemm_config < kNumConfigs) return g_gemm_config;
     if (p.N <= 64) return 3;                      // bottleneck products: 64-wide tiles
     const long t128 = (long)ceil_div(p.M, 128) * ceil_div(p.N, 128);
-    return t128 >= 700 ? 0 : 2;
+    const bool hoist = g_gemm_hoist != 0;
+    if (t128 >= 700 || p.K >= 2048) return hoist ? 5 : 0;
+    return hoist ? 7 : 4;
 }
 
 template <int EPI>
@@ -355,13 +424,18 @@ int launch_epi(const GemmParams& p, hipStream_t stream) {
         case 1: return launch_cfg<EPI, 1>(p, stream);
         case 2: return launch_cfg<EPI, 2>(p, stream);
         case 3: return launch_cfg<EPI, 3>(p, stream);
-        default: return launch_cfg<EPI, 4>(p, stream);
+        case 4: return launch_cfg<EPI, 4>(p, stream);
+        case 5: return launch_cfg<EPI, 5>(p, stream);
+        case 6: return launch_cfg<EPI, 6>(p, stream);
+        default: return launch_cfg<EPI, 7>(p, stream);
     }
 }
 
 }  // namespace
 
 int pevit_gemm_set_variant(int v) { const int old = g_gemm_config; g_gemm_config = v; return old; }
+int pevit_gemm_set_hoist(int v) { const int old = g_gemm_hoist; g_gemm_hoist = v; return old; }
+int pevit_gemm_set_persistent(int v) { const int old = g_gemm_persistent; g_gemm_persistent = v; return old; }
 
 int pevit_launch_gemm(int epi, const GemmParams& p, hipStream_t stream) {
     if (p.K % 64 != 0 || p.K <= 0) { pevit_set_error("gemm: K=%d must be a positive multiple of 64", p.K); return -1; }

@@ -35,6 +35,8 @@ struct GemmParams {
 };
 
 int pevit_launch_gemm(int epi, const GemmParams& p, hipStream_t stream);
+int pevit_gemm_set_persistent(int v);
+int pevit_gemm_set_hoist(int v);
 int pevit_gemm_set_variant(int v);   // -1: heuristic, >= 0: forced tile configuration; returns the previous value
 
 // ---- norm.hip --------------------------------------------------------------------
@@ -55,6 +57,8 @@ int pevit_launch_attn_fwd(const bf16* q, const bf16* k, const bf16* v, bf16* out
 int pevit_launch_attn_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* out, int ldo,
                           const bf16* dout, int lddo, const float* lse, bf16* dqkv, int ld,
                           int B, int H, int N, hipStream_t s);
+
+int pevit_attn_set_bwd_phase(int v);
 
 // ---- lowrank.hip -----------------------------------------------------------------
 struct AdapterPanels {      // per layer, rewritten every step from the f32 master parameters

@@ -81,74 +81,71 @@ __global__ void prep_lora_kernel(const float* __restrict__ a1q, const float* __r
 }
 
 // ---------------------------------------------------------------------------------
-// delta-add: one wave = 128 consecutive e of DA_ROWS reference rows.  Each lane keeps the 2 x 32
-// panel entries of its two columns in registers; the wave stages its DA_ROWS x 32 slice of t in
-// LDS once (coalesced) and then reads it back with broadcast ds_read_b128 (no bank conflicts:
-// all lanes read the same address).  Rows are processed four at a time so that the four
-// read-modify-write loads of q are in flight together.
-constexpr int DA_ROWS = 64;
+// delta-add on the matrix core.  D[e][rr] = sum_j Q[e][j] t[rr][j] is a K=32 product, exactly one
+// v_mfma_f32_16x16x32_bf16; t and Q are f32, so each is split into bf16 hi + lo parts and the product
+// is taken as hi*hi + hi*lo + lo*hi (error ~2^-17, i.e. f32-class, at 3 MFMAs per 16x16 tile).
+// A wave owns 16 reference rows and walks E in steps of 32 columns: two tiles whose output rows are
+// interleaved (tile 0: e = 8g+r, tile 1: e = 8g+4+r) so that each lane ends up with 8 consecutive e
+// of one row -> one 16-byte read-modify-write of the bf16 q (or v) buffer per step.
+__device__ __forceinline__ void split_bf16(const float* src, bf16x8& hi, bf16x8& lo) {
+    const float4 a = *reinterpret_cast<const float4*>(src);
+    const float4 b = *reinterpret_cast<const float4*>(src + 4);
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        hi[i] = f2bf(v[i]);
+        lo[i] = f2bf(v[i] - bf2f(hi[i]));
+    }
+}
+
+constexpr int DA_ESPLIT = 2;     // waves per 16-row group (each takes E/DA_ESPLIT columns)
 __global__ __launch_bounds__(256) void delta_add_kernel(bf16* qbuf, bf16* vbuf, const float* __restrict__ t,
                                                         const float* __restrict__ q32, const float* __restrict__ bias,
                                                         float ascale, int B, int N, int E) {
-    __shared__ __attribute__((aligned(16))) float ts[4][DA_ROWS][32];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int wg = blockIdx.x * 4 + wid;
+    const int lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
+    const int wg = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int which = blockIdx.y;                  // 0: q, 1: v
-    const int slabs = E / 128;
-    const int slab = wg % slabs, rg = wg / slabs;
     const int T = B * N;
-    const int r0 = rg * DA_ROWS;
-    if (r0 >= T) return;                           // whole wave exits together
-    const int nrows = min(DA_ROWS, T - r0);
-    // stage t: lane l loads 16 floats of row (l>>1) + 32*pass, half l&1
-    {
-        const int hf = lane & 1;
+    const int grp = wg / DA_ESPLIT, part = wg - grp * DA_ESPLIT;
+    const int rr0 = grp * 16;
+    if (rr0 >= T) return;                          // whole wave exits together
+    int rr = rr0 + c16; const bool rok = rr < T; rr = rok ? rr : T - 1;
+    bf16x8 th, tl;
+    split_bf16(t + (size_t)row_of_ref(rr, B, N) * 64 + which * 32 + 8 * g, th, tl);
+    bf16* buf = (which ? vbuf : qbuf) + (size_t)rr * E;
+    const int ecols = E / DA_ESPLIT;
+    const int m = c16;
+#pragma unroll 2
+    for (int eb = part * ecols; eb < (part + 1) * ecols; eb += 32) {
+        const int e_t0 = eb + 8 * (m >> 2) + (m & 3);
+        bf16x8 q0h, q0l, q1h, q1l;
+        split_bf16(q32 + (size_t)e_t0 * 64 + which * 32 + 8 * g, q0h, q0l);
+        split_bf16(q32 + (size_t)(e_t0 + 4) * 64 + which * 32 + 8 * g, q1h, q1l);
+        const bf16x8 cur = load_bf16x8(buf + eb + 8 * g);
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+        a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0l, th, a0, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0h, tl, a0, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0h, th, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1l, th, a1, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1h, tl, a1, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1h, th, a1, 0, 0, 0);
+        // lane: column rr, rows 4g+r of each tile -> e = eb + 8g + r (tile 0), eb + 8g + 4 + r (tile 1)
+        float bb[8];
+        if (bias) {
+            const float4 b0 = *reinterpret_cast<const float4*>(bias + eb + 8 * g);
+            const float4 b1 = *reinterpret_cast<const float4*>(bias + eb + 8 * g + 4);
+            bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
+        } else {
 #pragma unroll
-        for (int ps = 0; ps < DA_ROWS / 32; ++ps) {
-            const int rl = (lane >> 1) + 32 * ps;
-            const int rr = r0 + (rl < nrows ? rl : nrows - 1);
-            const float* src = t + (size_t)row_of_ref(rr, B, N) * 64 + which * 32 + hf * 16;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                *reinterpret_cast<float4*>(&ts[wid][rl][hf * 16 + 4 * i]) = *reinterpret_cast<const float4*>(src + 4 * i);
+            for (int i = 0; i < 8; ++i) bb[i] = 0.f;
         }
-    }
-    const int e = slab * 128 + lane * 2;
-    float q0[32], q1[32];
+        bf16x8 o;
 #pragma unroll
-    for (int j = 0; j < 32; j += 4) {
-        const float4 a = *reinterpret_cast<const float4*>(q32 + (size_t)e * 64 + which * 32 + j);
-        const float4 b = *reinterpret_cast<const float4*>(q32 + (size_t)(e + 1) * 64 + which * 32 + j);
-        q0[j] = a.x; q0[j + 1] = a.y; q0[j + 2] = a.z; q0[j + 3] = a.w;
-        q1[j] = b.x; q1[j + 1] = b.y; q1[j + 2] = b.z; q1[j + 3] = b.w;
-    }
-    const float b0 = bias ? bias[e] : 0.f, b1 = bias ? bias[e + 1] : 0.f;
-    bf16* buf = (which ? vbuf : qbuf) + (size_t)r0 * E + e;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (int r = 0; r < nrows; r += 4) {
-        bf16x2 cur[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (r + u < nrows) cur[u] = *reinterpret_cast<const bf16x2*>(buf + (size_t)(r + u) * E);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (r + u >= nrows) break;
-            float d0 = 0.f, d1 = 0.f;
-#pragma unroll
-            for (int j = 0; j < 32; j += 4) {
-                const float4 tv = *reinterpret_cast<const float4*>(&ts[wid][r + u][j]);
-                d0 = fmaf(tv.x, q0[j], d0);     d1 = fmaf(tv.x, q1[j], d1);
-                d0 = fmaf(tv.y, q0[j + 1], d0); d1 = fmaf(tv.y, q1[j + 1], d1);
-                d0 = fmaf(tv.z, q0[j + 2], d0); d1 = fmaf(tv.z, q1[j + 2], d1);
-                d0 = fmaf(tv.w, q0[j + 3], d0); d1 = fmaf(tv.w, q1[j + 3], d1);
-            }
-            bf16x2 o;
-            o[0] = f2bf(bf2f(cur[u][0]) + ascale * d0 + b0);
-            o[1] = f2bf(bf2f(cur[u][1]) + ascale * d1 + b1);
-            *reinterpret_cast<bf16x2*>(buf + (size_t)(r + u) * E) = o;
+        for (int r = 0; r < 4; ++r) {
+            o[r] = f2bf(bf2f(cur[r]) + ascale * a0[r] + bb[r]);
+            o[4 + r] = f2bf(bf2f(cur[4 + r]) + ascale * a1[r] + bb[4 + r]);
         }
+        if (rok) store_bf16x8(buf + eb + 8 * g, o);
     }
 }
 
@@ -461,11 +458,11 @@ int pevit_launch_prep_lora(const float* a1q, const float* a2q, const float* a1v,
 
 int pevit_launch_delta_add(bf16* qbuf, bf16* vbuf, const float* t, const float* q32, const float* bias, float ascale,
                            int B, int N, int E, hipStream_t s) {
-    if (E % 128) { pevit_set_error("delta_add: width %d must be a multiple of 128", E); return -1; }
+    if (E % (32 * DA_ESPLIT)) { pevit_set_error("delta_add: width %d must be a multiple of %d", E, 32 * DA_ESPLIT); return -1; }
     const int T = B * N;
-    const int waves = (E / 128) * ceil_div(T, DA_ROWS);
-    hipLaunchKernelGGL(delta_add_kernel, dim3(ceil_div(waves, 4), 2), dim3(256), 0, s, qbuf, vbuf, t, q32, bias,
-                       ascale, B, N, E);
+    const int waves = ceil_div(T, 16) * DA_ESPLIT;
+    hipLaunchKernelGGL(delta_add_kernel, dim3(ceil_div(waves, 4), 2), dim3(256), 0, s, qbuf, vbuf, t, q32, bias, ascale,
+                       B, N, E);
     return 0;
 }
 

@@ -44,11 +44,14 @@ def run(name, epi, M, N, K, iters=30):
 
 
 def main():
-    names = {-1: "heuristic", 0: "128x128x64", 1: "128x128x32", 2: "128x64x64", 3: "64x64x64", 4: "128x64x32"}
-    for cfg in (0, 1, 2, 3, 4, -1):
-        lib.pevit_tune(b"gemm_config", cfg)
-        print(f"---- gemm_config {cfg} ({names[cfg]})")
-        shapes(big=(cfg in (0, 1)))
+    names = {-1: "heuristic", 0: "128x128x64", 1: "128x128x32", 2: "128x64x64", 3: "64x64x64", 4: "64x128x64"}
+    names.update({5: "128x128x64 hoisted frags", 6: "128x128x64 hoisted + setprio"})
+    for persistent in (1,):
+        lib.pevit_tune(b"gemm_persistent", persistent)
+        for cfg in (0, 5, 6, -1):
+            lib.pevit_tune(b"gemm_config", cfg)
+            print(f"---- persistent {persistent} gemm_config {cfg} ({names[cfg]})")
+            shapes(big=(cfg in (0, 5, 6)))
 
 
 def shapes(big=False):
