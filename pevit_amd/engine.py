@@ -123,6 +123,19 @@ class HipEngine:
         except Exception:
             pass
 
+    def ensure_batch(self, batch: int):
+        """Grow the activation workspace so that steps of ``batch`` images fit (re-binds; weights stay)."""
+        if batch <= self.max_batch:
+            return
+        torch.cuda.synchronize(self.device)
+        self.workspace = None
+        self.workspace = torch.empty(self.lib.pevit_workspace_bytes(self._ctx, batch), dtype=torch.uint8,
+                                     device=self.device)
+        _lib.check(self.lib.pevit_bind(self._ctx, _lib.ptr(self.arena), self.arena.numel(), _lib.ptr(self.workspace),
+                                       self.workspace.numel(), batch), "pevit_bind")
+        self._logits = torch.empty((batch, self.num_classes), dtype=torch.float32, device=self.device)
+        self.max_batch = batch
+
     # ------------------------------------------------------------------ parameters
     def param_views(self, buf: torch.Tensor | None = None) -> "OrderedDict[str, torch.Tensor]":
         """Views of the flat buffer under the reference's parameter names (+ head)."""
@@ -166,7 +179,10 @@ class HipEngine:
             _lib.check(self.lib.pevit_load_phm_rule(self._ctx, s, _lib.ptr(r)), "pevit_load_phm_rule")
         torch.cuda.current_stream().synchronize()     # the temporaries above may now be freed
         del keep
-        # adapter tensors present in the checkpoint overlay their initial values (model.py:1247-1250)
+        self.load_trainable(sd)
+
+    def load_trainable(self, sd):
+        """Adapter / head tensors present in ``sd`` overlay the current values (model.py:1247-1250)."""
         views = self.param_views()
         with torch.no_grad():
             for name, v in views.items():
@@ -244,6 +260,13 @@ class HipEngine:
     def reset_optimizer(self):
         self._steps = 0
         self.momentum.zero_()
+
+    def reset_run(self):
+        """State a fresh ``Classifier`` would have, with the frozen backbone left resident (the
+        reference rebuilds everything for each of its ~90 sweep runs)."""
+        self.reset_optimizer()
+        self.params.zero_(); self.grads.zero_()
+        self.running_mean.zero_(); self.running_var.fill_(1.0)
 
     def train_step(self, images, labels, lr, momentum=0.9, weight_decay=0.0, bn_training=True, process_group=None,
                    world_size=1):

@@ -1,0 +1,6 @@
+"""Host-side mirror of ``vision_benchmark.evaluation`` for the PEFT fine-tune path.
+
+Same importable names and call signatures as the reference's Python modules; the vision tower,
+head, loss and optimiser execute in ``libpevit_hip.so``.  Dataset download/manifest code, the BPE
+vocabulary and the knowledge-augmented prompt sources of the reference are not part of this path.
+"""

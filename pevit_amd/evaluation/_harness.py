@@ -1,0 +1,432 @@
+"""Shared implementation of the four fine-tune harness modules (kadaptation_clip / lora_clip /
+adapter_tuning_clip / compacter_clip), which in the reference are four near-identical copies
+(e.g. evaluation/kadaptation_clip.py:78-521).  Behaviour kept from the reference:
+
+* trainability by substring of the parameter name (kadaptation_clip.py:104-122, lora_clip.py:120,
+  adapter_tuning_clip.py:116, compacter_clip.py:122);
+* ``Classifier.forward`` = backbone -> BatchNorm1d(affine=False) -> [normalize] -> Linear (:176-185);
+* ``train_one`` / ``validate`` / ``adjust_learning_rate`` / the two-level sweep (:188-243, :446-466) --
+  including that ``validate`` leaves the module in eval mode, so from the second epoch on the reference
+  trains with the BatchNorm *running* statistics (:385, no ``model.train()`` anywhere);
+* ``train_task`` return contract: best score for sweep runs, ``(best, model_info)`` otherwise (:257-317).
+
+What differs is where the work runs: one ``train_one`` iteration is a single fused call into the HIP engine
+(forward, loss, backward, SGD) whenever the configuration is the plain one of the reference's yaml files, and
+an autograd step over the engine's forward/backward otherwise.  Per-step ``loss.item()`` is replaced by one
+read-back per epoch.  Consecutive ``train_task`` calls (the ~90 runs of a sweep) re-use the resident frozen
+backbone.
+"""
+from __future__ import annotations
+
+import gc
+import logging
+import time
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ..optim import build_optimizer
+from . import clip_load
+from .feature import create_dataloader, extract_text_features
+from .metric import get_metric
+
+MULTILABEL_DATASETS = {"voc-2007-classification", "chestx-ray8"}
+
+_LOADERS = {"kadaptation": "load", "lora": "lora_load", "adapter": "adapter_load", "compacter": "compacter_load"}
+
+
+def trainable_by_name(method: str, name: str) -> bool:
+    if method == "kadaptation":
+        return "adapter" in name or "phm_rule" in name or "attn.b" in name
+    if method == "compacter":
+        return "compacter" in name
+    return "adapter" in name
+
+
+def gpu_gc():
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+class AverageMeter(object):
+    """Computes and stores the average and current value"""
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.val = self.avg = self.sum = self.count = 0
+
+    def update(self, val, n=1):
+        self.val = val
+        self.sum += val * n
+        self.count += n
+        self.avg = self.sum / self.count
+
+
+def get_cls_model(method, config, feature_type="image"):
+    model, _ = getattr(clip_load, _LOADERS[method])(config.MODEL.NAME, jit=False)
+    if feature_type == "image":
+        model.forward = model.encode_image
+    elif feature_type == "text":
+        model.forward = model.encode_text
+    else:
+        raise Exception("Incorrect model type.")
+    return model
+
+
+class ClassifierBase(nn.Module):
+    """Linear classifier on the adapted CLIP tower."""
+    METHOD = "kadaptation"
+    tokenizer = None        # set to a callable(texts, context_length=...) to use INIT_HEAD_WITH_TEXT_ENCODER
+
+    def __init__(self, config, l2_lambda):
+        super().__init__()
+        self.backbone = get_cls_model(self.METHOD, config, feature_type="image")
+        for name, param in self.backbone.named_parameters():
+            param.requires_grad = trainable_by_name(self.METHOD, name)
+        input_dim, output_dim = config.MODEL.SPEC.EMBED_DIM, config.DATASET.NUM_CLASSES
+        self.optim = None
+        self.l2_lambda = l2_lambda
+        self.channel_bn = nn.BatchNorm1d(input_dim, affine=False)
+        self.layers = nn.Sequential(nn.Linear(input_dim, output_dim))
+        dev = self.backbone.logit_scale.device
+        self.channel_bn.to(dev); self.layers.to(dev)
+
+        if config.TRAIN.INIT_HEAD_WITH_TEXT_ENCODER:
+            zeroshot_weights = extract_text_features(config, self.tokenizer, model=self.backbone, return_numpy=False)
+            w = self.layers[0].weight
+            w.data = zeroshot_weights.T.to(w.dtype).to(w.device).contiguous()
+            self.layers[0].bias.data.fill_(0.0)
+
+        if config.TRAIN.MERGE_ENCODER_AND_HEAD_PROJ:
+            raise RuntimeError("TRAIN.MERGE_ENCODER_AND_HEAD_PROJ folds visual.proj into the head; the HIP tower "
+                               "always applies visual.proj -- leave this option off")
+
+        self.logit_scale = nn.Parameter(torch.ones([], device=dev))
+        self.logit_scale.requires_grad = config.TRAIN.TRAINABLE_LOGIT_SCALE
+        if config.TRAIN.LOGIT_SCALE_INIT == "pretrained":
+            self.logit_scale.data = self.backbone.logit_scale.data.to(self.logit_scale.dtype).to(self.logit_scale.device)
+        elif config.TRAIN.LOGIT_SCALE_INIT == "ln_cls":
+            self.logit_scale.data *= np.log(np.log(config.DATASET.NUM_CLASSES))
+        elif config.TRAIN.LOGIT_SCALE_INIT == "clip":
+            self.logit_scale.data *= np.log(1 / 0.07)
+        else:
+            self.logit_scale.data *= 0
+
+        self.normalize_visual_output = config.TRAIN.NORMALIZE_VISUAL_FEATURE
+        if not config.TRAIN.USE_CHANNEL_BN:
+            self.channel_bn = nn.Identity()
+
+        visual = self.backbone.visual
+        visual._num_classes = output_dim
+        visual._max_batch = max(int(config.TRAIN.BATCH_SIZE_PER_GPU), int(config.TEST.BATCH_SIZE_PER_GPU))
+        if visual._engine is not None and visual._engine.num_classes != output_dim:
+            visual._engine = None
+        self._bound = None
+
+    # ---- engine binding ------------------------------------------------------------------
+    def engine(self):
+        """HIP context of the tower with this module's head / BatchNorm buffers seated in it."""
+        eng = self.backbone.visual.engine()
+        if self._bound is not eng:
+            views = eng.param_views()
+            lin = self.layers[0]
+            with torch.no_grad():
+                views["layers.0.weight"].copy_(lin.weight)
+                views["layers.0.bias"].copy_(lin.bias)
+            lin.weight.data, lin.bias.data = views["layers.0.weight"], views["layers.0.bias"]
+            if isinstance(self.channel_bn, nn.BatchNorm1d):
+                eng.running_mean.copy_(self.channel_bn.running_mean)
+                eng.running_var.copy_(self.channel_bn.running_var)
+                self.channel_bn.running_mean = eng.running_mean
+                self.channel_bn.running_var = eng.running_var
+            self._bound = eng
+        return eng
+
+    def forward(self, img):
+        pdtype = img.dtype
+        if img.is_cuda:
+            self.engine()
+        feature = self.backbone(img).to(pdtype)
+        outputs = self.channel_bn(feature)
+        if self.normalize_visual_output:
+            outputs = F.normalize(outputs)
+        return self.layers(outputs)
+
+    # ---- fused step ----------------------------------------------------------------------
+    def can_fuse(self, criterion, optimizer) -> bool:
+        """True when one ``pevit_train_forward_backward`` + ``pevit_sgd_step`` is exactly the reference step."""
+        if not isinstance(criterion, nn.CrossEntropyLoss) or criterion.weight is not None:
+            return False
+        if criterion.reduction != "mean" or getattr(criterion, "label_smoothing", 0.0) != 0.0 or criterion.ignore_index >= 0:
+            return False
+        if type(optimizer) is not torch.optim.SGD or not isinstance(self.channel_bn, nn.BatchNorm1d):
+            return False
+        if self.normalize_visual_output or self.logit_scale.requires_grad:
+            return False
+        if self.channel_bn.momentum != 0.1 or self.channel_bn.eps != 1e-5:
+            return False
+        live = [g for g in optimizer.param_groups if len(g["params"]) > 0]
+        if not live:
+            return False
+        g0 = live[0]
+        for g in live:
+            if g["nesterov"] or g["dampening"] != 0 or g.get("maximize", False):
+                return False
+            if (g["lr"], g["momentum"], g["weight_decay"]) != (g0["lr"], g0["momentum"], g0["weight_decay"]):
+                return False
+        mine = {id(p) for p in self.parameters() if p.requires_grad}
+        theirs = {id(p) for g in live for p in g["params"]}
+        return mine == theirs
+
+    def fused_train_step(self, images, target, optimizer):
+        eng = self.engine()
+        eng.ensure_batch(images.shape[0])
+        g = next(g for g in optimizer.param_groups if len(g["params"]) > 0)
+        logits, loss = eng.train_step(images.contiguous().float(), target.contiguous(), lr=g["lr"], momentum=g["momentum"],
+                                      weight_decay=g["weight_decay"], bn_training=self.channel_bn.training)
+        if self.channel_bn.training:
+            self.channel_bn.num_batches_tracked += 1
+        return logits.clone(), loss.clone()
+
+
+def adjust_learning_rate(optimizer, epoch, config):
+    """Decay the learning rate based on schedule"""
+    lr = config.TRAIN.LR
+    for milestone in config.TRAIN.SCHEDULE:
+        lr *= 0.1 if epoch >= milestone else 1.0
+    for param_group in optimizer.param_groups:
+        param_group["lr"] = lr
+
+
+def accuracy(output, target, topk=(1,)):
+    """Computes the accuracy over the k top predictions for the specified values of k"""
+    with torch.no_grad():
+        maxk = max(topk)
+        _, pred = output.topk(maxk, 1, True, True)
+        correct = pred.t().eq(target.view(1, -1))
+        return [correct[:k].reshape(-1).float().sum(0, keepdim=True).mul_(100.0 / target.size(0)) for k in topk]
+
+
+def _score(metric, outputs, targets):
+    logits = torch.cat(outputs, dim=0).softmax(-1).data.cpu().numpy()
+    labels = torch.cat(targets, dim=0).data.cpu().numpy()
+    try:                                    # the reference guards NaNs of mAP-like metrics the same way
+        return 100.0 * metric(labels, logits), logits
+    except Exception:
+        return 0.0, logits
+
+
+def train_one(train_loader, model, criterion, optimizer, epoch, config):
+    batch_time, data_time, losses = AverageMeter(), AverageMeter(), AverageMeter()
+    metric = get_metric(config.TEST.METRIC)
+    outputs, targets, step_losses, step_sizes = [], [], [], []
+    fused = model.can_fuse(criterion, optimizer)
+    dev = config.GPUS[0]
+    end = time.time()
+    for _, batch in enumerate(train_loader):
+        images, target = batch[:2]
+        data_time.update(time.time() - end)
+        if len(config.GPUS) == 1:
+            images = images.cuda(dev, non_blocking=True)
+        if images.shape[0] == 1:
+            continue                                      # BatchNorm cannot take a single-sample batch (reference :341)
+        if target.shape[-1] == 1:
+            target = target[:, 0]
+        target = target.cuda(dev, non_blocking=True)
+
+        if fused and target.dim() == 1 and target.dtype == torch.int64:
+            output, loss = model.fused_train_step(images, target, optimizer)
+        else:
+            optimizer.zero_grad()
+            output = model.forward(images)
+            loss = criterion(output, target)
+            loss.backward()
+            optimizer.step()
+        step_losses.append(loss.detach().reshape(1)); step_sizes.append(images.size(0))
+        outputs.append(output.detach() if fused else output)
+        targets.append(target)
+        batch_time.update(time.time() - end)
+        end = time.time()
+
+    if not outputs:
+        return
+    for v, n in zip(torch.cat(step_losses).cpu().tolist(), step_sizes):       # one sync per epoch, not per step
+        losses.update(v, n)
+    metric_result, _ = _score(metric, outputs, targets)
+    logging.info(f"[Epoch {epoch}] Train: {metric.__name__} {metric_result:.3f}")
+    return losses.avg
+
+
+@torch.no_grad()
+def validate(val_loader, model, criterion, epoch, config, return_logits=False):
+    metric = get_metric(config.TEST.METRIC)
+    outputs, targets = [], []
+    model.eval()
+    dev = config.GPUS[0]
+    for batch in val_loader:
+        images, target = batch[:2]
+        if len(config.GPUS) == 1:
+            images = images.cuda(dev, non_blocking=True)
+        target = target.cuda(dev, non_blocking=True)
+        if target.shape[-1] == 1:
+            target = target[:, 0]
+        outputs.append(model(images))
+        targets.append(target)
+    metric_result, logits = _score(metric, outputs, targets)
+    logging.info(f"[Epoch {epoch}] Val: {metric.__name__} {metric_result:.3f}")
+    return (metric_result, logits) if return_logits else metric_result
+
+
+def train_task(classifier_cls, train_dataloader, test_dataloader, config, sweep_run=False):
+    best_acc1 = 0
+    model = classifier_cls(config, 0)
+    n_train = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    logging.info(f"Number of trainable params: {n_train / 1000000}M.")
+
+    gpu = config.GPUS
+    if len(gpu) == 1:
+        torch.cuda.set_device(gpu[0])
+        model = model.cuda(gpu[0])
+
+    if config.DATASET.DATASET in MULTILABEL_DATASETS:
+        criterion = nn.BCEWithLogitsLoss().cuda(gpu[0])
+    else:
+        criterion = nn.CrossEntropyLoss().cuda(gpu[0])
+    optimizer = build_optimizer(config, model)
+
+    model_info = {}
+    visual = model.backbone.visual if getattr(model.backbone, "visual", None) is not None else model.backbone
+    model_info["n_trainable_params"] = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    model_info["n_visual_params"] = sum(p.numel() for p in visual.parameters())
+    model_info["n_backbone_params"] = sum(p.numel() for p in model.backbone.parameters())
+    model_info["n_params"] = sum(p.numel() for p in model.parameters())
+
+    acc1 = 0.0
+    for epoch in range(config.TRAIN.BEGIN_EPOCH, config.TRAIN.END_EPOCH):
+        adjust_learning_rate(optimizer, epoch, config)
+        if not config.TRAIN.EMULATE_ZERO_SHOT:
+            train_one(train_dataloader, model, criterion, optimizer, epoch, config)
+        acc1, logits = validate(test_dataloader, model, criterion, epoch, config, return_logits=True)
+        if acc1 > best_acc1:
+            model_info["best_logits"] = logits
+        best_acc1 = max(acc1, best_acc1)
+
+    logging.info(f"=> Learning rate {config.TRAIN.LR}, L2 lambda {config.TRAIN.WD}: Best score: Acc@1 {best_acc1:.3f}")
+    if sweep_run and config.TRAIN.SEARCH_RESULT_ON_LAST_EPOCH:
+        return acc1
+
+    del model, criterion, optimizer
+    gpu_gc()
+    return best_acc1 if sweep_run else (best_acc1, model_info)
+
+
+def hyperparameter_sweep(train_task_fn, train_dataloader, val_dataloader, config):
+    """Weight-decay search at a fixed LR: 7 coarse points of a 97-point log grid, then bisection with spans
+    8,4,2,1 around the running peak (reference :188-243).  Failed runs score 0, as in the reference."""
+    logging.info(f"=> Learning rate {config.TRAIN.LR}: tuning l2 regularization strength.")
+    start = time.time()
+    lo, hi = config.TRAIN.SEARCH_WD_LOG_LOWER, config.TRAIN.SEARCH_WD_LOG_UPPER
+    grid = np.logspace(lo, hi, num=97).tolist()
+    coarse = set(np.logspace(lo, hi, num=7))
+    init_idx = [i for i, v in enumerate(grid) if v in coarse]
+    peak_idx, peak_score, score = -1, 0, 0.0
+
+    def run(wd):
+        config.defrost()
+        config.TRAIN.WD = wd
+        try:
+            return train_task_fn(train_dataloader, val_dataloader, config, sweep_run=True)
+        except Exception:
+            gpu_gc()
+            return None
+
+    for idx in init_idx:
+        score = run(grid[idx])
+        if score is None:
+            score = 0.0
+            continue
+        if score > peak_score:
+            peak_idx, peak_score = idx, score
+    logging.info(f"Iteration 0: l2_lambda: {grid[peak_idx]}, best score {score}")
+
+    step_span, it = 8, 0
+    while step_span > 0:
+        left, right = max(peak_idx - step_span, 0), min(peak_idx + step_span, len(grid) - 1)
+        for idx in [i for i in (left, right) if i != peak_idx]:
+            # WD_SEARCH_LEFT reproduces the reference's initial release, which always probed the left neighbour
+            score = run(grid[left] if config.TRAIN.WD_SEARCH_LEFT else grid[idx])
+            if score is None:
+                score = 0.0
+                continue
+            if score > peak_score:
+                peak_idx, peak_score = idx, score
+        it += 1
+        logging.info(f"Iteration {it}: l2_lambda: {grid[peak_idx]}, best score {score}")
+        step_span //= 2
+
+    logging.info(f"=> Learning rate {config.TRAIN.LR}: The best l2 lambda is {grid[peak_idx]}")
+    logging.info("=> Learning rate {}: l2 regularization strength tuning duration time: {:.2f}s".format(
+        config.TRAIN.LR, time.time() - start))
+    return grid[peak_idx], peak_score
+
+
+def hyperparameter_sweep_lr(sweep_fn, train_dataloader, val_dataloader, config):
+    logging.info("=> Start hyperparameter tuning.")
+    start = time.time()
+    best_score, best_lr, best_l2 = 0, 0, 0
+    for lr_one in np.logspace(-6, -1, num=6).tolist():
+        config.defrost()
+        config.TRAIN.LR = lr_one
+        config.freeze()
+        l2, score = sweep_fn(train_dataloader, val_dataloader, config)
+        logging.info(f"=> Learning rate: {lr_one}, best_score {score}")
+        if best_score < score:
+            best_score, best_lr, best_l2 = score, lr_one, l2
+    logging.info(f"Hyper parameter tuning result: learning rate {best_lr}, l2_lambda {best_l2}")
+    logging.info("=> Hyperparameter tuning duration time: {:.2f}s".format(time.time() - start))
+    return best_lr, best_l2
+
+
+def clone_loader(loader, shuffle=True):
+    return create_dataloader(loader.dataset, batch_size=loader.batch_size, shuffle=shuffle,
+                             num_workers=loader.num_workers, pin_memory=loader.pin_memory)
+
+
+def merge_trainval_loader(train_loader, val_loader):
+    trainset, valset = train_loader.dataset, val_loader.dataset
+    fullset = trainset.dataset
+    assert trainset.dataset is valset.dataset
+    assert len(fullset) == len(trainset) + len(valset)
+    return torch.utils.data.DataLoader(fullset, batch_size=train_loader.batch_size, shuffle=True,
+                                       num_workers=train_loader.num_workers, pin_memory=train_loader.pin_memory,
+                                       sampler=None, drop_last=False)
+
+
+def final_run(train_task_fn, sweep_lr_fn, train_dataloader, val_dataloader, test_dataloader, no_hyperparameter_tuning,
+              lr, l2, config):
+    """Entry point of a fine-tune job (reference kadapt_clip, :488-521): optional LR x WD search on (train, val),
+    then the final run on train(+val) evaluated on test with END_EPOCH += EXTRA_FINAL_TRAIN_EPOCH."""
+    if no_hyperparameter_tuning:
+        best_lr, best_l2 = lr, l2
+    else:
+        best_lr, best_l2 = sweep_lr_fn(train_dataloader, val_dataloader, config)
+    logging.info("=> The final classifier is on training ...")
+    logging.info(f"Hyperparameters: learning_rate = {best_lr}, l2_lambda = {best_l2}")
+    config.defrost()
+    config.TRAIN.LR = best_lr
+    config.TRAIN.WD = best_l2
+    config.TRAIN.END_EPOCH += config.TRAIN.EXTRA_FINAL_TRAIN_EPOCH
+    config.freeze()
+    if config.DATASET.DATASET == "patch-camelyon" and config.DATASET.NUM_SAMPLES_PER_CLASS == 10000:
+        raise RuntimeError("the patch-camelyon full-set regeneration (:505-513) needs the reference's dataset layer")
+    if config.DATASET.MERGE_TRAIN_VAL_FINAL_RUN:
+        trainval = merge_trainval_loader(train_dataloader, val_dataloader)
+        logging.info(f"Using the full trainval set to train final model. len(dataset)={len(trainval.dataset)}")
+    else:
+        trainval = train_dataloader
+        logging.info(f"Using the train set only to train final model. len(dataset)={len(trainval.dataset)}")
+    return train_task_fn(trainval, test_dataloader, config)

@@ -1,0 +1,364 @@
+"""Host mirror of the reference's model entry points, backed by the HIP engine.
+
+Keeps the importable names and the module/parameter naming of
+``vision_benchmark/evaluation/model.py`` (and its lora / adapter / compacter siblings) of
+eric-ai-lab/PEViT -- ``build_model(state_dict) -> CLIP`` (eval mode, fp32 parameters,
+adapter keys keep their initial values unless the checkpoint has them: model.py:1210-1250),
+``CLIP.encode_image``, ``.visual.input_resolution``, ``.visual.proj``, ``.logit_scale``,
+``named_parameters()`` names (trainability is decided by substring match on
+these names in the harness) -- while the vision tower itself executes in
+``libpevit_hip.so``.  Nothing here computes the tower in PyTorch: on a machine without the
+HIP library / a GPU, ``encode_image`` raises.
+
+The text tower (``encode_text``, used once to initialise the zero-shot head) is plain host
+PyTorch, as SURVEY 8f-4 prescribes; it is not on the accelerated path.
+"""
+from __future__ import annotations
+
+import math
+import weakref
+from collections import OrderedDict
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import _lib
+from ..engine import HipEngine, adapter_param_spec
+from ..synth import VitArch
+
+
+# --------------------------------------------------------------------------- host-side pieces
+class LayerNorm(nn.LayerNorm):
+    """fp32 statistics regardless of input dtype (reference model.py:154-160)."""
+
+    def forward(self, x):
+        return super().forward(x.float()).type(x.dtype)
+
+
+class QuickGELU(nn.Module):
+    def forward(self, x):
+        return x * torch.sigmoid(1.702 * x)
+
+
+class _TextBlock(nn.Module):
+    def __init__(self, width, heads, mask):
+        super().__init__()
+        self.attn = nn.MultiheadAttention(width, heads)
+        self.ln_1 = LayerNorm(width)
+        self.mlp = nn.Sequential(OrderedDict([("c_fc", nn.Linear(width, 4 * width)), ("gelu", QuickGELU()),
+                                              ("c_proj", nn.Linear(4 * width, width))]))
+        self.ln_2 = LayerNorm(width)
+        self.attn_mask = mask
+
+    def forward(self, x):
+        m = self.attn_mask.to(dtype=x.dtype, device=x.device) if self.attn_mask is not None else None
+        y = self.ln_1(x)
+        x = x + self.attn(y, y, y, need_weights=False, attn_mask=m)[0]
+        return x + self.mlp(self.ln_2(x))
+
+
+class _TextTransformer(nn.Module):
+    def __init__(self, width, layers, heads, mask):
+        super().__init__()
+        self.width, self.layers = width, layers
+        self.resblocks = nn.Sequential(*[_TextBlock(width, heads, mask) for _ in range(layers)])
+
+    def forward(self, x):
+        return self.resblocks(x)
+
+
+class _Params(nn.Module):
+    """Named container: holds parameters / sub-containers under the reference's attribute names."""
+
+    def add(self, name, tensor, trainable=False):
+        head, _, rest = name.partition(".")
+        if rest:
+            if head not in self._modules:
+                self.add_module(head, _Params())
+            self._modules[head].add(rest, tensor, trainable)
+        else:
+            self.register_parameter(head, nn.Parameter(tensor, requires_grad=trainable))
+
+
+# parameter registration order of one residual block, per method, exactly as the reference's
+# named_parameters() lists it (checked against tests/golden/*.json: "all_names")
+_FROZEN_BLOCK = ["attn.in_proj_weight", "attn.in_proj_bias", "attn.out_proj.weight", "attn.out_proj.bias",
+                 "ln_1.weight", "ln_1.bias", "mlp.c_fc.weight", "mlp.c_fc.bias", "mlp.c_proj.weight",
+                 "mlp.c_proj.bias", "ln_2.weight", "ln_2.bias"]
+
+
+def _block_order(method, adapter_names):
+    attn_direct = [n for n in adapter_names if n.startswith("attn.") and n.count(".") == 1]   # KAdaptation factors, b
+    attn_child = [n for n in adapter_names if n.startswith("attn.") and n.count(".") > 1]     # LoRA Linear modules
+    other = [n for n in adapter_names if not n.startswith("attn.")]                           # adapter.* / compacter.*
+    order = list(other)                      # post-MLP adapter module is registered before self.attn
+    order += ["attn.in_proj_weight", "attn.in_proj_bias"] + attn_direct
+    order += ["attn.out_proj.weight", "attn.out_proj.bias"] + attn_child
+    order += _FROZEN_BLOCK[4:]
+    return order
+
+
+class _EngineCache:
+    """Sweep-level reuse: ``train_task`` builds a new Classifier for each of the ~90 sweep runs;
+    the frozen, pre-packed bf16 backbone in the engine arena is identical every time, so an engine whose owner
+    has been garbage-collected is handed to the next model with the same checkpoint fingerprint."""
+
+    def __init__(self):
+        self._items = []          # (key, engine, weakref-to-owner)
+
+    @staticmethod
+    def _key(visual, device, num_classes):
+        fp = getattr(visual, "_frozen_fingerprint", None)
+        return None if fp is None else (fp, visual.method, visual.lora_rank, num_classes, str(device))
+
+    def acquire(self, visual, device, num_classes, max_batch):
+        key = self._key(visual, device, num_classes)
+        if key is None:
+            return None
+        for i, (k, e, w) in enumerate(self._items):
+            if k == key and w() is None:
+                self._items[i] = (k, e, weakref.ref(visual))
+                return e
+        return None
+
+    def register(self, visual, eng):
+        key = self._key(visual, eng.device, eng.num_classes)
+        if key is not None:
+            self._items = [(k, e, w) for k, e, w in self._items if w() is not None][-3:]   # bound resident engines
+            self._items.append((key, eng, weakref.ref(visual)))
+
+    def clear(self):
+        self._items.clear()
+
+
+_ENGINES = _EngineCache()
+
+
+class _VisualFn(torch.autograd.Function):
+    """images -> features through the HIP engine; gradients of the trainable tensors come back as
+    the engine's flat-buffer views (the reference gets them from autograd over aten ops)."""
+
+    @staticmethod
+    def forward(ctx, images, visual, save, *params):
+        eng = visual._engine
+        feat = eng.visual_forward(images, save=save)
+        ctx.visual, ctx.n = visual, len(params)
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        eng = ctx.visual._engine
+        eng.grads[:eng.n_tower].zero_()
+        eng.visual_backward(dfeat)
+        views = eng.grad_views()
+        mask = ctx.visual._has_grad
+        grads = [views["visual." + n].clone() if mask[n] else None for n in ctx.visual._trainable_names]
+        return (None, None, None, *grads)
+
+
+class VisionTransformer(nn.Module):
+    """visual.* of the reference (model.py:1017-1051); forward is one engine call."""
+
+    def __init__(self, arch: VitArch, method: str, lora_rank: int):
+        super().__init__()
+        self.input_resolution, self.output_dim = arch.resolution, arch.embed_dim
+        self.arch, self.method, self.lora_rank = arch, method, lora_rank
+        self._engine: HipEngine | None = None
+        E, L = arch.width, arch.layers
+        scale = E ** -0.5
+        spec = adapter_param_spec(method, E, L, lora_rank)
+        self._trainable_names = [n[len("visual."):] for n, _, tr in spec if tr]
+        shapes = {n[len("visual."):]: (s, tr) for n, s, tr in spec}
+        self.register_parameter("class_embedding", nn.Parameter(scale * torch.randn(E), requires_grad=False))
+        self.register_parameter("positional_embedding", nn.Parameter(scale * torch.randn(arch.tokens, E), requires_grad=False))
+        self.register_parameter("proj", nn.Parameter(scale * torch.randn(E, arch.embed_dim), requires_grad=False))
+        self.conv1 = _Params(); self.conv1.add("weight", torch.zeros(E, 3, arch.patch, arch.patch))
+        self.ln_pre = _Params(); self.ln_pre.add("weight", torch.ones(E)); self.ln_pre.add("bias", torch.zeros(E))
+        self.transformer = _Params()
+        for n, (s, tr) in shapes.items():              # shared rules live on the Transformer (model.py:987-999)
+            if n.startswith("transformer.phm_rule"):
+                self.transformer.add(n[len("transformer."):], torch.zeros(s), tr)
+        self.transformer.add_module("resblocks", _Params())
+        frozen_shapes = {"attn.in_proj_weight": (3 * E, E), "attn.in_proj_bias": (3 * E,), "attn.out_proj.weight": (E, E),
+                         "attn.out_proj.bias": (E,), "ln_1.weight": (E,), "ln_1.bias": (E,), "mlp.c_fc.weight": (4 * E, E),
+                         "mlp.c_fc.bias": (4 * E,), "mlp.c_proj.weight": (E, 4 * E), "mlp.c_proj.bias": (E,),
+                         "ln_2.weight": (E,), "ln_2.bias": (E,)}
+        for i in range(L):
+            pre = f"transformer.resblocks.{i}."
+            mine = [n[len(pre):] for n in shapes if n.startswith(pre)]
+            blk = _Params()
+            for n in _block_order(method, mine):
+                if n in frozen_shapes:
+                    blk.add(n, torch.zeros(frozen_shapes[n]))
+                else:
+                    s, tr = shapes[pre + n]
+                    blk.add(n, torch.zeros(s), tr)
+            self.transformer.resblocks.add_module(str(i), blk)
+        self.ln_post = _Params(); self.ln_post.add("weight", torch.ones(E)); self.ln_post.add("bias", torch.zeros(E))
+        self._has_grad = {n: True for n in self._trainable_names}
+
+    # -- engine life cycle ---------------------------------------------------------------
+    def _apply(self, fn, *a, **kw):
+        out = super()._apply(fn, *a, **kw)
+        eng = self._engine
+        if eng is not None and self.class_embedding.device != eng.device:
+            self._engine = None            # moved away: parameters are plain tensors again (values kept by fn)
+        return out
+
+    def engine(self) -> HipEngine:
+        """The HIP context of this tower; created on first use once the module lives on a GPU (the head size
+        of the surrounding Classifier, ``_num_classes``, is known by then)."""
+        if self._engine is None:
+            dev = self.class_embedding.device
+            if dev.type != "cuda":
+                raise _lib.PevitError("the vision tower runs only in the HIP engine: move the model to a GPU "
+                                      "(model.cuda()) -- there is no PyTorch/CPU fallback")
+            self.attach_engine(dev)
+        return self._engine
+
+    def attach_engine(self, device, num_classes: int | None = None, max_batch: int | None = None):
+        """Create (or, for sweep runs over the same checkpoint, re-use) the HIP context on ``device``, load the
+        frozen weights into it and re-seat every trainable Parameter as a view of the engine's flat buffer
+        (the values the Parameters hold now are preserved)."""
+        num_classes = num_classes or getattr(self, "_num_classes", 1)
+        max_batch = max_batch or getattr(self, "_max_batch", 128)
+        sd = {"visual." + k: v for k, v in self.state_dict().items()}
+        eng = _ENGINES.acquire(self, torch.device(device), num_classes, max_batch)
+        if eng is None:
+            eng = HipEngine(self.arch, self.method, num_classes, max_batch, lora_rank=self.lora_rank, device=device)
+            eng.load_state_dict(sd)                    # frozen weights + overlay of the adapter values in sd
+            _ENGINES.register(self, eng)
+        else:
+            eng.reset_run()
+            eng.ensure_batch(max_batch)
+            eng.load_trainable(sd)
+        views = eng.param_views()
+        named = dict(self.named_parameters())
+        for n in self._trainable_names:
+            named[n].data = views["visual." + n]
+        mask, off = eng.grad_mask_host, 0
+        for n in self._trainable_names:
+            k = named[n].numel()
+            self._has_grad[n] = bool(mask[off:off + k].any())
+            off += k
+        self._engine = eng
+        return eng
+
+    def forward(self, x):
+        eng = self.engine()
+        eng.ensure_batch(x.shape[0])
+        named = dict(self.named_parameters())
+        params = [named[n] for n in self._trainable_names]
+        save = torch.is_grad_enabled() and any(p.requires_grad for p in params)   # grad mode is off inside Function.forward
+        return _VisualFn.apply(x.contiguous().float(), self, save, *params)
+
+
+class CLIP(nn.Module):
+    """Same attribute surface as the reference CLIP (model.py:1054-1183)."""
+
+    def __init__(self, embed_dim, image_resolution, vision_layers, vision_width, vision_patch_size, context_length,
+                 vocab_size, transformer_width, transformer_heads, transformer_layers, method="kadaptation", lora_rank=4):
+        super().__init__()
+        self.context_length = context_length
+        arch = VitArch("custom", vision_width, vision_layers, vision_patch_size, image_resolution, embed_dim,
+                       text_width=transformer_width, text_layers=transformer_layers, context_length=context_length,
+                       vocab_size=vocab_size)
+        self.positional_embedding = nn.Parameter(torch.empty(context_length, transformer_width).normal_(std=0.01))
+        self.text_projection = nn.Parameter(torch.empty(transformer_width, embed_dim).normal_(std=transformer_width ** -0.5))
+        self.logit_scale = nn.Parameter(torch.ones([]) * np.log(1 / 0.07))
+        self.visual = VisionTransformer(arch, method, lora_rank)
+        self.transformer = _TextTransformer(transformer_width, transformer_layers, transformer_heads, self.build_attention_mask())
+        self.vocab_size = vocab_size
+        self.token_embedding = nn.Embedding(vocab_size, transformer_width)
+        self.ln_final = LayerNorm(transformer_width)
+
+    def build_attention_mask(self):
+        mask = torch.empty(self.context_length, self.context_length)
+        mask.fill_(float("-inf"))
+        mask.triu_(1)
+        return mask
+
+    @property
+    def dtype(self):
+        return self.visual.conv1.weight.dtype
+
+    def encode_image(self, image):
+        return self.visual(image.type(self.dtype))
+
+    def encode_text(self, text):
+        x = self.token_embedding(text).type(self.dtype)
+        x = x + self.positional_embedding.type(self.dtype)
+        x = self.transformer(x.permute(1, 0, 2)).permute(1, 0, 2)
+        x = self.ln_final(x).type(self.dtype)
+        return x[torch.arange(x.shape[0]), text.argmax(dim=-1)] @ self.text_projection
+
+    def forward(self, image, text):
+        img, txt = self.encode_image(image), self.encode_text(text)
+        img = img / img.norm(dim=-1, keepdim=True)
+        txt = txt / txt.norm(dim=-1, keepdim=True)
+        logits = self.logit_scale.exp() * img @ txt.t()
+        return logits, logits.t()
+
+
+def _init_adapters(model: CLIP, method: str):
+    """Reference initialisation of the added tensors (model.py:533-554,987-999; lora_model.py:466-475;
+    adapter_model.py:285-295; compacter_model.py:254-297,511-519)."""
+    for name, p in model.visual.named_parameters():
+        with torch.no_grad():
+            if "phm_rule" in name and (name.endswith("_left") or name.endswith("_right")):
+                p.uniform_(-0.01, 0.01)
+            elif name.endswith("phm_rule"):
+                p.uniform_(-1, 1)
+            elif "adapter_norm_before" in name:
+                p.fill_(1.0 if name.endswith("weight") else 0.0)
+            elif method == "lora" and "adapter1.weight" in name:
+                p.normal_(std=0.02)
+            elif method == "adapter" and (name.endswith("adapter_down.1.weight") or name.endswith("adapter_up.weight")):
+                p.normal_(mean=0.0, std=0.02)
+            elif method == "compacter" and ("W_left" in name or "W_right" in name):
+                for i in range(p.shape[0]):
+                    nn.init.xavier_uniform_(p[i], gain=math.sqrt(2))
+            # everything else added by the adapters starts at zero (already zero-filled)
+
+
+def _fingerprint(sd) -> tuple:
+    """Cheap identity of the frozen vision weights (shape + a few sampled values of three tensors)."""
+    out = []
+    for k in ("visual.conv1.weight", "visual.proj", "visual.transformer.resblocks.0.mlp.c_fc.weight"):
+        t = sd[k].detach().float().flatten()
+        idx = torch.linspace(0, t.numel() - 1, 16).long()
+        out.append((tuple(sd[k].shape), tuple(round(float(v), 7) for v in t[idx])))
+    return tuple(out)
+
+
+def build_peft_model(state_dict: dict, method: str, lora_rank: int = 4) -> CLIP:
+    if "visual.proj" not in state_dict:
+        raise RuntimeError("only the ViT variants of CLIP are supported by the PEFT engines (the reference's "
+                           "adapters are injected into VisionTransformer only)")
+    vision_width = state_dict["visual.conv1.weight"].shape[0]
+    vision_layers = len([k for k in state_dict if k.startswith("visual.") and k.endswith(".attn.in_proj_weight")])
+    vision_patch_size = state_dict["visual.conv1.weight"].shape[-1]
+    grid_size = round((state_dict["visual.positional_embedding"].shape[0] - 1) ** 0.5)
+    image_resolution = vision_patch_size * grid_size
+    embed_dim = state_dict["text_projection"].shape[1]
+    context_length = state_dict["positional_embedding"].shape[0]
+    vocab_size = state_dict["token_embedding.weight"].shape[0]
+    transformer_width = state_dict["ln_final.weight"].shape[0]
+    transformer_heads = transformer_width // 64
+    transformer_layers = len(set(k.split(".")[2] for k in state_dict if k.startswith("transformer.resblocks")))
+    model = CLIP(embed_dim, image_resolution, vision_layers, vision_width, vision_patch_size, context_length, vocab_size,
+                 transformer_width, transformer_heads, transformer_layers, method=method, lora_rank=lora_rank)
+    _init_adapters(model, method)
+    for key in ("input_resolution", "context_length", "vocab_size"):
+        state_dict.pop(key, None)
+    own = model.state_dict()
+    own.update({k: state_dict[k].float() for k in own if k in state_dict})      # checkpoint overlays, adapters keep init
+    model.load_state_dict(own)
+    model.visual._frozen_fingerprint = state_dict.get("__fingerprint__", None) or _fingerprint(own)
+    return model.eval()
+
+
+def build_model(state_dict: dict) -> CLIP:
+    """KAdaptation CLIP (reference: evaluation/model.py:1210-1250)."""
+    return build_peft_model(state_dict, "kadaptation")

@@ -227,11 +227,44 @@ def param_count_table():
     return table
 
 
+def text_case():
+    """encode_text of the reference CLIP (model.py:1153-1168) on seeded tokens + the zero-shot head
+    reduction of feature.py:513-520 (normalise, mean over templates, normalise, stack on dim 1)."""
+    arch = ARCHS["tiny-128"]
+    sd = synth_state_dict(arch, seed=2, text_tower=True)
+    sd = {k: (v.half().float() if v.dim() > 0 else v) for k, v in sd.items()}
+    model = build_ref("kadaptation", sd)
+    g = torch.Generator(device="cpu"); g.manual_seed(11)
+    classes, templates = 10, 3
+    tokens = torch.randint(1, arch.vocab_size - 1, (classes, templates, arch.context_length), generator=g)
+    # an end-of-text marker (the arg-max token, model.py:1166) at a random position per prompt
+    eot = torch.randint(2, arch.context_length, (classes, templates), generator=g)
+    for c in range(classes):
+        for t in range(templates):
+            tokens[c, t, eot[c, t]] = arch.vocab_size - 1
+            tokens[c, t, eot[c, t] + 1:] = 0
+    feats, cols = [], []
+    with torch.no_grad():
+        for c in range(classes):
+            e = model.encode_text(tokens[c])
+            feats.append(e.clone())
+            e = e / e.norm(dim=-1, keepdim=True)
+            m = e.mean(dim=0)
+            cols.append(m / m.norm())
+    return dict(tokens=tokens.numpy(), text_features=torch.stack(feats).numpy(),
+                zeroshot_weights=torch.stack(cols, dim=1).numpy())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also run the full-size ViT-B/32 bs=8 cases")
     ap.add_argument("--counts", action="store_true", help="also regenerate the parameter-count table")
+    ap.add_argument("--text-only", action="store_true", help="only (re)generate tiny_text.npz")
     args = ap.parse_args()
+    if args.text_only:
+        np.savez_compressed(os.path.join(HERE, "tiny_text.npz"), **text_case())
+        print("tiny_text written")
+        return
     torch.manual_seed(0)
     torch.set_num_threads(8)
     # the tiny checkpoint is stored once (fp16-exact values) and shared by all tiny cases
@@ -248,6 +281,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "tiny_lora_r8.npz"), **tensors)
     with open(os.path.join(HERE, "tiny_lora_r8.json"), "w") as f:
         json.dump(meta, f, indent=1)
+    np.savez_compressed(os.path.join(HERE, "tiny_text.npz"), **text_case())
     if args.counts:
         with open(os.path.join(HERE, "param_counts.json"), "w") as f:
             json.dump(param_count_table(), f, indent=1)
