@@ -73,6 +73,21 @@ def cpu_baseline(seconds_budget=25.0):
                       f"median {med * 1e3:.0f} ms/step, torch {torch.__version__} CPU"}
 
 
+def pmc_traffic(arch, method, batch):
+    """HBM bytes per GEMM launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE and
+    WRITE_SIZE cannot share a pass and cannot be read from inside this process; scripts/pmc_traffic.py
+    produced the file from this very command line).  None when no pass exists for this workload."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic.json")
+    try:
+        with open(path) as f:
+            entry = json.load(f).get(f"{arch}|{method}|bs{batch}")
+    except (OSError, ValueError):
+        entry = None
+    if not entry:
+        return None, "no PMC pass committed for this workload"
+    return entry["gemm"]["hbm_bytes_per_launch"], entry["how"]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -84,6 +99,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=INT",
                     help="library tuning knob for A/B runs, e.g. gemm_hoist=0 (see pevit_tune)")
+    ap.add_argument("--pmc-calib", action="store_true",
+                    help="(profiling runs only) first move a known byte count through HBM so that the FETCH_SIZE / "
+                         "WRITE_SIZE counters of the same rocprofv3 pass can be calibrated (scripts/pmc_traffic.py)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -122,6 +140,17 @@ def main():
     images, labels = synth_batch(args.batch, arch.resolution, classes, seed_img=rank * 2, seed_lbl=rank * 2 + 1)
     images, labels = images.to(dev), labels.to(dev)
 
+    if args.pmc_calib:
+        import ctypes as C
+        n = 256 << 20                                   # 1 GiB of f32: 4x the 256 MiB Infinity Cache
+        src = torch.ones(n, dtype=torch.float32, device=dev)
+        dst16 = torch.empty(n, dtype=torch.bfloat16, device=dev)
+        for _ in range(3):                              # pevit cast kernel: reads 4n bytes (16 B/lane), writes 2n
+            eng.lib.pevit_op_cast_bf16(C.c_void_p(torch.cuda.current_stream().cuda_stream), C.c_void_p(src.data_ptr()),
+                                       C.c_void_p(dst16.data_ptr()), n, 1.0)
+        torch.cuda.synchronize()
+        del src, dst16
+
     def step():
         return eng.train_step(images, labels, lr=0.01, momentum=0.9, weight_decay=1e-6, world_size=world)
 
@@ -156,6 +185,8 @@ def main():
         gflop = train_gflop_per_image(arch.width, arch.layers, arch.patch, arch.resolution, arch.embed_dim, classes, r, site)
         step_tflops = value / world * gflop / 1e3      # whole-step algorithmic TFLOP/s per GPU
         gemm_tflops = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        algo_bytes = eng.last_profile_bytes / max(gemm_launches, 1)
+        traffic, traffic_how = pmc_traffic(args.arch, args.method, args.batch)
         out = {
             "metric": "images/sec fine-tune, CLIP ViT-B/32 + KAdaptation, bs=128, 1/2/4/8 GPU",
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -168,7 +199,8 @@ def main():
                        "train_gflop_per_image": gflop, "final_loss": final_loss},
             "roofline": {"bound": "mfma", "kernel": "gemm_bf16_nt_kernel (all epilogues / tile shapes)",
                          "achieved": gemm_tflops, "peak": PEAK_TFLOPS_BF16, "unit": "TFLOP/s",
-                         "frac": gemm_tflops / PEAK_TFLOPS_BF16, "traffic": None,
+                         "frac": gemm_tflops / PEAK_TFLOPS_BF16, "traffic": traffic, "traffic_unit": "bytes/launch",
+                         "traffic_how": traffic_how, "algorithmic_bytes_per_launch": algo_bytes,
                          "launches_per_step": gemm_launches / prof_steps,
                          "avg_launch_us": gemm_ms * 1e3 / max(gemm_launches, 1),
                          "gemm_ms_per_step": gemm_ms / prof_steps,

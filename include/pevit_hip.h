@@ -122,7 +122,7 @@ int pevit_train_forward_backward(pevit_ctx* ctx, void* stream, const float* imag
 /* ---- measurement: HIP events around every MFMA GEMM launch of the context (the dominant kernel
  * family); totals over the launches recorded between begin and end ---------------------------- */
 int pevit_profile_begin(pevit_ctx* ctx, int max_launches);
-int pevit_profile_end(pevit_ctx* ctx, double* total_ms, double* total_flops, int* launches);
+int pevit_profile_end(pevit_ctx* ctx, double* total_ms, double* total_flops, double* total_bytes, int* launches);
 
 /* ---- single kernels, exposed for parity tests and profiling ------------------------- */
 int pevit_op_gemm(void* stream, int epilogue, const void* A_bf16, int lda, const void* B_bf16, int ldb, int b_rows,

@@ -85,6 +85,7 @@ struct pevit_ctx {
     int prof_n = 0, prof_cap = 0;
     hipEvent_t* prof_ev = nullptr;      // 2 per launch
     double* prof_flops = nullptr;
+    double* prof_bytes = nullptr;       // algorithmic operand + result bytes of each launch
 };
 
 namespace {
@@ -260,6 +261,7 @@ extern "C" void pevit_ctx_destroy(pevit_ctx* c) {
     for (int i = 0; i < 2 * c->prof_cap; ++i) (void)hipEventDestroy(c->prof_ev[i]);
     delete[] c->prof_ev;
     delete[] c->prof_flops;
+    delete[] c->prof_bytes;
     delete[] c->blk;
     delete[] c->sav;
     delete c;
@@ -399,6 +401,11 @@ int gemm(pevit_ctx* c, int epi, const GemmParams& p, hipStream_t s) {
     if (rec) {
         (void)hipEventRecord(c->prof_ev[2 * c->prof_n + 1], s);
         c->prof_flops[c->prof_n] = 2.0 * (double)p.M * (double)p.N * (double)p.K;
+        // every operand read once, every result written once (the minimum any schedule must move)
+        const double mn = (double)p.M * (double)p.N;
+        c->prof_bytes[c->prof_n] = 2.0 * ((double)p.M + (double)p.N) * (double)p.K + (p.bias ? 4.0 * p.N : 0.0) +
+                                   mn * ((p.resid ? 4.0 : 0.0) + (p.aux ? 2.0 : 0.0) + (p.outf ? 4.0 : 0.0) +
+                                         (p.outf2 ? 4.0 : 0.0) + (p.outb ? 2.0 : 0.0) + (p.outb2 ? 2.0 : 0.0));
         ++c->prof_n;
     }
     return rc;
@@ -796,10 +803,11 @@ extern "C" int pevit_profile_begin(pevit_ctx* c, int max_launches) {
     if (!c || max_launches <= 0) { pevit_set_error("profile_begin: bad argument"); return -1; }
     if (c->prof_cap < max_launches) {
         for (int i = 0; i < 2 * c->prof_cap; ++i) (void)hipEventDestroy(c->prof_ev[i]);
-        delete[] c->prof_ev; delete[] c->prof_flops;
+        delete[] c->prof_ev; delete[] c->prof_flops; delete[] c->prof_bytes;
         c->prof_ev = new (std::nothrow) hipEvent_t[2 * max_launches];
         c->prof_flops = new (std::nothrow) double[max_launches];
-        if (!c->prof_ev || !c->prof_flops) { pevit_set_error("profile_begin: out of host memory"); return -1; }
+        c->prof_bytes = new (std::nothrow) double[max_launches];
+        if (!c->prof_ev || !c->prof_flops || !c->prof_bytes) { pevit_set_error("profile_begin: out of host memory"); return -1; }
         for (int i = 0; i < 2 * max_launches; ++i) HIP_OK(hipEventCreate(&c->prof_ev[i]));
         c->prof_cap = max_launches;
     }
@@ -807,18 +815,19 @@ extern "C" int pevit_profile_begin(pevit_ctx* c, int max_launches) {
     return 0;
 }
 
-extern "C" int pevit_profile_end(pevit_ctx* c, double* total_ms, double* total_flops, int* launches) {
+extern "C" int pevit_profile_end(pevit_ctx* c, double* total_ms, double* total_flops, double* total_bytes, int* launches) {
     if (!c || !c->prof_on) { pevit_set_error("profile_end: profiling is not active"); return -1; }
     c->prof_on = false;
-    double ms = 0.0, fl = 0.0;
+    double ms = 0.0, fl = 0.0, by = 0.0;
     for (int i = 0; i < c->prof_n; ++i) {
         HIP_OK(hipEventSynchronize(c->prof_ev[2 * i + 1]));
         float t = 0.f;
         HIP_OK(hipEventElapsedTime(&t, c->prof_ev[2 * i], c->prof_ev[2 * i + 1]));
-        ms += t; fl += c->prof_flops[i];
+        ms += t; fl += c->prof_flops[i]; by += c->prof_bytes[i];
     }
     if (total_ms) *total_ms = ms;
     if (total_flops) *total_flops = fl;
+    if (total_bytes) *total_bytes = by;
     if (launches) *launches = c->prof_n;
     return 0;
 }

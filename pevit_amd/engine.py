@@ -250,11 +250,14 @@ class HipEngine:
         self._steps += 1
 
     def profile_gemms(self, fn, max_launches=4096):
-        """Run ``fn()`` with HIP events around every GEMM launch; returns (ms, flops, launches)."""
+        """Run ``fn()`` with HIP events around every GEMM launch; returns (ms, flops, launches); the algorithmic
+        operand+result bytes of those launches are left in ``self.last_profile_bytes``."""
         _lib.check(self.lib.pevit_profile_begin(self._ctx, max_launches), "pevit_profile_begin")
         fn()
-        ms, fl, n = C.c_double(), C.c_double(), C.c_int()
-        _lib.check(self.lib.pevit_profile_end(self._ctx, C.byref(ms), C.byref(fl), C.byref(n)), "pevit_profile_end")
+        ms, fl, by, n = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+        _lib.check(self.lib.pevit_profile_end(self._ctx, C.byref(ms), C.byref(fl), C.byref(by), C.byref(n)),
+                   "pevit_profile_end")
+        self.last_profile_bytes = by.value
         return ms.value, fl.value, n.value
 
     def reset_optimizer(self):
