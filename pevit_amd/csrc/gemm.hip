@@ -30,6 +30,7 @@ constexpr int TILE_BAND = 6;
 int g_gemm_config = -1;    // -1: heuristic ; >= 0: force a tile configuration (A/B measurements)
 int g_gemm_persistent = 1;
 int g_gemm_hoist = 1;       // hoist all fragment reads of a k-tile ahead of its MFMAs
+int g_gemm_ablate = 0;      // measurement only (GemmParams::dbg)
 
 int num_cus() {
     static int n = 0;
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_bf16_nt_kernel(GemmParams p, i
 #pragma unroll
     for (int i = 0; i < WN; ++i) b_off[i] = A_BYTES + (wn * (BN / 2) + i * 32 + frow) * ROWB;
 
-    const int nk = p.K / BK;
+    const int nk = (p.dbg & 1) ? 0 : p.K / BK;
     int tile = blockIdx.x;
     int m0, n0;
     tile_origin<BM, BN>(p, tile, m0, n0);
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_bf16_nt_kernel(GemmParams p, i
                     const int col = cn0 + wn * (BN / 2) + j * 32 + lc;
                     const float4 x0 = *reinterpret_cast<const float4*>(cw + lr * 32 + lc);
                     const float4 x1 = *reinterpret_cast<const float4*>(cw + lr * 32 + lc + 4);
-                    if (row < p.M && col < p.N) {
+                    if (row < p.M && col < p.N && !(p.dbg & 2)) {
                         float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
                         epilogue_store<EPI>(p, row, col, v);
                     }
@@ -364,6 +365,190 @@ __global__ __launch_bounds__(256, MINB) void gemm_bf16_nt_kernel(GemmParams p, i
         if (next >= ntiles) break;
         tile = next;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Ring form.  Measured on MI355X (scripts/ablate_gemm.py, profiles/r01_gemm_ablation.txt): the k-loop of
+// the kernel above runs at the same per-workgroup speed whatever shares its CU, and every tile shape with
+// the same number of operand bytes in flight per CU lands at the same TFLOP/s -- it is bound by the
+// round trip of the ONE k-tile it keeps in flight, not by MFMA, LDS or L2 bandwidth.  This form keeps
+// S-1 k-tiles (BK = 32, 16 KiB each) in flight per workgroup in an S-deep LDS ring, with counted
+// s_waitcnt vmcnt (never 0 in steady state) and a raw s_barrier per k-tile, and treats the k-tiles of all
+// the output tiles a persistent workgroup owns as ONE stream: the loads of the next output tile are
+// already in flight while the current one runs its epilogue.
+//
+// Ordering rules relied on (MI355X_MICROARCH.md item 7 / cdna guide "8-phase" notes):
+//   RAW  a ds_read of ring slot g sees the LDS-DMA data once the issuing waves waited for it with a
+//        counted vmcnt AND the reader passed a barrier after that wait  (wait -> s_barrier -> ds_read);
+//   WAR  slot (g-1) % S is re-targeted by DMA only after the barrier of iteration g, which every wave
+//        reaches after its ds_reads of iteration g-1 returned (they feed its MFMAs);
+//   vmcnt decrements in issue order on gfx9-family parts (loads, LDS-DMA and stores share the counter),
+//        so "at most N outstanding" means "all but the youngest N completed": the epilogue's global
+//        loads / stores sit between DMA groups in that order and only make the waits conservative.
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int EPI, int S>
+__global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmParams p, int ntiles) {
+    constexpr int BM = 128, BN = 128, BK = 32;
+    constexpr int ROWB = BK * 2, CH = 4, RPP = 16;      // 64-byte rows, 4 chunks, 16 rows per 1 KiB piece
+    constexpr int A_BYTES = BM * ROWB, STAGE_BYTES = (BM + BN) * ROWB;   // 8 KiB + 8 KiB
+    constexpr int G = 4;                                // LDS-DMA instructions per wave per k-tile
+    static_assert(S >= 3 && (S - 2) * G <= 63, "ring depth");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wid >> 1, wn = wid & 1;
+    const int nk = (p.dbg & 1) ? 1 : p.K / BK;
+
+    // ---- producer state: position of the next k-tile to request in this workgroup's stream
+    int itile = blockIdx.x, ikt = 0, islot = 0, kstart = 0;
+    const bf16* a_src[2];
+    const bf16* b_src[2];
+    auto set_sources = [&](int tile) {
+        int m0, n0;
+        tile_origin<BM, BN>(p, tile, m0, n0);
+        if (p.dbg & 16) kstart = ((((n0 >> 7) + 3 * (m0 >> 7)) & 7) * nk) >> 3;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (wid * 2 + i) * RPP + lane / CH;
+            const int chunk = (lane % CH) ^ ((row >> 2) & (CH - 1));
+            int ar = m0 + row; ar = ar < p.M ? ar : p.M - 1;
+            int br = n0 + row; br = br < p.Nb ? br : p.Nb - 1;
+            a_src[i] = p.A + (size_t)ar * p.lda + chunk * 8;
+            b_src[i] = p.B + (size_t)br * p.ldb + chunk * 8;
+        }
+    };
+    auto issue_next = [&]() {
+        if (itile >= ntiles) return;
+        char* sa = smem + islot * STAGE_BYTES + (wid * 2) * 1024;
+        char* sb = sa + A_BYTES;
+        int kk = ikt + kstart; kk = kk >= nk ? kk - nk : kk;
+        const int koff = kk * BK;
+        if (!(p.dbg & 4)) {
+            glds16(a_src[0] + koff, sa);
+            glds16(a_src[1] + koff, sa + 1024);
+            glds16(b_src[0] + koff, sb);
+            glds16(b_src[1] + koff, sb + 1024);
+        }
+        islot = (islot + 1 == S) ? 0 : islot + 1;
+        if (++ikt == nk) {
+            ikt = 0;
+            itile += gridDim.x;
+            if (itile < ntiles) set_sources(itile);
+        }
+    };
+
+    // ---- consumer state
+    const int frow = lane & 31, fswz = (frow >> 2) & (CH - 1), fhalf = lane >> 5;
+    int a_off[2], b_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        a_off[i] = (wm * 64 + i * 32 + frow) * ROWB;
+        b_off[i] = A_BYTES + (wn * 64 + i * 32 + frow) * ROWB;
+    }
+    const int c0 = ((0 + fhalf) ^ fswz) << 4, c1 = ((2 + fhalf) ^ fswz) << 4;
+
+    set_sources(itile);
+#pragma unroll
+    for (int i = 0; i < S - 1; ++i) issue_next();
+
+    int cslot = 0;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        for (int kt = 0; kt < nk; ++kt) {
+            // the oldest group in flight is the k-tile about to be consumed; while the stream still has
+            // k-tiles to request exactly S-1 groups are in flight here, afterwards fewer (drain).
+            if (itile < ntiles) wait_vmcnt<(S - 2) * G>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            issue_next();
+            const char* st = smem + cslot * STAGE_BYTES;
+            cslot = (cslot + 1 == S) ? 0 : cslot + 1;
+            if (p.dbg & 8) continue;
+            bf16x8 a0[2], b0[2], a1[2], b1[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a0[i] = *reinterpret_cast<const bf16x8*>(st + a_off[i] + c0);
+                b0[i] = *reinterpret_cast<const bf16x8*>(st + b_off[i] + c0);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a1[i] = *reinterpret_cast<const bf16x8*>(st + a_off[i] + c1);
+                b1[i] = *reinterpret_cast<const bf16x8*>(st + b_off[i] + c1);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b0[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
+        }
+        // ---- epilogue through the ring slot that was consumed last: it is not a DMA target before the
+        // next iteration's barrier.  One barrier so that no wave is still reading it.
+        __builtin_amdgcn_s_barrier();
+        int cm0, cn0;
+        tile_origin<BM, BN>(p, tile, cm0, cn0);
+        const int eslot = (cslot == 0) ? S - 1 : cslot - 1;
+        float* cw = reinterpret_cast<float*>(smem + eslot * STAGE_BYTES + wid * 4096);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    cw[row * 32 + (lane & 31)] = acc[i][j][r];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int pass = 0; pass < 2; ++pass) {
+                    const int lr = pass * 16 + (lane >> 2);
+                    const int lc = (lane & 3) * 8;
+                    const int row = cm0 + wm * 64 + i * 32 + lr;
+                    const int col = cn0 + wn * 64 + j * 32 + lc;
+                    const float4 x0 = *reinterpret_cast<const float4*>(cw + lr * 32 + lc);
+                    const float4 x1 = *reinterpret_cast<const float4*>(cw + lr * 32 + lc + 4);
+                    if (row < p.M && col < p.N && !(p.dbg & 2)) {
+                        float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                        epilogue_store<EPI>(p, row, col, v);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+    }
+}
+
+int g_gemm_ring = 0;    // ring depth of gemm_ring_kernel (0: two-stage kernel everywhere; the ring measured no faster, see profiles/r01_l2_fetch_bound.md)
+
+template <int EPI, int S>
+int launch_ring(const GemmParams& p, hipStream_t stream) {
+    constexpr int lds = S * 16384;
+    auto kern = gemm_ring_kernel<EPI, S>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
+            hipSuccess) {
+            pevit_set_error("hipFuncSetAttribute(gemm ring epi %d S %d) failed", EPI, S);
+            return -1;
+        }
+        attr_set = true;
+    }
+    const int tiles = ceil_div(p.M, 128) * ceil_div(p.N, 128);
+    const int slots = num_cus() * 2;
+    hipLaunchKernelGGL(kern, dim3(tiles < slots ? tiles : slots), dim3(256), lds, stream, p, tiles);
+    return 0;
 }
 
 struct TileConfig { int bm, bn, bk, minb, sched; };
@@ -419,6 +604,13 @@ int pick_config(const GemmParams& p) {
 
 template <int EPI>
 int launch_epi(const GemmParams& p, hipStream_t stream) {
+    if (g_gemm_ring && g_gemm_config < 0 && p.N > 64) {
+        switch (g_gemm_ring) {
+            case 3: return launch_ring<EPI, 3>(p, stream);
+            case 4: return launch_ring<EPI, 4>(p, stream);
+            default: return launch_ring<EPI, 5>(p, stream);
+        }
+    }
     switch (pick_config(p)) {
         case 0: return launch_cfg<EPI, 0>(p, stream);
         case 1: return launch_cfg<EPI, 1>(p, stream);
@@ -435,9 +627,13 @@ int launch_epi(const GemmParams& p, hipStream_t stream) {
 
 int pevit_gemm_set_variant(int v) { const int old = g_gemm_config; g_gemm_config = v; return old; }
 int pevit_gemm_set_hoist(int v) { const int old = g_gemm_hoist; g_gemm_hoist = v; return old; }
+int pevit_gemm_set_ablate(int v) { const int old = g_gemm_ablate; g_gemm_ablate = v; return old; }
+int pevit_gemm_set_ring(int v) { const int old = g_gemm_ring; g_gemm_ring = v; return old; }
 int pevit_gemm_set_persistent(int v) { const int old = g_gemm_persistent; g_gemm_persistent = v; return old; }
 
-int pevit_launch_gemm(int epi, const GemmParams& p, hipStream_t stream) {
+int pevit_launch_gemm(int epi, const GemmParams& p_in, hipStream_t stream) {
+    GemmParams p = p_in;
+    p.dbg = g_gemm_ablate;
     if (p.K % 64 != 0 || p.K <= 0) { pevit_set_error("gemm: K=%d must be a positive multiple of 64", p.K); return -1; }
     if (p.N % 8 != 0) { pevit_set_error("gemm: N=%d must be a multiple of 8", p.N); return -1; }
     if (p.M <= 0 || p.N <= 0) { pevit_set_error("gemm: empty problem M=%d N=%d", p.M, p.N); return -1; }
