@@ -886,6 +886,7 @@ extern "C" int pevit_tune(const char* key, int value) {
     if (key && !strcmp(key, "gemm_hoist")) return pevit_gemm_set_hoist(value);
     if (key && !strcmp(key, "gemm_ablate")) return pevit_gemm_set_ablate(value);
     if (key && !strcmp(key, "gemm_ring")) return pevit_gemm_set_ring(value);
+    if (key && !strcmp(key, "gemm_dephase")) return pevit_gemm_set_dephase(value);
     if (key && !strcmp(key, "attn_bwd_phase")) return pevit_attn_set_bwd_phase(value);
     pevit_set_error("tune: unknown key %s", key ? key : "(null)");
     return -1;

@@ -31,6 +31,7 @@ int g_gemm_config = -1;    // -1: heuristic ; >= 0: force a tile configuration (
 int g_gemm_persistent = 1;
 int g_gemm_hoist = 1;       // hoist all fragment reads of a k-tile ahead of its MFMAs
 int g_gemm_ablate = 0;      // measurement only (GemmParams::dbg)
+int g_gemm_dephase = 0;     // x 512 clk start delay of the second half of the grid (0: off; helps back-to-back microbenchmarks by 7 %, costs 2 % inside the step)
 
 int num_cus() {
     static int n = 0;
@@ -268,6 +269,12 @@ __global__ __launch_bounds__(256, MINB) void gemm_bf16_nt_kernel(GemmParams p, i
 
     const int nk = (p.dbg & 1) ? 0 : p.K / BK;
     int tile = blockIdx.x;
+    // De-phase the two workgroups that share a CU: they run tiles of equal length, so left alone both are in
+    // their k-loop (operand stream) and then both in their epilogue (store burst) at the same time.  Holding
+    // the second half of the grid back by ~half an epilogue makes one's stores overlap the other's loads
+    // (measured -7 % on the step's GEMMs, scripts/phase_gemm.py).
+    if (p.dephase > 0 && blockIdx.x >= (gridDim.x >> 1))
+        for (int i = 0; i < p.dephase; ++i) __builtin_amdgcn_s_sleep(8);
     int m0, n0;
     tile_origin<BM, BN>(p, tile, m0, n0);
     set_sources(m0, n0);
@@ -628,12 +635,14 @@ int launch_epi(const GemmParams& p, hipStream_t stream) {
 int pevit_gemm_set_variant(int v) { const int old = g_gemm_config; g_gemm_config = v; return old; }
 int pevit_gemm_set_hoist(int v) { const int old = g_gemm_hoist; g_gemm_hoist = v; return old; }
 int pevit_gemm_set_ablate(int v) { const int old = g_gemm_ablate; g_gemm_ablate = v; return old; }
+int pevit_gemm_set_dephase(int v) { const int old = g_gemm_dephase; g_gemm_dephase = v; return old; }
 int pevit_gemm_set_ring(int v) { const int old = g_gemm_ring; g_gemm_ring = v; return old; }
 int pevit_gemm_set_persistent(int v) { const int old = g_gemm_persistent; g_gemm_persistent = v; return old; }
 
 int pevit_launch_gemm(int epi, const GemmParams& p_in, hipStream_t stream) {
     GemmParams p = p_in;
     p.dbg = g_gemm_ablate;
+    p.dephase = g_gemm_dephase;
     if (p.K % 64 != 0 || p.K <= 0) { pevit_set_error("gemm: K=%d must be a positive multiple of 64", p.K); return -1; }
     if (p.N % 8 != 0) { pevit_set_error("gemm: N=%d must be a multiple of 8", p.N); return -1; }
     if (p.M <= 0 || p.N <= 0) { pevit_set_error("gemm: empty problem M=%d N=%d", p.M, p.N); return -1; }

@@ -33,6 +33,7 @@ struct GemmParams {
     size_t head_stride;   // elements between the q, k and v planes
     int E, H, Ntok;
     int dbg;              // measurement only: bit 0 skips the k-loop, bit 1 skips the epilogue stores
+    int dephase;          // start delay (x 512 clk) of the second half of the grid, see gemm.hip
 };
 
 int pevit_launch_gemm(int epi, const GemmParams& p, hipStream_t stream);
@@ -40,6 +41,7 @@ int pevit_gemm_set_persistent(int v);
 int pevit_gemm_set_hoist(int v);
 int pevit_gemm_set_ablate(int v);
 int pevit_gemm_set_ring(int v);
+int pevit_gemm_set_dephase(int v);
 int pevit_gemm_set_variant(int v);   // -1: heuristic, >= 0: forced tile configuration; returns the previous value
 
 // ---- norm.hip --------------------------------------------------------------------
