@@ -322,3 +322,83 @@ def test_long_sequences_full_step_vs_oracle(method, arch_name, B):
         else:
             err = rel_err(gv[k].cpu(), tr.p[k].grad)
             assert err < tol(GRAD_TOL, noise[k], max(noise.values())), (k, err, noise[k])
+
+
+# ---- the architectures of BASELINE configs 3-5 at full width/depth ---------------------------------------
+def _full_size_case(arch_name, method, lora_r, seed=2):
+    from pevit_amd.engine import adapter_param_spec
+    from pevit_amd.synth import ARCHS, randomize_adapters, synth_state_dict
+    arch = ARCHS[arch_name]
+    sd = {k: v for k, v in synth_state_dict(arch, seed=seed, text_tower=False).items() if k.startswith("visual.")}
+    ad = [(n, torch.zeros(s)) for n, s, tr in adapter_param_spec(method, arch.width, arch.layers, lora_r)]
+    randomize_adapters(ad, seed=3)
+    for n, v in ad:
+        if n.endswith("phm_rule"):
+            v.copy_(torch.rand(v.shape, generator=torch.Generator().manual_seed(8)) * 2 - 1)
+    sd.update(dict(ad))
+    return arch, sd
+
+
+@pytest.mark.parametrize("arch_name,method,lora_r", [("ViT-B/32", "lora", 8), ("ViT-B/16", "compacter", 4),
+                                                      ("ViT-L/14", "kadaptation", 4)])
+def test_baseline_config_architectures_vs_oracle(arch_name, method, lora_r):
+    """BASELINE configs 3 (ViT-B/32 + LoRA r=8), 4 (ViT-B/16 + Compacter, N=197) and 5 (ViT-L/14 + KAdaptation,
+    width 1024, 24 layers, N=257, patch 14) at their real width and depth, batch 8 (what the CPU oracle finishes
+    in seconds): whole step against the live oracle.  Same gates as the 12-layer fixture test, widened per
+    tensor only where bf16 operand rounding alone exceeds them (24 layers accumulate more of it)."""
+    from oracle import ref_cpu
+    from pevit_amd.engine import HipEngine
+    from pevit_amd.synth import synth_batch
+    arch, sd = _full_size_case(arch_name, method, lora_r)
+    B, C = 8, 10
+    images, labels = synth_batch(B, arch.resolution, C, seed_img=3, seed_lbl=4)
+    g = torch.Generator().manual_seed(5)
+    D = arch.embed_dim
+    head_w = (torch.rand((C, D), generator=g) * 2 - 1) / D ** 0.5
+    head_b = (torch.rand((C,), generator=g) * 2 - 1) / D ** 0.5
+    if method == "lora" and lora_r != 4:
+        pytest.importorskip("oracle")      # the oracle infers r from the tensor shapes
+    tr, ref_logits, ref_loss, logit_noise, noise = bf16_noise(sd, method, C, images, labels, head_w, head_b)
+    eng = HipEngine(arch, method, C, B, lora_rank=lora_r)
+    eng.load_state_dict(sd)
+    v = eng.param_views()
+    with torch.no_grad():
+        v["layers.0.weight"].copy_(head_w); v["layers.0.bias"].copy_(head_b)
+    logits, loss = eng.forward_backward(images.cuda(), labels.cuda())
+    torch.cuda.synchronize()
+    assert torch.isfinite(logits).all() and torch.isfinite(eng.grads).all()
+    assert max_rel(logits.cpu(), ref_logits) < tol(DEEP_LOGIT_TOL, logit_noise)
+    assert abs(float(loss) - float(ref_loss)) < 5e-2
+    gv = eng.grad_views()
+    worst = max(noise.values())
+    for k in tr.names:
+        if tr.p[k].grad is None:
+            assert float(gv[k].abs().max()) == 0.0
+        else:
+            err = rel_err(gv[k].cpu(), tr.p[k].grad)
+            assert err < tol(DEEP_GRAD_TOL, noise[k], worst), (k, err, noise[k])
+
+
+@pytest.mark.parametrize("arch_name,method,lora_r,B", [("ViT-B/32", "lora", 8, 128), ("ViT-B/16", "compacter", 4, 64),
+                                                        ("ViT-L/14", "kadaptation", 4, 32)])
+def test_baseline_config_per_gpu_sizes_train(arch_name, method, lora_r, B):
+    """The per-GPU shard sizes of BASELINE configs 3-5 (1024/8, 512/8, 256/8): the step is deterministic and
+    a few SGD steps on one batch reduce the loss (size-independent properties; no oracle at this size)."""
+    from pevit_amd.engine import HipEngine
+    from pevit_amd.synth import reference_init_, synth_batch
+    arch, sd = _full_size_case(arch_name, method, lora_r)
+    eng = HipEngine(arch, method, 100, B, lora_rank=lora_r)
+    eng.load_state_dict(sd)
+    views = eng.param_views()
+    reference_init_(views.items(), method)
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(5)
+        views["layers.0.weight"].copy_((torch.rand(views["layers.0.weight"].shape, generator=g) * 2 - 1) * arch.embed_dim ** -0.5)
+        views["layers.0.bias"].zero_()
+    images, labels = synth_batch(B, arch.resolution, 100)
+    images, labels = images.cuda(), labels.cuda()
+    l1, loss1 = eng.forward_backward(images, labels); g1 = eng.grads.clone(); l1 = l1.clone(); loss1 = float(loss1)
+    l2, loss2 = eng.forward_backward(images, labels)
+    assert torch.equal(l1, l2) and torch.equal(g1, eng.grads) and loss1 == float(loss2)
+    losses = [float(eng.train_step(images, labels, lr=0.05, momentum=0.9, weight_decay=0.0)[1]) for _ in range(6)]
+    assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < 0.7 * losses[0], losses
