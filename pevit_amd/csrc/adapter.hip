@@ -158,22 +158,24 @@ __global__ __launch_bounds__(256) void tn_gemm64_kernel(const bf16* __restrict__
 // LayerNorm backward with trainable affine: dx (+ dres) as ln_bwd, plus per-block partial sums of
 // d gamma = sum_r dy*xhat, d beta = sum_r dy, and the f32 column sums of dres (the gradient of the
 // adapter's up-projection bias: summing its bf16 copy instead loses the cancellation-heavy sum).
-// Block = 64 rows (16 per wave); partial[block][3][E].
-constexpr int LNA_ROWS = 64;
+// Block = 32 rows = 8 waves x 4 rows (1600 waves at T = 6400: the 64-row / 4-wave form left 156 CUs idle and
+// ran 4x slower than the plain LayerNorm backward); partial[block][3][E].
+constexpr int LNA_ROWS = 32;
+constexpr int LNA_WAVES = 8;
 constexpr int LNA_MAXV = 4;
-__global__ __launch_bounds__(256) void ln_bwd_affine_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+__global__ __launch_bounds__(64 * LNA_WAVES) void ln_bwd_affine_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                             const float* __restrict__ gamma, const float* dres, float* dx,
                                                             bf16* __restrict__ dx_bf16, float* __restrict__ partial, int rows,
                                                             int E) {
-    extern __shared__ float red[];     // [3 waves][3][E]
+    extern __shared__ float red[];     // [LNA_WAVES - 1][3][E]
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     float4 ag[LNA_MAXV], ab[LNA_MAXV], ar[LNA_MAXV];      // sums of dy*xhat, dy, dres
 #pragma unroll
     for (int i = 0; i < LNA_MAXV; ++i) {
         ag[i] = make_float4(0.f, 0.f, 0.f, 0.f); ab[i] = make_float4(0.f, 0.f, 0.f, 0.f); ar[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    for (int rr = wid; rr < LNA_ROWS; rr += 4) {
+    for (int rr = wid; rr < LNA_ROWS; rr += LNA_WAVES) {
         const int row = blockIdx.x * LNA_ROWS + rr;
         if (row >= rows) break;
         const float mean = mean_in[row], rstd = rstd_in[row];
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(256) void ln_bwd_affine_kernel(const float* __restr
             }
         }
     }
-    // combine the 4 waves' column sums, write this block's partial [2][E]
+    // combine the waves' column sums (fixed order), write this block's partial [3][E]
     if (wid > 0) {
 #pragma unroll
         for (int i = 0; i < LNA_MAXV; ++i) {
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(256) void ln_bwd_affine_kernel(const float* __restr
             const int c = lane * 4 + i * 256;
             if (c < E) {
                 float4 g = ag[i], b = ab[i], r = ar[i];
-                for (int w = 0; w < 3; ++w) {
+                for (int w = 0; w < LNA_WAVES - 1; ++w) {
                     const float4 g2 = *reinterpret_cast<const float4*>(red + ((size_t)w * 3 + 0) * E + c);
                     const float4 b2 = *reinterpret_cast<const float4*>(red + ((size_t)w * 3 + 1) * E + c);
                     const float4 r2 = *reinterpret_cast<const float4*>(red + ((size_t)w * 3 + 2) * E + c);
@@ -252,32 +254,42 @@ __global__ __launch_bounds__(256) void ln_bwd_affine_kernel(const float* __restr
     }
 }
 
-// out[l*out_layer + i] += sum_c partial[l*partial_layer + c*n + i]     (fixed order: deterministic)
-__global__ void colsum_reduce_kernel(const float* __restrict__ partial, int chunks, int n, float* out, size_t partial_layer,
-                                     size_t out_layer) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float* p = partial + (size_t)blockIdx.y * partial_layer;
+// out[l*out_layer + i] += sum_c partial[l*partial_layer + c*n + i].  Block = 64 columns x 4 chunk groups
+// (group g sums chunks c = g, g+4, ... in order; the 4 group sums are combined in a fixed order): deterministic.
+constexpr int CR_COLS = 64, CR_GROUPS = 4;
+__device__ __forceinline__ float colsum_groups(const float* __restrict__ p, int chunks, size_t stride, int col, int g,
+                                               float (*red)[CR_COLS]) {
     float s0 = 0.f, s1 = 0.f;
-    int c = 0;
-    for (; c + 1 < chunks; c += 2) { s0 += p[(size_t)c * n + i]; s1 += p[(size_t)(c + 1) * n + i]; }
-    if (c < chunks) s0 += p[(size_t)c * n + i];
-    out[(size_t)blockIdx.y * out_layer + i] += s0 + s1;
+    int c = g;
+    for (; c + CR_GROUPS < chunks; c += 2 * CR_GROUPS) { s0 += p[(size_t)c * stride + col]; s1 += p[(size_t)(c + CR_GROUPS) * stride + col]; }
+    if (c < chunks) s0 += p[(size_t)c * stride + col];
+    red[g][threadIdx.x & (CR_COLS - 1)] = s0 + s1;
+    __syncthreads();
+    return (red[0][threadIdx.x & (CR_COLS - 1)] + red[1][threadIdx.x & (CR_COLS - 1)]) +
+           (red[2][threadIdx.x & (CR_COLS - 1)] + red[3][threadIdx.x & (CR_COLS - 1)]);
+}
+
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ partial, int chunks, int n, float* out,
+                                                            size_t partial_layer, size_t out_layer) {
+    __shared__ float red[CR_GROUPS][CR_COLS];
+    const int i = blockIdx.x * CR_COLS + (threadIdx.x & (CR_COLS - 1)), g = threadIdx.x >> 6;
+    const int col = i < n ? i : n - 1;
+    const float s = colsum_groups(partial + (size_t)blockIdx.y * partial_layer, chunks, (size_t)n, col, g, red);
+    if (g == 0 && i < n) out[(size_t)blockIdx.y * out_layer + i] += s;
 }
 
 // partial[l][block][3][n] -> out0/out1/out2[l*out_layer + i] += sum over blocks
-__global__ void colsum_reduce3_kernel(const float* __restrict__ partial, int chunks, int n, float* o0, float* o1, float* o2,
-                                      size_t partial_layer, size_t out_layer) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 3 * n) return;
-    const int which = i / n, e = i - which * n;
-    const float* p = partial + (size_t)blockIdx.y * partial_layer;
-    float s0 = 0.f, s1 = 0.f;
-    int c = 0;
-    for (; c + 1 < chunks; c += 2) { s0 += p[(size_t)c * 3 * n + i]; s1 += p[(size_t)(c + 1) * 3 * n + i]; }
-    if (c < chunks) s0 += p[(size_t)c * 3 * n + i];
-    float* o = which == 0 ? o0 : (which == 1 ? o1 : o2);
-    o[(size_t)blockIdx.y * out_layer + e] += s0 + s1;
+__global__ __launch_bounds__(256) void colsum_reduce3_kernel(const float* __restrict__ partial, int chunks, int n, float* o0, float* o1,
+                                                             float* o2, size_t partial_layer, size_t out_layer) {
+    __shared__ float red[CR_GROUPS][CR_COLS];
+    const int i = blockIdx.x * CR_COLS + (threadIdx.x & (CR_COLS - 1)), g = threadIdx.x >> 6;
+    const int col = i < 3 * n ? i : 3 * n - 1;
+    const float s = colsum_groups(partial + (size_t)blockIdx.y * partial_layer, chunks, (size_t)3 * n, col, g, red);
+    if (g == 0 && i < 3 * n) {
+        const int which = i / n, e = i - which * n;
+        float* o = which == 0 ? o0 : (which == 1 ? o1 : o2);
+        o[(size_t)blockIdx.y * out_layer + e] += s;
+    }
 }
 
 // Adapter chain: g_down[j][e] += G_down[e][j] ; g_up[e][j] += G_up[e][j]   (G already chunk-reduced)
@@ -291,50 +303,67 @@ __global__ void chain_adapter_kernel(const float* __restrict__ Gd, const float* 
     g_up[l * param_layer + idx] += Gu[l * g_layer + idx];
 }
 
-// Compacter chain: dH -> d W_left / d W_right of both PHM layers.  One block per (layer, which of
-// the 4 small tensors); every output element is a deterministic serial sum.
+// Compacter chain: dH -> d W_left / d W_right of both PHM layers.  One block per (which of the 4 small
+// tensors, layer, PHM slice i); every output element is a deterministic sum (fixed per-thread order, then a
+// fixed-order combine of 16 partials through LDS for the two tensors that contract the long dimension).
 //   dH_down[e][j] = Gd[e][j]  (e = a*Fi+k, j = c*16+p) ; dH_up[j][e] = Gu[e][j] (j = a*16+k, e = c*Fi+p)
 __global__ __launch_bounds__(256) void chain_compacter_kernel(const float* __restrict__ Gd, const float* __restrict__ Gu,
                                                               const float* __restrict__ rule, const float* __restrict__ params,
                                                               float* grads, int E, size_t g_layer, size_t param_layer,
                                                               size_t off_dWl, size_t off_dWr, size_t off_uWl, size_t off_uWr) {
+    __shared__ float part[16][17];
     const size_t l = blockIdx.y;
     const int which = blockIdx.x;          // 0: d down.W_left, 1: d down.W_right, 2: d up.W_left, 3: d up.W_right
+    const int i = blockIdx.z;              // PHM slice
     const int Fi = E / 4;
     const float* gd = Gd + l * g_layer; const float* gu = Gu + l * g_layer;
     const float* P = params + l * param_layer; float* Gp = grads + l * param_layer;
     const float* dWl = P + off_dWl; const float* dWr = P + off_dWr; const float* uWl = P + off_uWl; const float* uWr = P + off_uWr;
-    const int n = (which == 0 || which == 3) ? 4 * Fi : 64;
-    for (int o = threadIdx.x; o < n; o += blockDim.x) {
+    const float* rl = rule + i * 16;       // rule[i][a][c]
+    if (which == 0) {            // d dWl[i][k] = sum_{a,c,p} dHd[a*Fi+k][c*16+p] rule[i][a][c] dWr[i][p]
+        for (int k = threadIdx.x; k < Fi; k += blockDim.x) {
+            float s = 0.f;
+            for (int a = 0; a < 4; ++a)
+                for (int c = 0; c < 4; ++c) {
+                    const float r = rl[a * 4 + c];
+                    const float* row = gd + (size_t)(a * Fi + k) * 64 + c * 16;
+                    for (int pp = 0; pp < 16; ++pp) s += row[pp] * r * dWr[i * 16 + pp];
+                }
+            Gp[off_dWl + (size_t)i * Fi + k] += s;
+        }
+    } else if (which == 3) {     // d uWr[i][p] = sum_{a,c,k} dHu[a*16+k][c*Fi+p] rule[i][a][c] uWl[i][k]
+        for (int pp = threadIdx.x; pp < Fi; pp += blockDim.x) {
+            float s = 0.f;
+            for (int a = 0; a < 4; ++a)
+                for (int c = 0; c < 4; ++c) {
+                    const float r = rl[a * 4 + c];
+                    const float* row = gu + (size_t)(c * Fi + pp) * 64 + a * 16;
+                    for (int k = 0; k < 16; ++k) s += row[k] * r * uWl[i * 16 + k];
+                }
+            Gp[off_uWr + (size_t)i * Fi + pp] += s;
+        }
+    } else {
+        // 16 outputs, each a contraction over (a, c) and the long index (Fi): thread = (output o, group g of the
+        // long index); which 1: d dWr[i][o] = sum dHd[a*Fi+k][c*16+o] rule dWl[i][k]
+        //                which 2: d uWl[i][o] = sum dHu[a*16+o][c*Fi+p] rule uWr[i][p]
+        const int o = threadIdx.x & 15, g = threadIdx.x >> 4;
+        const float* src = (which == 1) ? gd : gu;
+        const float* vec = (which == 1) ? dWl + (size_t)i * Fi : uWr + (size_t)i * Fi;
         float s = 0.f;
-        if (which == 0) {            // d dWl[i][k] = sum_{a,c,p} dHd[a*Fi+k][c*16+p] rule[i][a][c] dWr[i][p]
-            const int i = o / Fi, k = o - i * Fi;
-            for (int a = 0; a < 4; ++a) for (int c = 0; c < 4; ++c) {
-                const float rl = rule[i * 16 + a * 4 + c];
-                for (int p = 0; p < 16; ++p) s += gd[(size_t)(a * Fi + k) * 64 + c * 16 + p] * rl * dWr[i * 16 + p];
+        for (int a = 0; a < 4; ++a)
+            for (int c = 0; c < 4; ++c) {
+                const float r = rl[a * 4 + c];
+                for (int q = g; q < Fi; q += 16) {
+                    const size_t idx = (which == 1) ? (size_t)(a * Fi + q) * 64 + c * 16 + o : (size_t)(c * Fi + q) * 64 + a * 16 + o;
+                    s += src[idx] * r * vec[q];
+                }
             }
-            Gp[off_dWl + o] += s;
-        } else if (which == 1) {     // d dWr[i][p] = sum_{a,c,k} dHd[a*Fi+k][c*16+p] rule[i][a][c] dWl[i][k]
-            const int i = o >> 4, p = o & 15;
-            for (int a = 0; a < 4; ++a) for (int c = 0; c < 4; ++c) {
-                const float rl = rule[i * 16 + a * 4 + c];
-                for (int k = 0; k < Fi; ++k) s += gd[(size_t)(a * Fi + k) * 64 + c * 16 + p] * rl * dWl[i * Fi + k];
-            }
-            Gp[off_dWr + o] += s;
-        } else if (which == 2) {     // d uWl[i][k] = sum_{a,c,p} dHu[a*16+k][c*Fi+p] rule[i][a][c] uWr[i][p]
-            const int i = o >> 4, k = o & 15;
-            for (int a = 0; a < 4; ++a) for (int c = 0; c < 4; ++c) {
-                const float rl = rule[i * 16 + a * 4 + c];
-                for (int p = 0; p < Fi; ++p) s += gu[(size_t)(c * Fi + p) * 64 + a * 16 + k] * rl * uWr[i * Fi + p];
-            }
-            Gp[off_uWl + o] += s;
-        } else {                     // d uWr[i][p] = sum_{a,c,k} dHu[a*16+k][c*Fi+p] rule[i][a][c] uWl[i][k]
-            const int i = o / Fi, p = o - i * Fi;
-            for (int a = 0; a < 4; ++a) for (int c = 0; c < 4; ++c) {
-                const float rl = rule[i * 16 + a * 4 + c];
-                for (int k = 0; k < 16; ++k) s += gu[(size_t)(c * Fi + p) * 64 + a * 16 + k] * rl * uWl[i * 16 + k];
-            }
-            Gp[off_uWr + o] += s;
+        part[g][o] = s;
+        __syncthreads();
+        if (threadIdx.x < 16) {
+            float t = 0.f;
+            for (int gg = 0; gg < 16; ++gg) t += part[gg][threadIdx.x];
+            Gp[((which == 1) ? off_dWr : off_uWl) + (size_t)i * 16 + threadIdx.x] += t;
         }
     }
 }
@@ -366,19 +395,26 @@ int pevit_launch_tn_gemm64(const bf16* X, int ldx, const bf16* Y, int ldy, float
 int pevit_launch_ln_bwd_affine(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                                const float* dres, float* dx, bf16* dx_bf16, float* partial, int rows, int E, hipStream_t s) {
     if (E % 4 || E > 256 * LNA_MAXV) { pevit_set_error("ln_bwd_affine: unsupported width %d", E); return -1; }
-    hipLaunchKernelGGL(ln_bwd_affine_kernel, dim3(ceil_div(rows, LNA_ROWS)), dim3(256), 3 * 3 * E * sizeof(float), s, dy, x, mean,
-                       rstd, gamma, dres, dx, dx_bf16, partial, rows, E);
+    const size_t lds = (size_t)(LNA_WAVES - 1) * 3 * E * sizeof(float);      // 64.5 KiB at E = 768
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(ln_bwd_affine_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (LNA_WAVES - 1) * 3 * 256 * LNA_MAXV * (int)sizeof(float)));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(ln_bwd_affine_kernel, dim3(ceil_div(rows, LNA_ROWS)), dim3(64 * LNA_WAVES), lds, s, dy, x, mean, rstd, gamma,
+                       dres, dx, dx_bf16, partial, rows, E);
     return 0;
 }
 int pevit_launch_colsum_reduce(const float* partial, int chunks, int n, float* out, int layers, size_t partial_layer,
                                size_t out_layer, hipStream_t s) {
-    hipLaunchKernelGGL(colsum_reduce_kernel, dim3(ceil_div(n, 256), layers), dim3(256), 0, s, partial, chunks, n, out,
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3(ceil_div(n, CR_COLS), layers), dim3(256), 0, s, partial, chunks, n, out,
                        partial_layer, out_layer);
     return 0;
 }
 int pevit_launch_colsum_reduce3(const float* partial, int chunks, int n, float* o0, float* o1, float* o2, int layers,
                                 size_t partial_layer, size_t out_layer, hipStream_t s) {
-    hipLaunchKernelGGL(colsum_reduce3_kernel, dim3(ceil_div(3 * n, 256), layers), dim3(256), 0, s, partial, chunks, n, o0, o1, o2,
+    hipLaunchKernelGGL(colsum_reduce3_kernel, dim3(ceil_div(3 * n, CR_COLS), layers), dim3(256), 0, s, partial, chunks, n, o0, o1, o2,
                        partial_layer, out_layer);
     return 0;
 }
@@ -391,7 +427,7 @@ int pevit_launch_chain_adapter(const float* Gd, const float* Gu, float* g_down, 
 int pevit_launch_chain_compacter(const float* Gd, const float* Gu, const float* rule, const float* params, float* grads, int E,
                                  int layers, size_t g_layer, size_t param_layer, size_t off_dWl, size_t off_dWr, size_t off_uWl,
                                  size_t off_uWr, hipStream_t s) {
-    hipLaunchKernelGGL(chain_compacter_kernel, dim3(4, layers), dim3(256), 0, s, Gd, Gu, rule, params, grads, E, g_layer,
+    hipLaunchKernelGGL(chain_compacter_kernel, dim3(4, layers, 4), dim3(256), 0, s, Gd, Gu, rule, params, grads, E, g_layer,
                        param_layer, off_dWl, off_dWr, off_uWl, off_uWr);
     return 0;
 }
