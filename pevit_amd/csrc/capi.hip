@@ -51,6 +51,8 @@ struct LayerSaved {        // byte offsets inside the workspace, one per layer (
 
 }  // namespace
 
+static int g_side_stream = 1;     // adapter-gradient contractions on a second stream (pevit_tune "side_stream")
+
 struct pevit_ctx {
     pevit_dims d;
     int E, L, H, N, P, R, D, C, G2, Kpatch;
@@ -86,6 +88,10 @@ struct pevit_ctx {
     hipEvent_t* prof_ev = nullptr;      // 2 per launch
     double* prof_flops = nullptr;
     double* prof_bytes = nullptr;       // algorithmic operand + result bytes of each launch
+    // second stream for work that is off the backward critical path (adapter-gradient contractions); created on
+    // first use, so that contexts can still be sized on machines without a GPU
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 namespace {
@@ -262,6 +268,9 @@ extern "C" void pevit_ctx_destroy(pevit_ctx* c) {
     delete[] c->prof_ev;
     delete[] c->prof_flops;
     delete[] c->prof_bytes;
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->side) (void)hipStreamDestroy(c->side);
     delete[] c->blk;
     delete[] c->sav;
     delete c;
@@ -531,6 +540,13 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0, bool cls_
     bf16* dyb = at<bf16>(W, c->w_dyb);
     float* dxn = at<float>(W, c->w_dxn);
     bf16* dqkv = at<bf16>(W, c->w_dqkv);
+    const bool use_side = g_side_stream && site;
+    bool side_pending = false;
+    if (use_side && !c->side) {
+        HIP_OK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+        HIP_OK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    }
     for (int l = c->L - 1; l >= 0; --l) {
         const BlockArena& b = c->blk[l];
         const LayerSaved& v = c->sav[l];
@@ -587,13 +603,24 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0, bool cls_
             p.outb = at<bf16>(W, c->w_dO); p.ldob = rs;
             CHECK(gemm(c, EPI_BF16, p, s));
         }
+        // dqkv / u32 are about to be overwritten: the previous layer's gradient contraction must have read them
+        if (side_pending) { HIP_OK(hipStreamWaitEvent(s, c->ev_join, 0)); side_pending = false; }
         CHECK(pevit_launch_attn_bwd(qkv, qkv + plane, qkv + 2 * plane, at<bf16>(W, v.attn_out), E, at<bf16>(W, c->w_dO), E,
                                     at<float>(W, v.lse), dqkv, c->NQ, B, H, N, s));
         if (site) {
             CHECK(pevit_launch_lowrank_u(dqkv, c->NQ, at<bf16>(A, b.qT), at<float>(W, c->w_u32), dqkv + 3 * E, B, H, N, E, s));
+            // the token-contracted adapter gradients feed nothing before the end of the step: run them beside
+            // the QKV-backward GEMM / LayerNorm backward / next layer's MLP GEMMs on the second stream
+            hipStream_t gs = s;
+            if (use_side) {
+                HIP_OK(hipEventRecord(c->ev_fork, s));
+                HIP_OK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+                gs = c->side;
+            }
             CHECK(pevit_launch_lowrank_grad(at<bf16>(W, v.xn1), E, at<float>(W, c->w_u32), dqkv, c->NQ, at<float>(W, v.t),
                                             at<float>(W, c->w_partial + (size_t)l * c->partial_layer),
-                                            at<float>(W, c->w_dbias + (size_t)l * c->dbias_layer), chunks, B, H, N, E, s));
+                                            at<float>(W, c->w_dbias + (size_t)l * c->dbias_layer), chunks, B, H, N, E, gs));
+            if (use_side) { HIP_OK(hipEventRecord(c->ev_join, c->side)); side_pending = true; }
         }
         if (l > 0 || need_dx0) {
             GemmParams p = gp(dqkv, c->NQ, at<bf16>(A, b.wqkvT), c->NQ, E, T, E, site ? c->NQ : 3 * E);
@@ -603,6 +630,7 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0, bool cls_
                                       at<float>(A, b.ln1w), dxb, dxa, dyb, T, E, s));
         }
     }
+    if (side_pending) HIP_OK(hipStreamWaitEvent(s, c->ev_join, 0));
     // adapter gradients of all layers: reduce the partials and chain onto the reference's tensors
     if (c->d.method == PEVIT_KADAPTATION) {
         CHECK(pevit_launch_chain_kadapt(at<float>(W, c->w_partial), c->partial_layer / 4, at<float>(W, c->w_dbias),
@@ -886,6 +914,7 @@ extern "C" int pevit_tune(const char* key, int value) {
     if (key && !strcmp(key, "gemm_hoist")) return pevit_gemm_set_hoist(value);
     if (key && !strcmp(key, "gemm_ablate")) return pevit_gemm_set_ablate(value);
     if (key && !strcmp(key, "gemm_ring")) return pevit_gemm_set_ring(value);
+    if (key && !strcmp(key, "side_stream")) { const int old = g_side_stream; g_side_stream = value; return old; }
     if (key && !strcmp(key, "gemm_dephase")) return pevit_gemm_set_dephase(value);
     if (key && !strcmp(key, "attn_bwd_phase")) return pevit_attn_set_bwd_phase(value);
     pevit_set_error("tune: unknown key %s", key ? key : "(null)");
