@@ -273,9 +273,38 @@ class HipEngine:
 
     def train_step(self, images, labels, lr, momentum=0.9, weight_decay=0.0, bn_training=True, process_group=None,
                    world_size=1):
-        """One reference ``train_one`` iteration (kadaptation_clip.py:347-353).  With DP the flat
-        adapter-gradient buffer is the only thing that crosses xGMI (frozen backbone never does)."""
-        logits, loss = self.forward_backward(images, labels, bn_training)
-        scale = dp.all_reduce_flat(self.grads, process_group) if world_size > 1 else 1.0
-        self.sgd_step(lr, momentum, weight_decay, scale)
+        """One reference ``train_one`` iteration (kadaptation_clip.py:347-353).  With DP the flat gradient buffer
+        is the only thing that crosses xGMI (the frozen backbone never does), in two buckets: the head gradients
+        (available right after the head backward) are all-reduced while the tower backward runs, the adapter
+        gradients (the per-layer partials are chained onto the reference's tensors at the very end of the
+        backward) after it."""
+        if world_size <= 1:
+            logits, loss = self.forward_backward(images, labels, bn_training)
+            self.sgd_step(lr, momentum, weight_decay, 1.0)
+            return logits, loss
+        logits, loss = self.forward_backward_dp(images, labels, bn_training, process_group)
+        self.sgd_step(lr, momentum, weight_decay, 1.0 / world_size)
         return logits, loss
+
+    def forward_backward_dp(self, images, labels, bn_training=True, process_group=None):
+        """forward_backward() split at the head so that the head-gradient all-reduce overlaps the tower backward;
+        leaves the SUM over ranks in ``self.grads``.  The same three C entry points as the fused call, in the
+        same order, so a single rank reproduces forward_backward() bit for bit."""
+        import torch.distributed as dist
+        B = images.shape[0]
+        self.zero_grad()
+        feat = self.visual_forward(images, save=True)
+        _lib.check(self.lib.pevit_head_forward_backward(
+            self._ctx, _lib.stream_ptr(), _lib.ptr(feat), _lib.ptr(labels), _lib.ptr(self.running_mean),
+            _lib.ptr(self.running_var), int(bn_training), _lib.ptr(self._logits), _lib.ptr(self._loss),
+            _lib.ptr(self._dfeat(B)), B), "pevit_head_forward_backward")
+        head = dist.all_reduce(self.grads[self.n_tower:], op=dist.ReduceOp.SUM, group=process_group, async_op=True)
+        self.visual_backward(self._dfeat(B))
+        dist.all_reduce(self.grads[:self.n_tower], op=dist.ReduceOp.SUM, group=process_group)
+        head.wait()
+        return self._logits[:B], self._loss
+
+    def _dfeat(self, B):
+        if getattr(self, "_dfeat_buf", None) is None or self._dfeat_buf.shape[0] < B:
+            self._dfeat_buf = torch.empty((max(B, self.max_batch), self.arch.embed_dim), dtype=torch.float32, device=self.device)
+        return self._dfeat_buf[:B]

@@ -402,3 +402,30 @@ def test_baseline_config_per_gpu_sizes_train(arch_name, method, lora_r, B):
     assert torch.equal(l1, l2) and torch.equal(g1, eng.grads) and loss1 == float(loss2)
     losses = [float(eng.train_step(images, labels, lr=0.05, momentum=0.9, weight_decay=0.0)[1]) for _ in range(6)]
     assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < 0.7 * losses[0], losses
+
+
+def test_dp_bucketed_step_equals_fused_step_on_one_rank():
+    """The DP route (head-gradient all-reduce overlapped with the tower backward, adapter bucket after it) on a
+    one-rank RCCL group must reproduce the fused single-GPU step bit for bit; covers the code bench.py runs for
+    --gpus N > 1 (the 2-rank arithmetic is covered on CPU by tests/test_dp_gloo.py)."""
+    import os
+    import torch.distributed as dist
+    meta, t = load_golden("tiny_kadaptation")
+    images, labels = t["images"].cuda(), t["labels"].cuda()
+    eng_a, _ = make_engine(meta, t)
+    eng_b, _ = make_engine(meta, t)
+    own_group = not dist.is_initialized()
+    if own_group:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        for _ in range(2):
+            la, lossa = eng_a.train_step(images, labels, lr=0.01, momentum=0.9, weight_decay=1e-4)
+            la, lossa = la.clone(), float(lossa)
+            lb, _ = eng_b.forward_backward_dp(images, labels)
+            eng_b.sgd_step(0.01, 0.9, 1e-4, 1.0)
+            assert torch.equal(la, lb) and lossa == float(eng_b._loss)
+        assert torch.equal(eng_a.params, eng_b.params) and torch.equal(eng_a.running_mean, eng_b.running_mean)
+    finally:
+        if own_group:
+            dist.destroy_process_group()
