@@ -397,48 +397,57 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int EPI, int S>
-__global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmParams p, int ntiles) {
-    constexpr int BM = 128, BN = 128, BK = 32;
-    constexpr int ROWB = BK * 2, CH = 4, RPP = 16;      // 64-byte rows, 4 chunks, 16 rows per 1 KiB piece
-    constexpr int A_BYTES = BM * ROWB, STAGE_BYTES = (BM + BN) * ROWB;   // 8 KiB + 8 KiB
-    constexpr int G = 4;                                // LDS-DMA instructions per wave per k-tile
-    static_assert(S >= 3 && (S - 2) * G <= 63, "ring depth");
+template <int EPI, int BM, int BK, int S, int WROWS>
+__global__ __launch_bounds__(256) void gemm_ring_kernel(GemmParams p, int ntiles) {
+    constexpr int BN = 128, WCOLS = 4 / WROWS;
+    constexpr int WTM = BM / WROWS, WTN = BN / WCOLS;            // wave tile
+    constexpr int WM = WTM / 32, WN = WTN / 32;                 // 32x32 fragments per wave
+    constexpr int ROWB = BK * 2, CH = BK / 8, RPP = 1024 / ROWB;
+    constexpr int SWZ_SHIFT = (ROWB == 128) ? 1 : 2;
+    constexpr int A_BYTES = BM * ROWB, STAGE_BYTES = (BM + BN) * ROWB;
+    constexpr int PA = BM / RPP / 4, PB = BN / RPP / 4;         // 1 KiB pieces per wave
+    constexpr int G = PA + PB;                                  // LDS-DMA instructions per wave per k-tile
+    constexpr int KS = BK / 16;
+    static_assert(WTM % 32 == 0 && WTN % 32 == 0 && (BM / RPP) % 4 == 0, "tile shape");
+    static_assert(S >= 3 && (S - 2) * G <= 63 && STAGE_BYTES >= 16384, "ring depth");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wid >> 1, wn = wid & 1;
+    const int wm = wid / WCOLS, wn = wid % WCOLS;
     const int nk = (p.dbg & 1) ? 1 : p.K / BK;
 
     // ---- producer state: position of the next k-tile to request in this workgroup's stream
-    int itile = blockIdx.x, ikt = 0, islot = 0, kstart = 0;
-    const bf16* a_src[2];
-    const bf16* b_src[2];
+    int itile = blockIdx.x, ikt = 0, islot = 0;
+    const bf16* a_src[PA];
+    const bf16* b_src[PB];
     auto set_sources = [&](int tile) {
         int m0, n0;
         tile_origin<BM, BN>(p, tile, m0, n0);
-        if (p.dbg & 16) kstart = ((((n0 >> 7) + 3 * (m0 >> 7)) & 7) * nk) >> 3;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = (wid * 2 + i) * RPP + lane / CH;
-            const int chunk = (lane % CH) ^ ((row >> 2) & (CH - 1));
+        for (int i = 0; i < PA; ++i) {
+            const int row = (wid * PA + i) * RPP + lane / CH;
+            const int chunk = (lane % CH) ^ ((row >> SWZ_SHIFT) & (CH - 1));
             int ar = m0 + row; ar = ar < p.M ? ar : p.M - 1;
-            int br = n0 + row; br = br < p.Nb ? br : p.Nb - 1;
             a_src[i] = p.A + (size_t)ar * p.lda + chunk * 8;
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const int row = (wid * PB + i) * RPP + lane / CH;
+            const int chunk = (lane % CH) ^ ((row >> SWZ_SHIFT) & (CH - 1));
+            int br = n0 + row; br = br < p.Nb ? br : p.Nb - 1;
             b_src[i] = p.B + (size_t)br * p.ldb + chunk * 8;
         }
     };
     auto issue_next = [&]() {
         if (itile >= ntiles) return;
-        char* sa = smem + islot * STAGE_BYTES + (wid * 2) * 1024;
-        char* sb = sa + A_BYTES;
-        int kk = ikt + kstart; kk = kk >= nk ? kk - nk : kk;
-        const int koff = kk * BK;
+        char* sa = smem + islot * STAGE_BYTES + (wid * PA) * 1024;
+        char* sb = smem + islot * STAGE_BYTES + A_BYTES + (wid * PB) * 1024;
+        const int koff = ikt * BK;
         if (!(p.dbg & 4)) {
-            glds16(a_src[0] + koff, sa);
-            glds16(a_src[1] + koff, sa + 1024);
-            glds16(b_src[0] + koff, sb);
-            glds16(b_src[1] + koff, sb + 1024);
+#pragma unroll
+            for (int i = 0; i < PA; ++i) glds16(a_src[i] + koff, sa + i * 1024);
+#pragma unroll
+            for (int i = 0; i < PB; ++i) glds16(b_src[i] + koff, sb + i * 1024);
         }
         islot = (islot + 1 == S) ? 0 : islot + 1;
         if (++ikt == nk) {
@@ -449,14 +458,12 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmParams p, int nti
     };
 
     // ---- consumer state
-    const int frow = lane & 31, fswz = (frow >> 2) & (CH - 1), fhalf = lane >> 5;
-    int a_off[2], b_off[2];
+    const int frow = lane & 31, fswz = (frow >> SWZ_SHIFT) & (CH - 1), fhalf = lane >> 5;
+    int a_off[WM], b_off[WN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        a_off[i] = (wm * 64 + i * 32 + frow) * ROWB;
-        b_off[i] = A_BYTES + (wn * 64 + i * 32 + frow) * ROWB;
-    }
-    const int c0 = ((0 + fhalf) ^ fswz) << 4, c1 = ((2 + fhalf) ^ fswz) << 4;
+    for (int i = 0; i < WM; ++i) a_off[i] = (wm * WTM + i * 32 + frow) * ROWB;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) b_off[j] = A_BYTES + (wn * WTN + j * 32 + frow) * ROWB;
 
     set_sources(itile);
 #pragma unroll
@@ -464,11 +471,11 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmParams p, int nti
 
     int cslot = 0;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        f32x16 acc[2][2];
+        f32x16 acc[WM][WN];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < WM; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < WN; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
         for (int kt = 0; kt < nk; ++kt) {
@@ -480,25 +487,20 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmParams p, int nti
             const char* st = smem + cslot * STAGE_BYTES;
             cslot = (cslot + 1 == S) ? 0 : cslot + 1;
             if (p.dbg & 8) continue;
-            bf16x8 a0[2], b0[2], a1[2], b1[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                a0[i] = *reinterpret_cast<const bf16x8*>(st + a_off[i] + c0);
-                b0[i] = *reinterpret_cast<const bf16x8*>(st + b_off[i] + c0);
+            for (int ks = 0; ks < KS; ++ks) {
+                const int coff = (((ks * 2 + fhalf) ^ fswz) << 4);
+                bf16x8 af[WM], bfr[WN];
+#pragma unroll
+                for (int i = 0; i < WM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(st + a_off[i] + coff);
+#pragma unroll
+                for (int j = 0; j < WN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(st + b_off[j] + coff);
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
             }
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                a1[i] = *reinterpret_cast<const bf16x8*>(st + a_off[i] + c1);
-                b1[i] = *reinterpret_cast<const bf16x8*>(st + b_off[i] + c1);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b0[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
         }
         // ---- epilogue through the ring slot that was consumed last: it is not a DMA target before the
         // next iteration's barrier.  One barrier so that no wave is still reading it.
@@ -508,9 +510,9 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmParams p, int nti
         const int eslot = (cslot == 0) ? S - 1 : cslot - 1;
         float* cw = reinterpret_cast<float*>(smem + eslot * STAGE_BYTES + wid * 4096);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < WM; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < WN; ++j) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -522,8 +524,8 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmParams p, int nti
                 for (int pass = 0; pass < 2; ++pass) {
                     const int lr = pass * 16 + (lane >> 2);
                     const int lc = (lane & 3) * 8;
-                    const int row = cm0 + wm * 64 + i * 32 + lr;
-                    const int col = cn0 + wn * 64 + j * 32 + lc;
+                    const int row = cm0 + wm * WTM + i * 32 + lr;
+                    const int col = cn0 + wn * WTN + j * 32 + lc;
                     const float4 x0 = *reinterpret_cast<const float4*>(cw + lr * 32 + lc);
                     const float4 x1 = *reinterpret_cast<const float4*>(cw + lr * 32 + lc + 4);
                     if (row < p.M && col < p.N && !(p.dbg & 2)) {
@@ -537,23 +539,28 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmParams p, int nti
     }
 }
 
-int g_gemm_ring = 0;    // ring depth of gemm_ring_kernel (0: two-stage kernel everywhere; the ring measured no faster, see profiles/r01_l2_fetch_bound.md)
+// 0 (default): two-stage kernel everywhere.  1: 160x128x64 three-stage ring (108 KiB, one workgroup per CU) for
+// problems whose 128x128 tiling has more tiles than CUs while the 160-row tiling fits in one round (M = 6400,
+// N = 768: 240 tiles).  2: force that ring.  5: the 128x128x32 five-stage ring.  Both rings are bit-identical to
+// the two-stage kernel and measured SLOWER on the step's shapes (c_proj 63 vs 53 us; 6.32 vs 5.93 ms per step):
+// kept as measurement variants, see profiles/r01_l2_fetch_bound.md.
+int g_gemm_ring = 0;
 
-template <int EPI, int S>
+template <int EPI, int BM, int BK, int S, int WROWS>
 int launch_ring(const GemmParams& p, hipStream_t stream) {
-    constexpr int lds = S * 16384;
-    auto kern = gemm_ring_kernel<EPI, S>;
+    constexpr int lds = S * (BM + 128) * BK * 2;
+    auto kern = gemm_ring_kernel<EPI, BM, BK, S, WROWS>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
             hipSuccess) {
-            pevit_set_error("hipFuncSetAttribute(gemm ring epi %d S %d) failed", EPI, S);
+            pevit_set_error("hipFuncSetAttribute(gemm ring epi %d BM %d) failed", EPI, BM);
             return -1;
         }
         attr_set = true;
     }
-    const int tiles = ceil_div(p.M, 128) * ceil_div(p.N, 128);
-    const int slots = num_cus() * 2;
+    const int tiles = ceil_div(p.M, BM) * ceil_div(p.N, 128);
+    const int slots = num_cus() * ((160 * 1024) / lds);
     hipLaunchKernelGGL(kern, dim3(tiles < slots ? tiles : slots), dim3(256), lds, stream, p, tiles);
     return 0;
 }
@@ -612,11 +619,9 @@ int pick_config(const GemmParams& p) {
 template <int EPI>
 int launch_epi(const GemmParams& p, hipStream_t stream) {
     if (g_gemm_ring && g_gemm_config < 0 && p.N > 64) {
-        switch (g_gemm_ring) {
-            case 3: return launch_ring<EPI, 3>(p, stream);
-            case 4: return launch_ring<EPI, 4>(p, stream);
-            default: return launch_ring<EPI, 5>(p, stream);
-        }
+        if (g_gemm_ring == 5) return launch_ring<EPI, 128, 32, 5, 2>(p, stream);
+        const long t128 = (long)ceil_div(p.M, 128) * ceil_div(p.N, 128), t160 = (long)ceil_div(p.M, 160) * ceil_div(p.N, 128);
+        if (g_gemm_ring == 2 || (t128 > num_cus() && t160 <= num_cus())) return launch_ring<EPI, 160, 64, 3, 1>(p, stream);
     }
     switch (pick_config(p)) {
         case 0: return launch_cfg<EPI, 0>(p, stream);

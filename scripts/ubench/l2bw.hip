@@ -169,6 +169,99 @@ void run_gemm_like(const char* A, const char* B, size_t ld, int tiles_m, int til
     fflush(stdout);
 }
 
+// ---- co-resident pairing experiment: 512 workgroups (2 per CU); do two workgroups on one CU that stream the SAME A
+// panel (and different B panels) get the second copy from L1?  MODE 0: pairs by blockIdx (b, b+256 share A);
+// MODE 1: pairs by hardware CU id (s_getreg HW_ID / XCC_ID + atomics); MODE 2: no sharing (all panels distinct).
+template <int PMODE>
+__global__ __launch_bounds__(256) void pair_stream_kernel(const char* __restrict__ A, const char* __restrict__ B, size_t ld, int kbytes,
+                                                          unsigned* sink, int* cnt, int* dense, int* ncu) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int LPR = 8, DEPTH = 2, RPI = 64 / LPR, NI = 32 / RPI, SLAB = LPR * 16;
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    __shared__ int s_pair, s_slot;
+    if (threadIdx.x == 0) {
+        if (PMODE == 1) {
+            const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);      // HW_ID
+            const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);     // XCC_ID
+            const int key = (int)(((xcc & 15) << 8) | ((hw >> 8) & 0xff));                 // xcc | se,sh,cu
+            const int slot = atomicAdd(&cnt[key], 1);
+            if (slot == 0) { const int d = atomicAdd(ncu, 1); atomicExch(&dense[key], d); }
+            int d;
+            while ((d = atomicAdd(&dense[key], 0)) < 0) __builtin_amdgcn_s_sleep(1);
+            s_pair = d; s_slot = slot;
+        } else if (PMODE == 0) {
+            s_pair = blockIdx.x & 255; s_slot = blockIdx.x >> 8;
+        } else {
+            s_pair = blockIdx.x; s_slot = 0;
+        }
+    }
+    __syncthreads();
+    const int pair = s_pair, slot = s_slot;
+    // pair p -> A panel p % 50 ; B panel: (2 * (p / 50) + slot) ... distinct B panels per slot
+    const int tm = (PMODE == 2) ? (blockIdx.x % 50) : (pair % 50);
+    const int tn = (PMODE == 2) ? (blockIdx.x / 50) : (2 * (pair / 50) + (slot & 1) + 12 * (slot >> 1));
+    const char* a_src[NI];
+    const char* b_src[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int r = wid * 32 + i * RPI + lane / LPR;
+        a_src[i] = A + (size_t)(tm * 128 + r) * ld + (lane % LPR) * 16;
+        b_src[i] = B + (size_t)((tn % 24) * 128 + r) * ld + (lane % LPR) * 16;
+    }
+    int koff = 0;
+    u32x4 acc = {0, 0, 0, 0};
+    auto issue = [&](int s) {
+        char* dst = smem + ((s * 4 + wid) * 2 * NI) * 1024;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + koff),
+                                             (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[i] + koff),
+                                             (__attribute__((address_space(3))) void*)(dst + (NI + i) * 1024), 16, 0, 0);
+        }
+        koff += SLAB;
+    };
+    const int steps = kbytes / SLAB;
+    issue(0);
+    for (int s = 0; s + DEPTH <= steps; s += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            if (s + d + 1 < steps) { issue((d + 1) % DEPTH); wait_vm<2 * NI>(); } else wait_vm<0>();
+            const u32x4 v = *reinterpret_cast<const u32x4*>(smem + ((d * 4 + wid) * 2 * NI) * 1024 + lane * 16);
+            acc ^= v;
+        }
+    }
+    wait_vm<0>();
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[0] = 1;
+    if (PMODE == 1 && threadIdx.x == 0 && slot > 1) atomicAdd(&sink[1], 1u);      // CUs that got more than 2 workgroups
+}
+
+template <int PMODE>
+void run_pair(const char* A, const char* B, size_t ld, int kbytes, unsigned* sink, const char* what) {
+    int *cnt, *dense, *ncu;
+    CK(hipMalloc(&cnt, 4096 * 4)); CK(hipMalloc(&dense, 4096 * 4)); CK(hipMalloc(&ncu, 4));
+    auto kern = pair_stream_kernel<PMODE>;
+    const int lds = 64 * 1024;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float total = 0;
+    const int reps = 10;
+    for (int w = 0; w < reps + 2; ++w) {
+        CK(hipMemsetAsync(cnt, 0, 4096 * 4)); CK(hipMemsetAsync(dense, 0xff, 4096 * 4)); CK(hipMemsetAsync(ncu, 0, 4));
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(kern, dim3(512), dim3(256), lds, 0, A, B, ld, kbytes, sink, cnt, dense, ncu);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (w >= 2) total += ms;
+    }
+    int h_ncu = 0; unsigned h_sink[2] = {0, 0};
+    CK(hipMemcpy(&h_ncu, ncu, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(h_sink, sink, 8, hipMemcpyDeviceToHost));
+    const double bytes = 512.0 * 2 * 128.0 * kbytes * reps;
+    printf("  %-52s %7.1f us/launch %6.2f TB/s   (distinct CUs seen %d, extra slots %u)\n", what, total * 1e3 / reps,
+           bytes / (total * 1e-3) / 1e12, h_ncu, h_sink[1]);
+    fflush(stdout);
+}
+
 int main(int argc, char** argv) {
     const bool pmc = argc > 1;
     const int K = 3072;                       // bf16 elements per row
@@ -180,6 +273,17 @@ int main(int argc, char** argv) {
     {
         char* Bm; CK(hipMalloc(&Bm, (size_t)3072 * ld)); CK(hipMemset(Bm, 2, (size_t)3072 * ld));
         printf("GEMM-like stream, M=6400 (50 row panels), K=%d, 128x128 tiles\n", K);
+        if (argc > 1 && argv[1][0] == 'p') {     // co-resident pairing
+            CK(hipMemset(sink, 0, 4));
+            unsigned* sink2; CK(hipMalloc(&sink2, 8)); CK(hipMemset(sink2, 0, 8));
+            for (int kb : {1536, 6144}) {
+                printf(" K extent %d B\n", kb);
+                run_pair<2>(buf, Bm, ld, kb, sink2, "512 WGs, tiles in plain order (A shared by chance)");
+                run_pair<0>(buf, Bm, ld, kb, sink2, "512 WGs, blocks b and b+256 share the A panel");
+                run_pair<1>(buf, Bm, ld, kb, sink2, "512 WGs, the workgroups of one CU share the A panel");
+            }
+            return 0;
+        }
         if (argc > 1 && argv[1][0] == 'k') {     // split-K across workgroups
             run_gemm_like<8, 2, 0>(buf, Bm, ld, 50, 6, kbytes, sink, 6, "tn=6: one WG per tile");
             run_gemm_like<8, 2, 32>(buf, Bm, ld, 50, 6, kbytes, sink, 6, "tn=6: two WGs per tile (K halves), different XCDs");
