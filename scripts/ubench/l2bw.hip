@@ -262,6 +262,67 @@ void run_pair(const char* A, const char* B, size_t ld, int kbytes, unsigned* sin
     fflush(stdout);
 }
 
+// ---- 256x256 tiles: one 8-wave workgroup per CU streams a 256-row A panel and a 256-row B panel over a K range
+__global__ __launch_bounds__(512) void big_tile_stream_kernel(const char* __restrict__ A, const char* __restrict__ B, size_t ld,
+                                                              int tiles_m, int tiles_n, int ksplit, int kbytes, unsigned* sink) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int LPR = 8, RPI = 8, NI = 4, SLAB = 128;           // per wave and step: 32 rows of A and 32 rows of B
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int item = blockIdx.x, tile = item / ksplit, kpart = item - tile * ksplit;
+    const int tm = tile % tiles_m, tn = tile / tiles_m;
+    const char* a_src[NI];
+    const char* b_src[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int r = wid * 32 + i * RPI + lane / LPR;
+        a_src[i] = A + (size_t)(tm * 256 + r) * ld + (lane % LPR) * 16;
+        b_src[i] = B + (size_t)(tn * 256 + r) * ld + (lane % LPR) * 16;
+    }
+    const int kspan = kbytes / ksplit;
+    int koff = kpart * kspan;
+    u32x4 acc = {0, 0, 0, 0};
+    auto issue = [&](int s) {
+        char* dst = smem + ((s * 8 + wid) * 2 * NI) * 1024;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + koff),
+                                             (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[i] + koff),
+                                             (__attribute__((address_space(3))) void*)(dst + (NI + i) * 1024), 16, 0, 0);
+        }
+        koff += SLAB;
+    };
+    const int steps = kspan / SLAB;
+    issue(0);
+    for (int s = 0; s + 2 <= steps; s += 2) {
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            if (s + d + 1 < steps) { issue((d + 1) % 2); wait_vm<2 * NI>(); } else wait_vm<0>();
+            __builtin_amdgcn_s_barrier();
+            const u32x4 v = *reinterpret_cast<const u32x4*>(smem + ((d * 8 + wid) * 2 * NI) * 1024 + lane * 16);
+            acc ^= v;
+        }
+    }
+    wait_vm<0>();
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[0] = 1;
+}
+
+void run_big(const char* A, const char* B, size_t ld, int tiles_m, int tiles_n, int ksplit, int kbytes, unsigned* sink, const char* what) {
+    const int lds = 2 * 8 * 8 * 1024;     // 128 KiB: one workgroup per CU
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(big_tile_stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int wgs = tiles_m * tiles_n * ksplit;
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(big_tile_stream_kernel, dim3(wgs), dim3(512), lds, 0, A, B, ld, tiles_m, tiles_n, ksplit, kbytes, sink);
+    CK(hipEventRecord(e0));
+    const int reps = 10;
+    for (int w = 0; w < reps; ++w) hipLaunchKernelGGL(big_tile_stream_kernel, dim3(wgs), dim3(512), lds, 0, A, B, ld, tiles_m, tiles_n, ksplit, kbytes, sink);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double bytes = (double)tiles_m * tiles_n * 512.0 * kbytes * reps;
+    printf("  %-64s %4d WGs %7.1f us/launch %6.2f TB/s\n", what, wgs, ms * 1e3 / reps, bytes / (ms * 1e-3) / 1e12);
+    fflush(stdout);
+}
+
 int main(int argc, char** argv) {
     const bool pmc = argc > 1;
     const int K = 3072;                       // bf16 elements per row
@@ -273,6 +334,20 @@ int main(int argc, char** argv) {
     {
         char* Bm; CK(hipMalloc(&Bm, (size_t)3072 * ld)); CK(hipMemset(Bm, 2, (size_t)3072 * ld));
         printf("GEMM-like stream, M=6400 (50 row panels), K=%d, 128x128 tiles\n", K);
+        if (argc > 1 && argv[1][0] == 'b') {     // 256x256 tiles
+            run_big(buf, Bm, ld, 25, 9, 1, 1536, sink, "qkv   N=2304 K=768 : 256x256 tiles");
+            run_gemm_like<8, 2, 0>(buf, Bm, ld, 50, 18, 1536, sink, 6, "qkv   N=2304 K=768 : 128x128 tiles");
+            run_big(buf, Bm, ld, 25, 12, 1, 1536, sink, "c_fc  N=3072 K=768 : 256x256 tiles");
+            run_gemm_like<8, 2, 0>(buf, Bm, ld, 50, 24, 1536, sink, 6, "c_fc  N=3072 K=768 : 128x128 tiles");
+            run_big(buf, Bm, ld, 25, 3, 3, 6144, sink, "c_proj N=768 K=3072: 256x256 tiles, split-K 3");
+            run_big(buf, Bm, ld, 25, 3, 1, 6144, sink, "c_proj N=768 K=3072: 256x256 tiles, no split");
+            run_gemm_like<8, 2, 0>(buf, Bm, ld, 50, 6, 6144, sink, 6, "c_proj N=768 K=3072: 128x128 tiles");
+            run_big(buf, Bm, ld, 25, 3, 3, 4608, sink, "dqkv  N=768 K=2304: 256x256 tiles, split-K 3");
+            run_gemm_like<8, 2, 0>(buf, Bm, ld, 50, 6, 4608, sink, 6, "dqkv  N=768 K=2304: 128x128 tiles");
+            run_big(buf, Bm, ld, 25, 3, 3, 1536, sink, "out   N=768 K=768 : 256x256 tiles, split-K 3");
+            run_gemm_like<8, 2, 0>(buf, Bm, ld, 50, 6, 1536, sink, 6, "out   N=768 K=768 : 128x128 tiles");
+            return 0;
+        }
         if (argc > 1 && argv[1][0] == 'p') {     // co-resident pairing
             CK(hipMemset(sink, 0, 4));
             unsigned* sink2; CK(hipMalloc(&sink2, 8)); CK(hipMemset(sink2, 0, 8));
