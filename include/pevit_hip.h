@@ -145,8 +145,9 @@ int pevit_op_lowrank_u(void* stream, const void* dqkv, int ld, const void* qT, f
 int pevit_op_lowrank_grad(void* stream, const void* xn, int ldx, const float* u32, const void* dqkv, int ld,
                           const float* t, float* partial, float* dbias_partial, int B, int H, int N, int E);
 int pevit_op_lowrank_chunks(int T);
-/* tuning knobs for A/B measurements ("gemm_config": -1 = per-problem heuristic, 0..4 = force a tile shape);
- * returns the previous value, or a negative value for an unknown key */
+/* tuning knobs for A/B measurements: "gemm_config" (-1 = per-problem heuristic, 0..8 = force a tile configuration),
+ * "gemm_persistent", "gemm_hoist", "gemm_ring" (0 off, 1 auto, 2 force the 160x128x64 ring, 5 the 128x128x32 ring),
+ * "gemm_dephase", "gemm_ablate", "side_stream", "attn_bwd_phase"; returns 0, or -1 for an unknown key */
 int pevit_tune(const char* key, int value);
 
 #ifdef __cplusplus

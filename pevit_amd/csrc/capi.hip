@@ -909,14 +909,14 @@ extern "C" int pevit_op_lowrank_grad(void* stream, const void* xn, int ldx, cons
 }
 extern "C" int pevit_op_lowrank_chunks(int T) { return pevit_lowrank_chunks(T); }
 extern "C" int pevit_tune(const char* key, int value) {
-    if (key && !strcmp(key, "gemm_config")) return pevit_gemm_set_variant(value);
-    if (key && !strcmp(key, "gemm_persistent")) return pevit_gemm_set_persistent(value);
-    if (key && !strcmp(key, "gemm_hoist")) return pevit_gemm_set_hoist(value);
-    if (key && !strcmp(key, "gemm_ablate")) return pevit_gemm_set_ablate(value);
-    if (key && !strcmp(key, "gemm_ring")) return pevit_gemm_set_ring(value);
-    if (key && !strcmp(key, "side_stream")) { const int old = g_side_stream; g_side_stream = value; return old; }
-    if (key && !strcmp(key, "gemm_dephase")) return pevit_gemm_set_dephase(value);
-    if (key && !strcmp(key, "attn_bwd_phase")) return pevit_attn_set_bwd_phase(value);
+    if (key && !strcmp(key, "gemm_config")) { pevit_gemm_set_variant(value); return 0; }
+    if (key && !strcmp(key, "gemm_persistent")) { pevit_gemm_set_persistent(value); return 0; }
+    if (key && !strcmp(key, "gemm_hoist")) { pevit_gemm_set_hoist(value); return 0; }
+    if (key && !strcmp(key, "gemm_ablate")) { pevit_gemm_set_ablate(value); return 0; }
+    if (key && !strcmp(key, "gemm_ring")) { pevit_gemm_set_ring(value); return 0; }
+    if (key && !strcmp(key, "side_stream")) { g_side_stream = value; return 0; }
+    if (key && !strcmp(key, "gemm_dephase")) { pevit_gemm_set_dephase(value); return 0; }
+    if (key && !strcmp(key, "attn_bwd_phase")) { pevit_attn_set_bwd_phase(value); return 0; }
     pevit_set_error("tune: unknown key %s", key ? key : "(null)");
     return -1;
 }

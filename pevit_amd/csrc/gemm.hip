@@ -278,7 +278,8 @@ __global__ __launch_bounds__(256, MINB) void gemm_bf16_nt_kernel(GemmParams p, i
     int m0, n0;
     tile_origin<BM, BN>(p, tile, m0, n0);
     set_sources(m0, n0);
-    issue_tile(0, 0);
+    constexpr bool ONE_STAGE = (SCHED == 3);    // single LDS stage (32 KiB): no overlap inside the workgroup, 4 workgroups per CU
+    if constexpr (!ONE_STAGE) issue_tile(0, 0);
     while (true) {
         f32x16 acc[WM][WN];
 #pragma unroll
@@ -289,11 +290,18 @@ __global__ __launch_bounds__(256, MINB) void gemm_bf16_nt_kernel(GemmParams p, i
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
         for (int kt = 0; kt < nk; ++kt) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (kt + 1 < nk) issue_tile(kt + 1, (kt + 1) & 1);
-            const char* st = smem + (kt & 1) * STAGE_BYTES;
-            if constexpr (SCHED == 0) {
+            if constexpr (ONE_STAGE) {
+                __syncthreads();                       // the stage is no longer being read
+                issue_tile(kt, 0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (kt + 1 < nk) issue_tile(kt + 1, (kt + 1) & 1);
+            }
+            const char* st = smem + (ONE_STAGE ? 0 : (kt & 1)) * STAGE_BYTES;
+            if constexpr (SCHED == 0 || SCHED == 3) {
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     const int coff = (((ks * 2 + fhalf) ^ fswz) << 4);
@@ -339,9 +347,9 @@ __global__ __launch_bounds__(256, MINB) void gemm_bf16_nt_kernel(GemmParams p, i
         if (next < ntiles) {
             tile_origin<BM, BN>(p, next, m0, n0);
             set_sources(m0, n0);
-            issue_tile(0, 0);
+            if constexpr (!ONE_STAGE) issue_tile(0, 0);
         }
-        float* cw = reinterpret_cast<float*>(smem + STAGE_BYTES + wid * 4096);
+        float* cw = reinterpret_cast<float*>(smem + (ONE_STAGE ? 0 : STAGE_BYTES) + wid * 4096);
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -575,6 +583,7 @@ constexpr TileConfig kConfigs[] = {
     {128, 128, 64, 2, 1},   // 5: as 0, fragments hoisted
     {128, 128, 64, 2, 2},   // 6: as 5 + s_setprio around the MFMA block
     {64, 128, 64, 3, 1},    // 7: as 4, fragments hoisted
+    {128, 128, 64, 4, 3},   // 8: ONE 32 KiB stage, 4 workgroups / CU: overlap comes from the other workgroups only
 };
 constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
@@ -582,7 +591,8 @@ template <int EPI, int CFG>
 int launch_cfg(const GemmParams& p, hipStream_t stream) {
     constexpr TileConfig c = kConfigs[CFG];
     constexpr int stage = (c.bm + c.bn) * c.bk * 2;
-    constexpr int lds = 2 * stage > 16384 ? 2 * stage : 16384;
+    constexpr int nstage = c.sched == 3 ? 1 : 2;
+    constexpr int lds = nstage * stage > 16384 ? nstage * stage : 16384;
     auto kern = gemm_bf16_nt_kernel<EPI, c.bm, c.bn, c.bk, c.minb, c.sched>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -631,6 +641,7 @@ int launch_epi(const GemmParams& p, hipStream_t stream) {
         case 4: return launch_cfg<EPI, 4>(p, stream);
         case 5: return launch_cfg<EPI, 5>(p, stream);
         case 6: return launch_cfg<EPI, 6>(p, stream);
+        case 8: return launch_cfg<EPI, 8>(p, stream);
         default: return launch_cfg<EPI, 7>(p, stream);
     }
 }

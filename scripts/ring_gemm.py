@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Two-stage kernel vs the 160x128x64 ring on the step's shapes (ring 1 = automatic selection)."""
+"""Default tile selection vs the single-stage 4-workgroups-per-CU variant (config 8) on the step's shapes."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import bench_gemm as bg
-bg.lib.pevit_tune(b"gemm_config", -1)
-for ring in (0, 1, 0, 1):
-    bg.lib.pevit_tune(b"gemm_ring", ring)
-    print(f"==== ring {ring}")
-    bg.shapes()
+bg.lib.pevit_tune(b"gemm_ring", 0)
+for cfg in (-1, 8, -1, 8):
+    bg.lib.pevit_tune(b"gemm_config", cfg)
+    print(f"==== config {cfg}")
+    bg.shapes(big=True)
