@@ -51,7 +51,8 @@ struct LayerSaved {        // byte offsets inside the workspace, one per layer (
 
 }  // namespace
 
-static int g_side_stream = 1;     // adapter-gradient contractions on a second stream (pevit_tune "side_stream")
+static int g_side_stream = 0;     // adapter-gradient contractions on a second stream (pevit_tune "side_stream"): +0.5 % step throughput, but it
+                                  // slows the GEMMs it overlaps by 4 %, which blurs the per-kernel roofline measurement: off by default
 
 struct pevit_ctx {
     pevit_dims d;
