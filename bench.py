@@ -70,7 +70,19 @@ def cpu_baseline(seconds_budget=25.0):
     med = times[len(times) // 2]
     return {"value": bs / med, "unit": "images/sec", "cores": cores, "kind": "port",
             "sample": f"{len(times)} fine-tune steps of ViT-B/32+KAdaptation fp32 bs={bs} (BASELINE config 1), "
-                      f"median {med * 1e3:.0f} ms/step, torch {torch.__version__} CPU"}
+                      f"median {med * 1e3:.0f} ms/step, torch {torch.__version__} CPU, {cores} of {os.cpu_count()} "
+                      f"logical cores of {cpu_model()}"}
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
 
 
 def pmc_traffic(arch, method, batch):
@@ -200,6 +212,9 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "gemm_bf16_nt_kernel (all epilogues / tile shapes)",
                          "achieved": gemm_tflops, "peak": PEAK_TFLOPS_BF16, "unit": "TFLOP/s",
                          "frac": gemm_tflops / PEAK_TFLOPS_BF16, "traffic": traffic, "traffic_unit": "bytes/launch",
+                         "peak_attainable_measured": {"value": 1422.0, "unit": "TFLOP/s",
+                                                      "how": "vendor library bf16 4096^3 on this hardware, round 1 "
+                                                             "(scripts/ref_gemm_torch.py, profiles/r01_l2_fetch_bound.md)"},
                          "traffic_how": traffic_how, "algorithmic_bytes_per_launch": algo_bytes,
                          "launches_per_step": gemm_launches / prof_steps,
                          "avg_launch_us": gemm_ms * 1e3 / max(gemm_launches, 1),

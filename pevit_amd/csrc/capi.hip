@@ -801,6 +801,9 @@ extern "C" int pevit_head_forward_backward(pevit_ctx* c, void* stream, const flo
     if (B <= 0 || B > c->max_batch) { pevit_set_error("head: batch %d outside [1,%d]", B, c->max_batch); return -1; }
     if (!feat || !running_mean || !running_var || !logits) { pevit_set_error("head: null argument"); return -1; }
     if (labels && !loss) { pevit_set_error("head: labels given but loss is null"); return -1; }
+    // torch.nn.BatchNorm1d raises "Expected more than 1 value per channel when training" (the reference's train_one
+    // skips such batches, kadaptation_clip.py:341); the batch variance of one sample is 0, never a usable statistic
+    if (bn_training && B < 2) { pevit_set_error("head: BatchNorm in training mode needs more than 1 sample per batch (got %d)", B); return -1; }
     hipStream_t s = (hipStream_t)stream;
     char* W = c->ws;
     if (c->saved_batch == 0) { size_t total; layout_workspace(c, B, c->sav, &total, c); }

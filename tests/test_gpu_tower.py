@@ -429,3 +429,17 @@ def test_dp_bucketed_step_equals_fused_step_on_one_rank():
     finally:
         if own_group:
             dist.destroy_process_group()
+
+
+def test_single_sample_batches_fail_like_batchnorm():
+    """BatchNorm1d in training mode rejects a 1-sample batch in PyTorch (ValueError); the engine does the same
+    instead of normalising by a zero variance.  Evaluation mode (running statistics) accepts it."""
+    from pevit_amd import _lib
+    meta, t = load_golden("tiny_lora")
+    eng, _ = make_engine(meta, t)
+    img, lab = t["images"][:1].cuda(), t["labels"][:1].cuda()
+    with pytest.raises(_lib.PevitError, match="more than 1 sample"):
+        eng.forward_backward(img, lab, bn_training=True)
+    logits, loss = eng.forward_backward(img, lab, bn_training=False)
+    torch.cuda.synchronize()
+    assert logits.shape == (1, meta["classes"]) and torch.isfinite(logits).all() and torch.isfinite(loss).all()
