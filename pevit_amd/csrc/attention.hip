@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------
-template <int KT32>
+template <int KT32, bool ROWLDS_T>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
                                                        const bf16* __restrict__ v, const bf16* __restrict__ out,
                                                        int ldo, const bf16* __restrict__ dout, int lddo,
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
     // Small-N variant (N <= 64): the row-major operands are staged in LDS as well, so that every
     // MFMA fragment of the two passes is an LDS read (the pass loops are otherwise chains of
     // dependent global-load latencies).  Padded rows are zero.
-    constexpr bool ROWLDS = (KT32 == 2);
+    constexpr bool ROWLDS = ROWLDS_T;
     constexpr int LDR = 72;
     bf16* Qs = reinterpret_cast<bf16*>(del_s + NPAD);
     bf16* Ks = Qs + NPAD * LDR;
@@ -336,21 +336,21 @@ int launch_fwd(const bf16* q, const bf16* k, const bf16* v, bf16* out, int ldo, 
     return 0;
 }
 
-template <int KT32>
+template <int KT32, bool ROWLDS>
 int launch_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* out, int ldo, const bf16* dout, int lddo,
                const float* lse, bf16* dqkv, int ld, int B, int H, int N, hipStream_t s) {
     constexpr int NPAD = 32 * KT32;
-    const int bytes = 3 * 64 * (NPAD + 4) * 2 + 2 * NPAD * 4 + (KT32 == 2 ? 4 * NPAD * 72 * 2 : 0);
+    const int bytes = 3 * 64 * (NPAD + 4) * 2 + 2 * NPAD * 4 + (ROWLDS ? 4 * NPAD * 72 * 2 : 0);
     static bool attr = false;
     if (!attr && bytes > 48 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<KT32>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<KT32, ROWLDS>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
             pevit_set_error("attn_bwd: cannot reserve %d bytes of LDS", bytes); return -1;
         }
         attr = true;
     }
-    hipLaunchKernelGGL(attn_bwd_kernel<KT32>, dim3(B * H), dim3(256), bytes, s, q, k, v, out, ldo, dout, lddo, lse,
-                       dqkv, ld, H, N, g_attn_bwd_phase);
+    hipLaunchKernelGGL((attn_bwd_kernel<KT32, ROWLDS>), dim3(B * H), dim3(256), bytes, s, q, k, v, out, ldo, dout, lddo, lse,
+                       dqkv, ld, H, N, g_attn_bwd_phase & 3);
     return 0;
 }
 
@@ -371,7 +371,9 @@ int pevit_launch_attn_bwd(const bf16* q, const bf16* k, const bf16* v, const bf1
                           int lddo, const float* lse, bf16* dqkv, int ld, int B, int H, int N, hipStream_t s) {
     if (N < 1 || N > 288) { pevit_set_error("attn_bwd: tokens per image N=%d outside [1,288]", N); return -1; }
     if ((ldo % 8) || (lddo % 8) || (ld % 8)) { pevit_set_error("attn_bwd: leading dims must be multiples of 8"); return -1; }
-    if (N <= 64) return launch_bwd<2>(q, k, v, out, ldo, dout, lddo, lse, dqkv, ld, B, H, N, s);
-    if (N <= 224) return launch_bwd<7>(q, k, v, out, ldo, dout, lddo, lse, dqkv, ld, B, H, N, s);
-    return launch_bwd<9>(q, k, v, out, ldo, dout, lddo, lse, dqkv, ld, B, H, N, s);
+    // N <= 64: row-major copies in LDS as well (g_attn_bwd_phase bit 2 turns them off for A/B measurements)
+    if (N <= 64 && !(g_attn_bwd_phase & 4)) return launch_bwd<2, true>(q, k, v, out, ldo, dout, lddo, lse, dqkv, ld, B, H, N, s);
+    if (N <= 64) return launch_bwd<2, false>(q, k, v, out, ldo, dout, lddo, lse, dqkv, ld, B, H, N, s);
+    if (N <= 224) return launch_bwd<7, false>(q, k, v, out, ldo, dout, lddo, lse, dqkv, ld, B, H, N, s);
+    return launch_bwd<9, false>(q, k, v, out, ldo, dout, lddo, lse, dqkv, ld, B, H, N, s);
 }

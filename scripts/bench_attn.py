@@ -24,3 +24,7 @@ print(f"attn fwd {timeit(fwd):.1f} us")
 for ph in (1, 2, 3):
     lib.pevit_tune(b"attn_bwd_phase", ph)
     print(f"attn bwd phase<={ph}: {timeit(bwd):.1f} us")
+for ph in (5, 6, 7):
+    lib.pevit_tune(b"attn_bwd_phase", ph)
+    print(f"attn bwd without row-major LDS copies, phase<={ph & 3}: {timeit(bwd):.1f} us")
+lib.pevit_tune(b"attn_bwd_phase", 3)
