@@ -194,6 +194,11 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int row, int
     }
 }
 
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 // tile coordinates of this workgroup.  Order: XCD-contiguous (xcd_remap), and inside that a band
 // of TILE_BAND m-tiles is walked n-major, so the tiles an XCD has in flight share TILE_BAND
 // A-panels and only a few B-panels (a 128x768 bf16 panel is 192 KiB; the XCD's L2 is 4 MiB).
@@ -289,6 +294,49 @@ __global__ __launch_bounds__(256, MINB) void gemm_bf16_nt_kernel(GemmParams p, i
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+        if constexpr (SCHED == 4) {
+            // Register-resident schedule (the 128x128 edition of gemm256_kernel): all fragments of a k-tile are
+            // pulled into registers, the stage is released with a barrier and immediately re-targeted by the
+            // LDS-DMA of k-tile kt+2, so two k-tiles are in flight while k-tile kt is multiplied.
+            constexpr int G = PA + PB;
+            __syncthreads();                            // previous epilogue no longer uses stage 1 as scratch
+            if (nk > 1) issue_tile(1, 1);
+            if (nk > 1) wait_vmcnt<G>(); else wait_vmcnt<0>();      // k-tile 0 (and, in order, the epilogue's stores)
+            __builtin_amdgcn_s_barrier();
+            for (int kt = 0; kt < nk; ++kt) {
+                const char* st = smem + (kt & 1) * STAGE_BYTES;
+                bf16x8 af[KS][WM], bfr[KS][WN];
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int coff = (((ks * 2 + fhalf) ^ fswz) << 4);
+#pragma unroll
+                    for (int i = 0; i < WM; ++i) af[ks][i] = *reinterpret_cast<const bf16x8*>(st + a_off[i] + coff);
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) bfr[ks][j] = *reinterpret_cast<const bf16x8*>(st + b_off[j] + coff);
+                }
+#pragma unroll
+                for (int ks = 0; ks < KS / 2; ++ks)
+#pragma unroll
+                    for (int i = 0; i < WM; ++i)
+#pragma unroll
+                        for (int j = 0; j < WN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();           // nobody reads this stage any more
+                if (kt + 2 < nk) issue_tile(kt + 2, kt & 1);
+#pragma unroll
+                for (int ks = KS / 2; ks < KS; ++ks)
+#pragma unroll
+                    for (int i = 0; i < WM; ++i)
+#pragma unroll
+                        for (int j = 0; j < WN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+                if (kt + 1 < nk) {
+                    if (kt + 2 < nk) wait_vmcnt<G>(); else wait_vmcnt<0>();
+                    __builtin_amdgcn_s_barrier();
+                }
+            }
+        } else
         for (int kt = 0; kt < nk; ++kt) {
             if constexpr (ONE_STAGE) {
                 __syncthreads();                       // the stage is no longer being read
@@ -400,10 +448,6 @@ __global__ __launch_bounds__(256, MINB) void gemm_bf16_nt_kernel(GemmParams p, i
 //   vmcnt decrements in issue order on gfx9-family parts (loads, LDS-DMA and stores share the counter),
 //        so "at most N outstanding" means "all but the youngest N completed": the epilogue's global
 //        loads / stores sit between DMA groups in that order and only make the waits conservative.
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
 
 template <int EPI, int BM, int BK, int S, int WROWS>
 __global__ __launch_bounds__(256) void gemm_ring_kernel(GemmParams p, int ntiles) {
@@ -573,6 +617,163 @@ int launch_ring(const GemmParams& p, hipStream_t stream) {
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// 256x256x64 form for problems that tile into at most ~one workgroup per CU (QKV at B=128: 25 x 10 tiles).
+// Half the operand bytes per flop of the 128x128 kernel, which is what the L2 -> LDS stream bounds
+// (profiles/r01_l2_fetch_bound.md).  One 512-thread workgroup per CU, waves 2 (M) x 4 (N), wave tile 128 x 64
+// = 4 x 2 fragments of 32x32 (128 accumulator registers).  The operands of a whole k-tile are pulled from LDS
+// into registers (16 A + 8 B fragments = 96 registers) and the MFMAs run from registers, so an LDS buffer is
+// free again as soon as every wave has read it: with only two 64 KiB buffers TWO k-tiles of LDS-DMA stay in
+// flight (k-tile t+1 landing, t+2 just requested) while k-tile t is being multiplied, with a counted vmcnt:
+//     read k-tile t -> lgkmcnt(0), barrier -> request k-tile t+2 into the buffer just read -> MFMAs of t
+//     -> vmcnt(8) (k-tile t+1 landed, t+2 may fly) -> barrier
+// LDS image per buffer: A rows 0..255 then B rows 0..255, 128-byte rows, same source-side XOR swizzle as above.
+template <int EPI>
+__global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmParams p, int ntiles) {
+    constexpr int BM = 256, BN = 256, BK = 64, ROWB = 128, CH = 8;
+    constexpr int BUF_BYTES = (BM + BN) * ROWB;                 // 64 KiB
+    constexpr int G = 8;                                        // LDS-DMA instructions per wave per k-tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wid >> 2, wn = wid & 3;
+    const int nk = (p.dbg & 1) ? 0 : p.K / BK;
+    const int frow = lane & 31, fswz = (frow >> 1) & (CH - 1), fhalf = lane >> 5;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int m0, n0;
+        tile_origin<BM, BN>(p, tile, m0, n0);
+        // a 64 KiB buffer is 64 pieces of 1 KiB (8 rows x 128 B); wave w loads pieces w, w+8, ... (4 of A, 4 of B)
+        const bf16* src[G];
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int piece = wid + 8 * i;                      // 0..31 A, 32..63 B
+            const int row = (piece & 31) * 8 + (lane >> 3);     // row inside the 256-row panel
+            const int chunk = (lane & 7) ^ ((row >> 1) & (CH - 1));
+            if (piece < 32) {
+                int ar = m0 + row; ar = ar < p.M ? ar : p.M - 1;
+                src[i] = p.A + (size_t)ar * p.lda + chunk * 8;
+            } else {
+                int br = n0 + row; br = br < p.Nb ? br : p.Nb - 1;
+                src[i] = p.B + (size_t)br * p.ldb + chunk * 8;
+            }
+        }
+        auto issue_tile = [&](int kt, int buf) {
+            char* base = smem + buf * BUF_BYTES;
+            const int koff = kt * BK;
+#pragma unroll
+            for (int i = 0; i < G; ++i) glds16(src[i] + koff, base + (wid + 8 * i) * 1024);
+        };
+        int a_off[4], b_off[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a_off[i] = (wm * 128 + i * 32 + frow) * ROWB;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b_off[j] = BM * ROWB + (wn * 64 + j * 32 + frow) * ROWB;
+
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+        if (nk > 0) issue_tile(0, 0);
+        if (nk > 1) { issue_tile(1, 1); wait_vmcnt<G>(); } else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        for (int kt = 0; kt < nk; ++kt) {
+            const char* st = smem + (kt & 1) * BUF_BYTES;
+            bf16x8 af[4][4], bfr[4][2];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int coff = (((ks * 2 + fhalf) ^ fswz) << 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[ks][i] = *reinterpret_cast<const bf16x8*>(st + a_off[i] + coff);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bfr[ks][j] = *reinterpret_cast<const bf16x8*>(st + b_off[j] + coff);
+            }
+            // first half of the products while the second half of the fragments is still arriving
+            if (p.dbg & 32) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+            if (p.dbg & 32) __builtin_amdgcn_s_setprio(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                       // nobody reads this buffer any more
+            if (kt + 2 < nk) issue_tile(kt + 2, kt & 1);
+            if (p.dbg & 32) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 2; ks < 4; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+            if (p.dbg & 32) __builtin_amdgcn_s_setprio(0);
+            if (kt + 1 < nk) {
+                if (kt + 2 < nk) wait_vmcnt<G>(); else wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();                   // k-tile kt+1 has landed for every wave
+            }
+        }
+        // ---- epilogue: both buffers are idle (the last k-tile was read, nothing is in flight)
+        __builtin_amdgcn_s_barrier();
+        float* cw = reinterpret_cast<float*>(smem + wid * 4096);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    cw[row * 32 + (lane & 31)] = acc[i][j][r];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int pass = 0; pass < 2; ++pass) {
+                    const int lr = pass * 16 + (lane >> 2);
+                    const int lc = (lane & 3) * 8;
+                    const int row = m0 + wm * 128 + i * 32 + lr;
+                    const int col = n0 + wn * 64 + j * 32 + lc;
+                    const float4 x0 = *reinterpret_cast<const float4*>(cw + lr * 32 + lc);
+                    const float4 x1 = *reinterpret_cast<const float4*>(cw + lr * 32 + lc + 4);
+                    if (row < p.M && col < p.N && !(p.dbg & 2)) {
+                        float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                        epilogue_store<EPI>(p, row, col, v);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        __builtin_amdgcn_s_barrier();                           // scratch is about to become a DMA target again
+    }
+}
+
+int g_gemm_256 = 0;     // 0: never, 1: when the 256x256 tiling has at most one tile per CU and more than half of them, 2: always
+
+template <int EPI>
+int launch_256(const GemmParams& p, hipStream_t stream) {
+    constexpr int lds = 2 * 512 * 128;
+    auto kern = gemm256_kernel<EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
+            hipSuccess) {
+            pevit_set_error("hipFuncSetAttribute(gemm256 epi %d) failed", EPI);
+            return -1;
+        }
+        attr_set = true;
+    }
+    const int tiles = ceil_div(p.M, 256) * ceil_div(p.N, 256);
+    const int slots = num_cus();
+    hipLaunchKernelGGL(kern, dim3(tiles < slots ? tiles : slots), dim3(512), lds, stream, p, tiles);
+    return 0;
+}
+
 struct TileConfig { int bm, bn, bk, minb, sched; };
 constexpr TileConfig kConfigs[] = {
     {128, 128, 64, 2, 0},   // 0: 64 KiB LDS, 2 workgroups / CU
@@ -584,6 +785,7 @@ constexpr TileConfig kConfigs[] = {
     {128, 128, 64, 2, 2},   // 6: as 5 + s_setprio around the MFMA block
     {64, 128, 64, 3, 1},    // 7: as 4, fragments hoisted
     {128, 128, 64, 4, 3},   // 8: ONE 32 KiB stage, 4 workgroups / CU: overlap comes from the other workgroups only
+    {128, 128, 64, 2, 4},   // 9: register-resident k-tile, two k-tiles of LDS-DMA in flight per workgroup
 };
 constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
@@ -628,6 +830,10 @@ int pick_config(const GemmParams& p) {
 
 template <int EPI>
 int launch_epi(const GemmParams& p, hipStream_t stream) {
+    if (g_gemm_256 && g_gemm_config < 0 && p.N > 64) {
+        const long t256 = (long)ceil_div(p.M, 256) * ceil_div(p.N, 256);
+        if (g_gemm_256 == 2 || (t256 <= num_cus() && 2 * t256 > num_cus())) return launch_256<EPI>(p, stream);
+    }
     if (g_gemm_ring && g_gemm_config < 0 && p.N > 64) {
         if (g_gemm_ring == 5) return launch_ring<EPI, 128, 32, 5, 2>(p, stream);
         const long t128 = (long)ceil_div(p.M, 128) * ceil_div(p.N, 128), t160 = (long)ceil_div(p.M, 160) * ceil_div(p.N, 128);
@@ -642,6 +848,7 @@ int launch_epi(const GemmParams& p, hipStream_t stream) {
         case 5: return launch_cfg<EPI, 5>(p, stream);
         case 6: return launch_cfg<EPI, 6>(p, stream);
         case 8: return launch_cfg<EPI, 8>(p, stream);
+        case 9: return launch_cfg<EPI, 9>(p, stream);
         default: return launch_cfg<EPI, 7>(p, stream);
     }
 }
@@ -652,6 +859,7 @@ int pevit_gemm_set_variant(int v) { const int old = g_gemm_config; g_gemm_config
 int pevit_gemm_set_hoist(int v) { const int old = g_gemm_hoist; g_gemm_hoist = v; return old; }
 int pevit_gemm_set_ablate(int v) { const int old = g_gemm_ablate; g_gemm_ablate = v; return old; }
 int pevit_gemm_set_dephase(int v) { const int old = g_gemm_dephase; g_gemm_dephase = v; return old; }
+int pevit_gemm_set_256(int v) { const int old = g_gemm_256; g_gemm_256 = v; return old; }
 int pevit_gemm_set_ring(int v) { const int old = g_gemm_ring; g_gemm_ring = v; return old; }
 int pevit_gemm_set_persistent(int v) { const int old = g_gemm_persistent; g_gemm_persistent = v; return old; }
 
