@@ -260,10 +260,22 @@ def main():
     ap.add_argument("--full", action="store_true", help="also run the full-size ViT-B/32 bs=8 cases")
     ap.add_argument("--counts", action="store_true", help="also regenerate the parameter-count table")
     ap.add_argument("--text-only", action="store_true", help="only (re)generate tiny_text.npz")
+    ap.add_argument("--other-archs", action="store_true",
+                    help="only generate the full-size summaries for the ViT-B/16 and ViT-L/14 configurations of BASELINE.json")
     args = ap.parse_args()
     if args.text_only:
         np.savez_compressed(os.path.join(HERE, "tiny_text.npz"), **text_case())
         print("tiny_text written")
+        return
+    if args.other_archs:
+        for method, arch_name, tag, lora_r in (("compacter", "ViT-B/16", "full_b16_compacter", 4),
+                                                ("kadaptation", "ViT-L/14", "full_l14_kadaptation", 4),
+                                                ("lora", "ViT-B/32", "full_b32_lora_r8", 8)):
+            meta, tensors = run_case(method, arch_name, batch=8, classes=100, lora_r=lora_r, steps=1, store_tensors=False)
+            np.savez_compressed(os.path.join(HERE, f"{tag}.npz"), **tensors)
+            with open(os.path.join(HERE, f"{tag}.json"), "w") as f:
+                json.dump(meta, f, indent=1)
+            print(tag, "ok; loss", meta["losses"])
         return
     torch.manual_seed(0)
     torch.set_num_threads(8)

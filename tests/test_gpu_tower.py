@@ -219,32 +219,43 @@ def test_reference_init_gives_bias_only_gradients():
             assert nz, name
 
 
-def test_full_size_vit_b32_bs8_matches_reference_fixture():
-    """ViT-B/32 + KAdaptation at the real width/depth, bs=8: logits, loss and per-tensor
-    gradient norms recorded from the reference (fixture holds summaries only)."""
+@pytest.mark.parametrize("case", ["full_b32_kadaptation", "full_b32_lora", "full_b32_adapter", "full_b32_compacter",
+                                  "full_b32_lora_r8", "full_b16_compacter"])
+def test_full_size_bs8_matches_reference_fixture(case):
+    """Real width/depth (ViT-B/32 all four methods, LoRA r=8, ViT-B/16 + Compacter), bs=8: logits, loss and
+    per-tensor gradient norms recorded from the reference itself (fixtures hold summaries only; the 88M-parameter
+    checkpoint is regenerated from its seed).  The 24-layer ViT-L/14 fixture (full_l14_kadaptation) pins the ORACLE
+    on CPU (tests/test_oracle_golden.py); on this random-weight 24-layer network bf16 operand rounding alone moves
+    the logits by ~13 % (emulated), so the engine is held to the live oracle with the emulation-calibrated gate
+    instead (test_baseline_config_architectures_vs_oracle)."""
+    import math
     from pevit_amd.engine import HipEngine, adapter_param_spec
     from pevit_amd.synth import ARCHS, randomize_adapters, synth_batch, synth_state_dict
-    meta, t = load_golden("full_b32_kadaptation")
-    arch = ARCHS["ViT-B/32"]
+    meta, t = load_golden(case)
+    arch, method = ARCHS[meta["arch"]], meta["method"]
     sd = synth_state_dict(arch, seed=2, text_tower=False)
-    spec = {n: s for n, s, _ in adapter_param_spec("kadaptation", 768, 12)}
+    spec = {n: s for n, s, _ in adapter_param_spec(method, arch.width, arch.layers, meta["lora_r"])}
     ordered = [(n, torch.zeros(spec[n])) for n in meta["trainable_names"]]
     randomize_adapters(ordered, seed=3)
     sd.update(dict(ordered))
-    eng = HipEngine(arch, "kadaptation", meta["classes"], meta["batch"])
+    for k, v in t.items():                       # tensors the reference adds but never trains (Compacter's phm_rule)
+        if k.startswith("adapter/"):
+            sd[k[len("adapter/"):]] = v.float()
+    eng = HipEngine(arch, method, meta["classes"], meta["batch"], lora_rank=meta["lora_r"])
     eng.load_state_dict(sd)
-    import math
     g = torch.Generator().manual_seed(5)
     bound = 1.0 / math.sqrt(arch.embed_dim)
     views = eng.param_views()
     with torch.no_grad():
         views["layers.0.weight"].copy_((torch.rand((meta["classes"], arch.embed_dim), generator=g) * 2 - 1) * bound)
         views["layers.0.bias"].copy_((torch.rand((meta["classes"],), generator=g) * 2 - 1) * bound)
-    images, labels = synth_batch(meta["batch"], 224, meta["classes"])
+    images, labels = synth_batch(meta["batch"], arch.resolution, meta["classes"])
     logits, loss = eng.forward_backward(images.cuda(), labels.cuda())
     torch.cuda.synchronize()
-    assert max_rel(logits.cpu(), t["logits0"]) < DEEP_LOGIT_TOL
-    assert abs(float(loss) - float(t["loss0"])) < LOSS_TOL
+    deep = 1.0
+    assert max_rel(logits.cpu(), t["logits0"]) < DEEP_LOGIT_TOL * deep
+    assert abs(float(loss) - float(t["loss0"])) < LOSS_TOL * deep
+    bad = []
     for name, gten in eng.grad_views().items():
         key = name if name.startswith("layers.") else "backbone." + name
         ref = meta["grad_norms"][key]
@@ -252,7 +263,9 @@ def test_full_size_vit_b32_bs8_matches_reference_fixture():
             assert float(gten.abs().max()) == 0.0
         else:
             got = float(gten.double().norm())
-            assert abs(got - ref) <= DEEP_GRAD_TOL * max(ref, 1e-8), (name, got, ref)
+            if abs(got - ref) > DEEP_GRAD_TOL * deep * max(ref, 1e-8):
+                bad.append((name, got, ref))
+    assert not bad, bad[:5]
 
 
 def test_bs128_properties_full_size():

@@ -124,22 +124,25 @@ def test_rank_r_identity():
     assert max_rel(P @ Q.T, H) < 1e-5
 
 
-FULL = ["full_b32_kadaptation", "full_b32_lora", "full_b32_adapter", "full_b32_compacter"]
+FULL = ["full_b32_kadaptation", "full_b32_lora", "full_b32_adapter", "full_b32_compacter",
+        # the architectures of BASELINE configs 3-5 (LoRA r=8; ViT-B/16 + Compacter; ViT-L/14 + KAdaptation)
+        "full_b32_lora_r8", "full_b16_compacter", "full_l14_kadaptation"]
 
 
 @pytest.mark.parametrize("case", FULL)
-def test_full_size_vit_b32_matches_reference(case):
-    """ViT-B/32, bs=8, C=100: logits / loss / per-tensor gradient norms recorded from the
-    reference.  The 88M-parameter state-dict is regenerated from its seed (checksummed)."""
+def test_full_size_vit_matches_reference(case):
+    """Full width / depth, bs=8, C=100: logits / loss / per-tensor gradient norms recorded from the
+    reference.  The 88-304M-parameter state-dict is regenerated from its seed (checksummed)."""
     from pevit_amd.synth import ARCHS, randomize_adapters, synth_batch, synth_state_dict
     meta, t = load_golden(case)
     method = meta["method"]
-    sd = synth_state_dict(ARCHS["ViT-B/32"], seed=2, text_tower=False)
+    arch = ARCHS[meta["arch"]]
+    sd = synth_state_dict(arch, seed=2, text_tower=False)
     for k, (s1, s2) in meta["sd_checksum"].items():
         assert abs(float(sd[k].double().sum()) - s1) <= 1e-6 * max(1.0, abs(s1)), "generator drift: " + k
         assert abs(float((sd[k].double() ** 2).sum()) - s2) <= 1e-6 * max(1.0, abs(s2)), "generator drift: " + k
     p = {k: v for k, v in sd.items() if k.startswith("visual.")}
-    shapes = ref_cpu.adapter_param_shapes(method, 768, 12, meta["lora_r"])
+    shapes = ref_cpu.adapter_param_shapes(method, arch.width, arch.layers, meta["lora_r"])
     ordered = [(n, torch.zeros(shapes[n])) for n in meta["trainable_names"]]
     randomize_adapters(ordered, seed=3)
     p.update(dict(ordered))
@@ -147,7 +150,7 @@ def test_full_size_vit_b32_matches_reference(case):
         if k.startswith("adapter/"):
             p[k[len("adapter/"):]] = v.float()
     tr = ref_cpu.OracleTrainer(p, method, meta["classes"], lr=meta["lr"], wd=meta["wd"])
-    images, labels = synth_batch(meta["batch"], 224, meta["classes"])
+    images, labels = synth_batch(meta["batch"], arch.resolution, meta["classes"])
     logits, loss = tr.loss_and_grads(images, labels)
     assert max_rel(logits, t["logits0"]) < 1e-4
     assert abs(float(loss) - float(t["loss0"])) < 1e-4
