@@ -112,8 +112,9 @@ int pevit_head_forward_backward(pevit_ctx* ctx, void* stream, const float* feat,
                                 float* running_mean, float* running_var, int bn_training, float* logits,
                                 float* loss, float* dfeat_or_null, int batch);
 int pevit_zero_grads(pevit_ctx* ctx, void* stream);
+/* flags: bit 0 = first step of the run (momentum buffer := gradient, like torch), bit 1 = Nesterov momentum */
 int pevit_sgd_step(pevit_ctx* ctx, void* stream, float lr, float momentum, float weight_decay,
-                   float grad_scale, int first_step);
+                   float grad_scale, int flags);
 /* whole fine-tune step: zero_grad -> forward -> CE -> backward -> (caller all-reduces) -> SGD */
 int pevit_train_forward_backward(pevit_ctx* ctx, void* stream, const float* images, const int64_t* labels,
                                  float* running_mean, float* running_var, int bn_training, float* logits,

@@ -697,9 +697,9 @@ extern "C" int pevit_zero_grads(pevit_ctx* c, void* stream) {
 }
 
 extern "C" int pevit_sgd_step(pevit_ctx* c, void* stream, float lr, float momentum, float wd, float grad_scale,
-                              int first_step) {
+                              int flags) {
     if (!c || !c->params || !c->grads || !c->mom) { pevit_set_error("sgd_step: parameters/momentum not set"); return -1; }
-    return pevit_launch_sgd(c->params, c->grads, c->mom, c->grad_mask, c->n_total, lr, momentum, wd, first_step,
+    return pevit_launch_sgd(c->params, c->grads, c->mom, c->grad_mask, c->n_total, lr, momentum, wd, flags,
                             grad_scale, (hipStream_t)stream);
 }
 

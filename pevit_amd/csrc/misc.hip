@@ -55,14 +55,15 @@ __global__ void scale_f32_kernel(float* p, size_t n, float scale) {
 
 __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ mom,
                            const unsigned char* __restrict__ has_grad, size_t n, float lr, float momentum, float wd,
-                           int first_step, float grad_scale) {
+                           int flags, float grad_scale) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     if (has_grad && !has_grad[i]) return;       // torch skips parameters whose .grad is None
+    const bool first_step = flags & 1, nesterov = flags & 2;
     float d = g[i] * grad_scale + wd * p[i];
     const float buf = first_step ? d : momentum * mom[i] + d;
     mom[i] = buf;
-    p[i] -= lr * buf;
+    p[i] -= lr * (nesterov ? d + momentum * buf : buf);      // torch.optim.SGD: grad.add(buf, alpha=momentum)
 }
 
 }  // namespace

@@ -55,7 +55,7 @@ def average_bn_buffers(running_mean: torch.Tensor, running_var: torch.Tensor, gr
             t.div_(world)
 
 
-def sgd_momentum_(params, grads, momentum_buf, mask, lr, momentum, weight_decay, grad_scale, first_step):
+def sgd_momentum_(params, grads, momentum_buf, mask, lr, momentum, weight_decay, grad_scale, first_step, nesterov=False):
     """Host statement of the fused SGD kernel (misc.hip: sgd_kernel) on flat tensors; used by the
     CPU tests of the DP path.  Mirrors torch.optim.SGD(momentum, nesterov=False), skipping
     parameters that never receive a gradient."""
@@ -63,4 +63,5 @@ def sgd_momentum_(params, grads, momentum_buf, mask, lr, momentum, weight_decay,
     buf = d if first_step else momentum * momentum_buf + d
     sel = mask.bool() if mask is not None else torch.ones_like(params, dtype=torch.bool)
     momentum_buf[sel] = buf[sel]
-    params[sel] -= lr * buf[sel]
+    upd = d + momentum * buf if nesterov else buf
+    params[sel] -= lr * upd[sel]

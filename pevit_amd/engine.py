@@ -244,9 +244,10 @@ class HipEngine:
             "pevit_train_forward_backward")
         return self._logits[:B], self._loss
 
-    def sgd_step(self, lr, momentum=0.9, weight_decay=0.0, grad_scale=1.0):
-        _lib.check(self.lib.pevit_sgd_step(self._ctx, _lib.stream_ptr(), lr, momentum, weight_decay, grad_scale,
-                                           int(self._steps == 0)), "pevit_sgd_step")
+    def sgd_step(self, lr, momentum=0.9, weight_decay=0.0, grad_scale=1.0, nesterov=False):
+        flags = int(self._steps == 0) | (2 if nesterov else 0)
+        _lib.check(self.lib.pevit_sgd_step(self._ctx, _lib.stream_ptr(), lr, momentum, weight_decay, grad_scale, flags),
+                   "pevit_sgd_step")
         self._steps += 1
 
     def profile_gemms(self, fn, max_launches=4096):
@@ -272,7 +273,7 @@ class HipEngine:
         self.running_mean.zero_(); self.running_var.fill_(1.0)
 
     def train_step(self, images, labels, lr, momentum=0.9, weight_decay=0.0, bn_training=True, process_group=None,
-                   world_size=1):
+                   world_size=1, nesterov=False):
         """One reference ``train_one`` iteration (kadaptation_clip.py:347-353).  With DP the flat gradient buffer
         is the only thing that crosses xGMI (the frozen backbone never does), in two buckets: the head gradients
         (available right after the head backward) are all-reduced while the tower backward runs, the adapter
@@ -280,10 +281,10 @@ class HipEngine:
         backward) after it."""
         if world_size <= 1:
             logits, loss = self.forward_backward(images, labels, bn_training)
-            self.sgd_step(lr, momentum, weight_decay, 1.0)
+            self.sgd_step(lr, momentum, weight_decay, 1.0, nesterov)
             return logits, loss
         logits, loss = self.forward_backward_dp(images, labels, bn_training, process_group)
-        self.sgd_step(lr, momentum, weight_decay, 1.0 / world_size)
+        self.sgd_step(lr, momentum, weight_decay, 1.0 / world_size, nesterov)
         return logits, loss
 
     def forward_backward_dp(self, images, labels, bn_training=True, process_group=None):

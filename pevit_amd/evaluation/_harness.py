@@ -11,7 +11,8 @@ adapter_tuning_clip / compacter_clip), which in the reference are four near-iden
 * ``train_task`` return contract: best score for sweep runs, ``(best, model_info)`` otherwise (:257-317).
 
 What differs is where the work runs: one ``train_one`` iteration is a single fused call into the HIP engine
-(forward, loss, backward, SGD) whenever the configuration is the plain one of the reference's yaml files, and
+(forward, loss, backward, SGD with or without Nesterov momentum) whenever the optimizer is SGD with one weight
+decay for every trainable tensor, and
 an autograd step over the engine's forward/backward otherwise.  Per-step ``loss.item()`` is replaced by one
 read-back per epoch.  Consecutive ``train_task`` calls (the ~90 runs of a sweep) re-use the resident frozen
 backbone.
@@ -174,9 +175,10 @@ class ClassifierBase(nn.Module):
             return False
         g0 = live[0]
         for g in live:
-            if g["nesterov"] or g["dampening"] != 0 or g.get("maximize", False):
+            if g["dampening"] != 0 or g.get("maximize", False):
                 return False
-            if (g["lr"], g["momentum"], g["weight_decay"]) != (g0["lr"], g0["momentum"], g0["weight_decay"]):
+            if (g["lr"], g["momentum"], g["weight_decay"], g["nesterov"]) != (g0["lr"], g0["momentum"], g0["weight_decay"],
+                                                                             g0["nesterov"]):
                 return False
         mine = {id(p) for p in self.parameters() if p.requires_grad}
         theirs = {id(p) for g in live for p in g["params"]}
@@ -187,7 +189,8 @@ class ClassifierBase(nn.Module):
         eng.ensure_batch(images.shape[0])
         g = next(g for g in optimizer.param_groups if len(g["params"]) > 0)
         logits, loss = eng.train_step(images.contiguous().float(), target.contiguous(), lr=g["lr"], momentum=g["momentum"],
-                                      weight_decay=g["weight_decay"], bn_training=self.channel_bn.training)
+                                      weight_decay=g["weight_decay"], bn_training=self.channel_bn.training,
+                                      nesterov=bool(g["nesterov"]))
         if self.channel_bn.training:
             self.channel_bn.num_batches_tracked += 1
         return logits.clone(), loss.clone()

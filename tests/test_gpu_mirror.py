@@ -117,12 +117,14 @@ def test_train_one_trajectory_matches_reference_fixture(method, route, ckpt):
     assert int(clf.channel_bn.num_batches_tracked) == meta["steps"]
 
 
-@pytest.mark.parametrize("method", ["kadaptation", "compacter"])
-def test_fused_and_autograd_routes_agree(method, ckpt):
+@pytest.mark.parametrize("method,nesterov", [("kadaptation", False), ("compacter", False), ("lora", True)])
+def test_fused_and_autograd_routes_agree(method, nesterov, ckpt):
+    """Same two SGD steps through the fused kernel and through torch.optim.SGD on the engine's gradients
+    (also with Nesterov momentum, the reference's config default)."""
     meta, t = load_golden("tiny_" + method)
     outs = {}
     for route in ("fused", "autograd"):
-        mod, cfg, clf = seeded_classifier(method, ckpt, meta, t)
+        mod, cfg, clf = seeded_classifier(method, ckpt, meta, t, NESTEROV=nesterov)
         opt = mod.build_optimizer(cfg, clf)
         crit = torch.nn.CrossEntropyLoss().cuda(0)
         if route == "autograd":

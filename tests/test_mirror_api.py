@@ -184,10 +184,10 @@ def test_build_optimizer_groups_and_fusability(ckpt):
     for epoch, lr in [(0, 0.1), (2, 0.01), (5, 0.001)]:
         adjust_learning_rate(opt, epoch, cfg)
         assert all(abs(g["lr"] - lr) < 1e-12 for g in opt.param_groups)
-    # anything the fused kernel does not implement falls back to the optimizer's own step()
-    cfg.TRAIN.NESTEROV = True
-    assert not clf.can_fuse(crit, build_optimizer(cfg, clf))
+    cfg.TRAIN.NESTEROV = True                                       # the fused kernel implements Nesterov momentum too
+    assert clf.can_fuse(crit, build_optimizer(cfg, clf))
     cfg.TRAIN.NESTEROV = False
+    # anything the fused kernel does not implement falls back to the optimizer's own step()
     cfg.TRAIN.WITHOUT_WD_LIST = ["bias"]
     opt = build_optimizer(cfg, clf)
     assert [n for n, p in clf.named_parameters() if any(p is q for q in opt.param_groups[1]["params"])] == \
