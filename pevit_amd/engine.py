@@ -181,6 +181,12 @@ class HipEngine:
         del keep
         self.load_trainable(sd)
 
+    def load_phm_rule(self, rule: torch.Tensor):
+        """Compacter's shared, frozen (4,4,4) rule (compacter_model.py:511-519) into the arena."""
+        r = rule.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        _lib.check(self.lib.pevit_load_phm_rule(self._ctx, _lib.stream_ptr(), _lib.ptr(r)), "pevit_load_phm_rule")
+        torch.cuda.current_stream().synchronize()
+
     def load_trainable(self, sd):
         """Adapter / head tensors present in ``sd`` overlay the current values (model.py:1247-1250)."""
         views = self.param_views()

@@ -21,7 +21,9 @@ from __future__ import annotations
 
 import gc
 import logging
+import os
 import time
+import weakref
 
 import numpy as np
 import torch
@@ -67,8 +69,63 @@ class AverageMeter(object):
         self.avg = self.sum / self.count
 
 
-def get_cls_model(method, config, feature_type="image"):
-    model, _ = getattr(clip_load, _LOADERS[method])(config.MODEL.NAME, jit=False)
+class _BackboneCache:
+    """Sweep-level reuse.  ``train_task`` builds a Classifier per run (~90 per dataset); rebuilding
+    the 151 M-parameter CLIP module tree and uploading it costs far more than the few dozen steps of a few-shot run.
+    The backbone of a Classifier that has been garbage-collected is handed to the next one after being put back
+    into the state a fresh ``load()`` would give: adapters re-initialised from the torch RNG exactly like
+    ``build_model`` does, adapter keys of the checkpoint overlaid, frozen tensors untouched (nothing on this path
+    ever writes them), engine optimiser state cleared when the new Classifier binds."""
+
+    def __init__(self):
+        self._items = {}            # key -> (weakref to the owning Classifier, model)
+
+    def take(self, key):
+        entry = self._items.get(key)
+        if entry is None or entry[0]() is not None:
+            return None
+        return entry[1]
+
+    def give(self, key, owner, model):
+        self._items = {k: v for k, v in self._items.items() if k == key or v[0]() is not None}   # drop other idle models
+        self._items[key] = (weakref.ref(owner), model)
+
+    def clear(self):
+        self._items.clear()
+
+
+_BACKBONES = _BackboneCache()
+_ZEROSHOT = {}
+
+
+def _reinitialise(model, method, name):
+    from .model import _init_adapters
+    with torch.no_grad():
+        for n, p in model.visual.named_parameters():
+            if n in model.visual._trainable_names or "phm_rule" in n:
+                p.zero_()
+    _init_adapters(model, method)
+    if method == "compacter" and model.visual._engine is not None:       # the engine keeps its own copy of the frozen rule
+        model.visual._engine.load_phm_rule(dict(model.visual.named_parameters())["transformer.phm_rule"])
+    if os.path.isfile(name):
+        sd = clip_load._read_state_dict(name)
+        own = dict(model.named_parameters())
+        with torch.no_grad():
+            for k in ["visual." + n for n in model.visual._trainable_names]:
+                if k in sd:
+                    own[k].copy_(sd[k].to(own[k].device, own[k].dtype))
+    return model.eval()
+
+
+def get_cls_model(method, config, feature_type="image", owner=None):
+    key = (config.MODEL.NAME, method, clip_load._DEFAULT_DEVICE)
+    model = _BACKBONES.take(key) if owner is not None else None
+    if model is not None:
+        _reinitialise(model, method, config.MODEL.NAME)
+    else:
+        model, _ = getattr(clip_load, _LOADERS[method])(config.MODEL.NAME, jit=False)
+    if owner is not None:
+        _BACKBONES.give(key, owner, model)
     if feature_type == "image":
         model.forward = model.encode_image
     elif feature_type == "text":
@@ -78,6 +135,17 @@ def get_cls_model(method, config, feature_type="image"):
     return model
 
 
+def _zeroshot_key(config):
+    names = config.DATASET.get("CLASS_NAMES", None)
+    if not names:
+        return None
+    parts = []
+    for n in names:
+        n = n[0] if type(n) == list else n
+        parts.append(n.cpu().numpy().tobytes() if torch.is_tensor(n) else str(n))
+    return (config.MODEL.NAME, tuple(parts), tuple(config.DATASET.get("TEMPLATES", None) or ()))
+
+
 class ClassifierBase(nn.Module):
     """Linear classifier on the adapted CLIP tower."""
     METHOD = "kadaptation"
@@ -85,7 +153,7 @@ class ClassifierBase(nn.Module):
 
     def __init__(self, config, l2_lambda):
         super().__init__()
-        self.backbone = get_cls_model(self.METHOD, config, feature_type="image")
+        self.backbone = get_cls_model(self.METHOD, config, feature_type="image", owner=self)
         for name, param in self.backbone.named_parameters():
             param.requires_grad = trainable_by_name(self.METHOD, name)
         input_dim, output_dim = config.MODEL.SPEC.EMBED_DIM, config.DATASET.NUM_CLASSES
@@ -97,7 +165,12 @@ class ClassifierBase(nn.Module):
         self.channel_bn.to(dev); self.layers.to(dev)
 
         if config.TRAIN.INIT_HEAD_WITH_TEXT_ENCODER:
-            zeroshot_weights = extract_text_features(config, self.tokenizer, model=self.backbone, return_numpy=False)
+            zkey = _zeroshot_key(config)
+            zeroshot_weights = _ZEROSHOT.get(zkey) if zkey is not None else None
+            if zeroshot_weights is None:            # the text tower is frozen: one evaluation per (checkpoint, prompts)
+                zeroshot_weights = extract_text_features(config, self.tokenizer, model=self.backbone, return_numpy=False)
+                if zkey is not None:
+                    _ZEROSHOT.clear(); _ZEROSHOT[zkey] = zeroshot_weights.detach().clone()
             w = self.layers[0].weight
             w.data = zeroshot_weights.T.to(w.dtype).to(w.device).contiguous()
             self.layers[0].bias.data.fill_(0.0)
@@ -139,6 +212,7 @@ class ClassifierBase(nn.Module):
                 views["layers.0.weight"].copy_(lin.weight)
                 views["layers.0.bias"].copy_(lin.bias)
             lin.weight.data, lin.bias.data = views["layers.0.weight"], views["layers.0.bias"]
+            eng.reset_optimizer()                 # a new Classifier is a new run: no momentum carried over
             if isinstance(self.channel_bn, nn.BatchNorm1d):
                 eng.running_mean.copy_(self.channel_bn.running_mean)
                 eng.running_var.copy_(self.channel_bn.running_var)

@@ -292,3 +292,30 @@ def test_reference_import_names_resolve():
     assert bm is build_model and bo is build_optimizer
     with pytest.raises(ModuleNotFoundError):
         import vision_benchmark.datasets  # noqa: F401  (out of scope: not mirrored)
+
+
+def test_consecutive_classifiers_reuse_the_backbone(ckpt):
+    """Sweep-level reuse: the second Classifier of a sweep gets the first one's (garbage-collected) backbone back,
+    re-initialised like a fresh build_model(); a live Classifier is never robbed of its backbone."""
+    import gc
+    from pevit_amd.evaluation.kadaptation_clip import Classifier
+    cfg = tiny_config(ckpt)
+    _harness._BACKBONES.clear()
+    a = Classifier(cfg, 0)
+    backbone_id = id(a.backbone)
+    b = Classifier(cfg, 0)                                   # a is alive: b must get its own model
+    assert id(b.backbone) != backbone_id
+    name = "visual.transformer.resblocks.0.attn.q_proj_adapter1_left"
+    with torch.no_grad():
+        dict(b.backbone.named_parameters())[name].fill_(3.0)  # "training"
+        dict(b.backbone.named_parameters())["visual.transformer.phm_rule1_left"].fill_(3.0)
+    kept = id(b.backbone)
+    del a, b
+    gc.collect()
+    c = Classifier(cfg, 0)
+    assert id(c.backbone) == kept                            # re-used ...
+    named = dict(c.backbone.named_parameters())
+    assert float(named[name].abs().max()) == 0.0             # ... with the reference initialisation restored
+    assert 0.0 < float(named["visual.transformer.phm_rule1_left"].abs().max()) <= 0.01
+    assert [n for n, p in c.named_parameters() if p.requires_grad][-2:] == ["layers.0.weight", "layers.0.bias"]
+    _harness._BACKBONES.clear()
