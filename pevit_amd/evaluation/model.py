@@ -220,7 +220,9 @@ class VisionTransformer(nn.Module):
     def attach_engine(self, device, num_classes: int | None = None, max_batch: int | None = None):
         """Create (or, for sweep runs over the same checkpoint, re-use) the HIP context on ``device``, load the
         frozen weights into it and re-seat every trainable Parameter as a view of the engine's flat buffer
-        (the values the Parameters hold now are preserved)."""
+        (the values the Parameters hold now are preserved).  Frozen tensors are packed (bf16, transposed copies)
+        at this point: edit them afterwards and call ``attach_engine`` again -- nothing on the reference's path
+        does."""
         num_classes = num_classes or getattr(self, "_num_classes", 1)
         max_batch = max_batch or getattr(self, "_max_batch", 128)
         sd = {"visual." + k: v for k, v in self.state_dict().items()}

@@ -6,7 +6,7 @@ torch optimizer) -- and the routes must agree with each other.
 Tolerances are those of tests/test_gpu_tower.py (bf16 operands, f32 accumulation; see that file's header):
 logits 3e-2 of the largest magnitude, loss 2e-2 absolute, gradients 1.5e-1 relative L2 (widened per tensor
 only where bf16 operand rounding alone exceeds it), 3-step SGD trajectory 8e-2.  Fused-vs-autograd route:
-identical HIP tower, head computed by the engine vs by torch in f32 -> 6e-3."""
+identical HIP tower, head computed by the engine vs by torch in f32 -> 5e-3."""
 import importlib
 
 import pytest
@@ -35,6 +35,9 @@ def ckpt(tmp_path_factory):
 
 def seeded_classifier(method, ckpt, meta, t, **cfg_over):
     """Classifier built exactly like train_task does, then given the fixture's adapter / head values."""
+    from pevit_amd.evaluation import _harness
+    _harness._BACKBONES.clear()            # a fresh build: the fixture's FROZEN tensors (Compacter's phm_rule) are packed
+                                           # into the engine when it attaches, so they must be in place before that
     mod = importlib.import_module("pevit_amd.evaluation." + HARNESS[method])
     cfg = tiny_config(ckpt, classes=meta["classes"])
     cfg.TRAIN.LR, cfg.TRAIN.WD, cfg.TRAIN.MOMENTUM = meta["lr"], meta["wd"], 0.9
@@ -135,7 +138,7 @@ def test_fused_and_autograd_routes_agree(method, nesterov, ckpt):
         del clf, opt
     for n, a in outs["fused"].items():
         # measured worst: 2.8e-3 on a LayerNorm bias (a cancellation-heavy column sum behind two SGD steps)
-        assert rel_err(a, outs["autograd"][n]) < 6e-3, (n, rel_err(a, outs["autograd"][n]))
+        assert rel_err(a, outs["autograd"][n]) < 5e-3, (n, rel_err(a, outs["autograd"][n]))
 
 
 def test_validate_uses_running_statistics_and_leaves_eval_mode(ckpt):
