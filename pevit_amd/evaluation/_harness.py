@@ -469,6 +469,9 @@ def hyperparameter_sweep_lr(sweep_fn, train_dataloader, val_dataloader, config):
 
 
 def clone_loader(loader, shuffle=True):
+    from .dataloader import TensorLoader
+    if isinstance(loader, TensorLoader):
+        return TensorLoader(loader.dataset, batch_size=loader.batch_size, shuffle=shuffle)
     return create_dataloader(loader.dataset, batch_size=loader.batch_size, shuffle=shuffle,
                              num_workers=loader.num_workers, pin_memory=loader.pin_memory)
 
@@ -478,6 +481,9 @@ def merge_trainval_loader(train_loader, val_loader):
     fullset = trainset.dataset
     assert trainset.dataset is valset.dataset
     assert len(fullset) == len(trainset) + len(valset)
+    from .dataloader import TensorLoader
+    if isinstance(train_loader, TensorLoader):
+        return TensorLoader(fullset, batch_size=train_loader.batch_size, shuffle=True)
     return torch.utils.data.DataLoader(fullset, batch_size=train_loader.batch_size, shuffle=True,
                                        num_workers=train_loader.num_workers, pin_memory=train_loader.pin_memory,
                                        sampler=None, drop_last=False)
