@@ -102,3 +102,35 @@ def test_kadaptation_command_end_to_end(tmp_path, monkeypatch):
     assert 0.0 <= acc <= 100.0 and info["best_logits"].shape == (10, 5)
     j = json.load(open(tmp_path / "out" / "predictions" / "finetuning_full" / "seed0_synthetic.json"))
     assert j["num_trainable_params"] == info["n_trainable_params"] and len(j["predictions"][0]) == 10
+
+
+@pytest.mark.gpu
+def test_full_sweep_then_final_run_on_the_engine(tmp_path, monkeypatch):
+    """The reference's whole job: 6 learning rates x (7 coarse + 8 bisection) weight decays on (train, val), then
+    the final run on train+val evaluated on test -- up to 91 train_task() runs through the fused engine step, the backbone
+    built once."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from pevit_amd.commands import lora_clip as cmd
+    from pevit_amd.evaluation import _harness, clip_load
+    ckpt = tmp_path / "tiny.pt"
+    torch.save(load_tiny_sd(), ckpt)
+    model = tmp_path / "model.yaml"
+    model.write_text(f"MODEL:\n  NAME: '{ckpt}'\n  SPEC:\n    EMBED_DIM: 64\nTRAIN:\n  END_EPOCH: 1\n  EXTRA_FINAL_TRAIN_EPOCH: 1\n"
+                     "  NESTEROV: false\nTEST:\n  METRIC: 'accuracy'\n")
+    monkeypatch.setattr(_finetune, "config", default_config())
+    runs = []
+    real = _harness.train_task
+    monkeypatch.setattr(_harness, "train_task", lambda *a, **k: runs.append(1) or real(*a, **k))
+    loads = []
+    real_build = clip_load.build_lora_model
+    monkeypatch.setattr(clip_load, "build_lora_model", lambda sd: loads.append(1) or real_build(sd))
+    _harness._BACKBONES.clear()
+    acc, info = cmd.main(["--model", str(model), "--no-tuning", "False", "DATASET.DATASET", "synthetic", "DATASET.NUM_CLASSES", "4",
+                          "OUTPUT_DIR", str(tmp_path / "out"), "TRAIN.IMAGE_SIZE", "[48, 48]", "DATASET.SYNTHETIC_SIZES", "(40, 12)"])
+    assert 6 * 11 + 1 <= len(runs) <= 6 * 15 + 1   # 7 coarse + 4 x (1 or 2) bisection probes per learning rate (one when the
+                                                    # peak sits on the edge of the grid), + the final run
+    assert len(loads) == 1                       # the module tree is built from the checkpoint once, not 91 times
+    assert 0.0 <= acc <= 100.0 and info["best_logits"].shape == (12, 4)
+    assert os.path.isfile(tmp_path / "out" / "predictions" / "finetuning_full" / "seed0_synthetic.json")
+    _harness._BACKBONES.clear()
