@@ -151,9 +151,9 @@ class _VisualFn(torch.autograd.Function):
         eng = ctx.visual._engine
         eng.grads[:eng.n_tower].zero_()
         eng.visual_backward(dfeat)
-        views = eng.grad_views()
+        views = eng.param_views(eng.grads.clone())         # ONE copy; autograd takes views of it as the gradients
         mask = ctx.visual._has_grad
-        grads = [views["visual." + n].clone() if mask[n] else None for n in ctx.visual._trainable_names]
+        grads = [views["visual." + n] if mask[n] else None for n in ctx.visual._trainable_names]
         return (None, None, None, *grads)
 
 
@@ -165,6 +165,7 @@ class VisionTransformer(nn.Module):
         self.input_resolution, self.output_dim = arch.resolution, arch.embed_dim
         self.arch, self.method, self.lora_rank = arch, method, lora_rank
         self._engine: HipEngine | None = None
+        self._train_params = None
         E, L = arch.width, arch.layers
         scale = E ** -0.5
         spec = adapter_param_spec(method, E, L, lora_rank)
@@ -247,11 +248,18 @@ class VisionTransformer(nn.Module):
         self._engine = eng
         return eng
 
+    def _trainable_params(self):
+        """The trainable Parameter objects in flat-buffer order (their identity survives device moves and
+        re-seating, so the list is built once)."""
+        if self._train_params is None:
+            named = dict(self.named_parameters())
+            self._train_params = [named[n] for n in self._trainable_names]
+        return self._train_params
+
     def forward(self, x):
         eng = self.engine()
         eng.ensure_batch(x.shape[0])
-        named = dict(self.named_parameters())
-        params = [named[n] for n in self._trainable_names]
+        params = self._trainable_params()
         save = torch.is_grad_enabled() and any(p.requires_grad for p in params)   # grad mode is off inside Function.forward
         return _VisualFn.apply(x.contiguous().float(), self, save, *params)
 
