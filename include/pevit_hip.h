@@ -20,8 +20,9 @@
  *   pevit_load_block / pevit_load_stem      build_model's load_state_dict  model.py:1247-1250
  *
  * Conventions: extern "C"; every function returns 0 on success and a negative value on error
- * (pevit_last_error() gives the message); nothing throws; no allocation after
- * pevit_ctx_create -- all device memory (weight arena, workspace, parameter and gradient
+ * (pevit_last_error() gives the message); nothing throws; no device-memory allocation, ever
+ * (the optional "side_stream" knob creates one stream + two events on first use, profiling its
+ * events in pevit_profile_begin) -- all device memory (weight arena, workspace, parameter and gradient
  * buffers) is owned by the caller and only borrowed; all work is enqueued asynchronously on
  * the caller's hipStream_t (passed as void*); a context is re-entrant across contexts but not
  * thread-safe within one, matching the reference's single-threaded caller.
