@@ -84,9 +84,6 @@ __global__ void prep_lora_kernel(const float* __restrict__ a1q, const float* __r
 // delta-add on the matrix core.  D[e][rr] = sum_j Q[e][j] t[rr][j] is a K=32 product, exactly one
 // v_mfma_f32_16x16x32_bf16; t and Q are f32, so each is split into bf16 hi + lo parts and the product
 // is taken as hi*hi + hi*lo + lo*hi (error ~2^-17, i.e. f32-class, at 3 MFMAs per 16x16 tile).
-// A wave owns 16 reference rows and walks E in steps of 32 columns: two tiles whose output rows are
-// interleaved (tile 0: e = 8g+r, tile 1: e = 8g+4+r) so that each lane ends up with 8 consecutive e
-// of one row -> one 16-byte read-modify-write of the bf16 q (or v) buffer per step.
 __device__ __forceinline__ void split_bf16(const float* src, bf16x8& hi, bf16x8& lo) {
     const float4 a = *reinterpret_cast<const float4*>(src);
     const float4 b = *reinterpret_cast<const float4*>(src + 4);
@@ -98,7 +95,11 @@ __device__ __forceinline__ void split_bf16(const float* src, bf16x8& hi, bf16x8&
     }
 }
 
-constexpr int DA_ESPLIT = 2;     // waves per 16-row group (each takes E/DA_ESPLIT columns)
+// A wave owns DA_RG groups of 16 reference rows and 64 columns of E (two steps of 32 = two 16x16 tiles whose
+// output rows are interleaved, tile 0: e = 8g+r, tile 1: e = 8g+4+r, so that a lane ends up with 8 consecutive e of
+// one row -> one 16-byte read-modify-write); the split Q fragments of a step are loaded once and reused for all
+// DA_RG row groups (they were 2/3 of this kernel's L2 traffic when every 16-row group re-read them).
+constexpr int DA_RG = 4, DA_COLS = 64;
 __global__ __launch_bounds__(256) void delta_add_kernel(bf16* qbuf, bf16* vbuf, const float* __restrict__ t,
                                                         const float* __restrict__ q32, const float* __restrict__ bias,
                                                         float ascale, int B, int N, int E) {
@@ -106,30 +107,29 @@ __global__ __launch_bounds__(256) void delta_add_kernel(bf16* qbuf, bf16* vbuf, 
     const int wg = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int which = blockIdx.y;                  // 0: q, 1: v
     const int T = B * N;
-    const int grp = wg / DA_ESPLIT, part = wg - grp * DA_ESPLIT;
-    const int rr0 = grp * 16;
+    const int parts = E / DA_COLS;
+    const int grp = wg / parts, part = wg - grp * parts;
+    const int rr0 = grp * 16 * DA_RG;
     if (rr0 >= T) return;                          // whole wave exits together
-    int rr = rr0 + c16; const bool rok = rr < T; rr = rok ? rr : T - 1;
-    bf16x8 th, tl;
-    split_bf16(t + (size_t)row_of_ref(rr, B, N) * 64 + which * 32 + 8 * g, th, tl);
-    bf16* buf = (which ? vbuf : qbuf) + (size_t)rr * E;
-    const int ecols = E / DA_ESPLIT;
+    bf16x8 th[DA_RG], tl[DA_RG];
+    bf16* buf[DA_RG];
+    bool rok[DA_RG];
+#pragma unroll
+    for (int k = 0; k < DA_RG; ++k) {
+        int rr = rr0 + 16 * k + c16;
+        rok[k] = rr < T;
+        rr = rok[k] ? rr : T - 1;
+        split_bf16(t + (size_t)row_of_ref(rr, B, N) * 64 + which * 32 + 8 * g, th[k], tl[k]);
+        buf[k] = (which ? vbuf : qbuf) + (size_t)rr * E;
+    }
     const int m = c16;
-#pragma unroll 2
-    for (int eb = part * ecols; eb < (part + 1) * ecols; eb += 32) {
+#pragma unroll
+    for (int st = 0; st < DA_COLS / 32; ++st) {
+        const int eb = part * DA_COLS + st * 32;
         const int e_t0 = eb + 8 * (m >> 2) + (m & 3);
         bf16x8 q0h, q0l, q1h, q1l;
         split_bf16(q32 + (size_t)e_t0 * 64 + which * 32 + 8 * g, q0h, q0l);
         split_bf16(q32 + (size_t)(e_t0 + 4) * 64 + which * 32 + 8 * g, q1h, q1l);
-        const bf16x8 cur = load_bf16x8(buf + eb + 8 * g);
-        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-        a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0l, th, a0, 0, 0, 0);
-        a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0h, tl, a0, 0, 0, 0);
-        a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0h, th, a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1l, th, a1, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1h, tl, a1, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1h, th, a1, 0, 0, 0);
-        // lane: column rr, rows 4g+r of each tile -> e = eb + 8g + r (tile 0), eb + 8g + 4 + r (tile 1)
         float bb[8];
         if (bias) {
             const float4 b0 = *reinterpret_cast<const float4*>(bias + eb + 8 * g);
@@ -139,13 +139,27 @@ __global__ __launch_bounds__(256) void delta_add_kernel(bf16* qbuf, bf16* vbuf, 
 #pragma unroll
             for (int i = 0; i < 8; ++i) bb[i] = 0.f;
         }
-        bf16x8 o;
+        bf16x8 cur[DA_RG];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            o[r] = f2bf(bf2f(cur[r]) + ascale * a0[r] + bb[r]);
-            o[4 + r] = f2bf(bf2f(cur[4 + r]) + ascale * a1[r] + bb[4 + r]);
+        for (int k = 0; k < DA_RG; ++k) cur[k] = load_bf16x8(buf[k] + eb + 8 * g);
+#pragma unroll
+        for (int k = 0; k < DA_RG; ++k) {
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+            a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0l, th[k], a0, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0h, tl[k], a0, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0h, th[k], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1l, th[k], a1, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1h, tl[k], a1, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1h, th[k], a1, 0, 0, 0);
+            // lane: column rr, rows 4g+r of each tile -> e = eb + 8g + r (tile 0), eb + 8g + 4 + r (tile 1)
+            bf16x8 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                o[r] = f2bf(bf2f(cur[k][r]) + ascale * a0[r] + bb[r]);
+                o[4 + r] = f2bf(bf2f(cur[k][4 + r]) + ascale * a1[r] + bb[4 + r]);
+            }
+            if (rok[k]) store_bf16x8(buf[k] + eb + 8 * g, o);
         }
-        if (rok) store_bf16x8(buf + eb + 8 * g, o);
     }
 }
 
@@ -458,9 +472,9 @@ int pevit_launch_prep_lora(const float* a1q, const float* a2q, const float* a1v,
 
 int pevit_launch_delta_add(bf16* qbuf, bf16* vbuf, const float* t, const float* q32, const float* bias, float ascale,
                            int B, int N, int E, hipStream_t s) {
-    if (E % (32 * DA_ESPLIT)) { pevit_set_error("delta_add: width %d must be a multiple of %d", E, 32 * DA_ESPLIT); return -1; }
+    if (E % DA_COLS) { pevit_set_error("delta_add: width %d must be a multiple of %d", E, DA_COLS); return -1; }
     const int T = B * N;
-    const int waves = ceil_div(T, 16) * DA_ESPLIT;
+    const int waves = ceil_div(T, 16 * DA_RG) * (E / DA_COLS);
     hipLaunchKernelGGL(delta_add_kernel, dim3(ceil_div(waves, 4), 2), dim3(256), 0, s, qbuf, vbuf, t, q32, bias, ascale,
                        B, N, E);
     return 0;
