@@ -36,13 +36,21 @@ __device__ __forceinline__ bf16x8 rowfrag(const bf16* base, size_t stride, int r
     return load_bf16x8(base + (size_t)row * stride + 32 * s + 8 * g);
 }
 
+// Transposed tiles Tt[64][LDT] keep token y of row d at column y ^ tswz(d): the scattered 2-byte writes of one
+// wave instruction go to rows 8c+i, c = 0..7, whose 136-byte stride maps them onto only two LDS banks (4-way
+// conflicts, 62 % of this kernel's LDS cycles by SQ_LDS_BANK_CONFLICT); XOR-ing bits 2..4 of the token index with
+// the row group spreads them over disjoint dwords and leaves every aligned group of 4 tokens contiguous, which is
+// all the fragment reads need.
+__device__ __forceinline__ int tswz(int d) { return ((d >> 3) & 7) << 2; }
+
 // fragment of a transposed tile Tt[64][LDT] (LDS): output row m -> d = 16*(m>>2) + 4*dt + (m&3)
 __device__ __forceinline__ bf16x8 tfrag(const bf16* Tt, int LDT, int dt, int s, int lane) {
     const int m = lane & 15, g = lane >> 4;
     const int d = 16 * (m >> 2) + 4 * dt + (m & 3);
-    const bf16* r = Tt + d * LDT + 32 * s + 4 * g;
-    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(r);
-    const bf16x4 hi = *reinterpret_cast<const bf16x4*>(r + 16);
+    const bf16* row = Tt + d * LDT;
+    const int sw = tswz(d);
+    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(row + ((32 * s + 4 * g) ^ sw));
+    const bf16x4 hi = *reinterpret_cast<const bf16x4*>(row + ((32 * s + 16 + 4 * g) ^ sw));
     bf16x8 o;
     o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
     o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
@@ -57,7 +65,7 @@ __device__ __forceinline__ void stage_transposed(bf16* Tt, int LDT, const bf16* 
         bf16x8 v = zero_bf16x8();
         if (y < N) v = load_bf16x8(src + (size_t)y * stride + 8 * c);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) Tt[(8 * c + i) * LDT + y] = v[i];
+        for (int i = 0; i < 8; ++i) Tt[(8 * c + i) * LDT + (y ^ (c << 2))] = v[i];      // tswz(8c+i) = c << 2
     }
 }
 
@@ -198,9 +206,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
             *reinterpret_cast<bf16x8*>(dOs + y * LDR + 8 * c) = vd;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                Kt[(8 * c + i) * LDT + y] = vk[i];
-                Qt[(8 * c + i) * LDT + y] = vq[i];
-                dOt[(8 * c + i) * LDT + y] = vd[i];
+                Kt[(8 * c + i) * LDT + (y ^ (c << 2))] = vk[i];
+                Qt[(8 * c + i) * LDT + (y ^ (c << 2))] = vq[i];
+                dOt[(8 * c + i) * LDT + (y ^ (c << 2))] = vd[i];
             }
         }
     } else {
