@@ -25,6 +25,14 @@
 #include "common.h"
 #include "kernels.h"
 
+// LDS paddings (elements): transposed tiles have rows of NPAD + ATT_TPAD tokens, row-major copies rows of ATT_LDR.
+#ifndef ATT_TPAD
+#define ATT_TPAD 4
+#endif
+#ifndef ATT_LDR
+#define ATT_LDR 80
+#endif
+
 namespace {
 
 __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
@@ -87,7 +95,7 @@ template <int KT32>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
                                                        const bf16* __restrict__ v, bf16* __restrict__ out, int ldo,
                                                        float* __restrict__ lse, int H, int N) {
-    constexpr int NPAD = 32 * KT32, LDT = NPAD + 4, LDK = 72;
+    constexpr int NPAD = 32 * KT32, LDT = NPAD + ATT_TPAD, LDK = ATT_LDR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* Ks = reinterpret_cast<bf16*>(smem);                 // [NPAD][LDK] row-major, padded rows
     bf16* Vt = Ks + NPAD * LDK;                               // [64][LDT]   transposed
@@ -166,7 +174,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
                                                        int ldo, const bf16* __restrict__ dout, int lddo,
                                                        const float* __restrict__ lse, bf16* __restrict__ dqkv, int ld,
                                                        int H, int N, int phase) {
-    constexpr int NPAD = 32 * KT32, LDT = NPAD + 4;
+    constexpr int NPAD = 32 * KT32, LDT = NPAD + ATT_TPAD;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* Kt = reinterpret_cast<bf16*>(smem);
     bf16* Qt = Kt + 64 * LDT;
@@ -185,7 +193,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
     // MFMA fragment of the two passes is an LDS read (the pass loops are otherwise chains of
     // dependent global-load latencies).  Padded rows are zero.
     constexpr bool ROWLDS = ROWLDS_T;
-    constexpr int LDR = 72;
+    constexpr int LDR = ATT_LDR;
     bf16* Qs = reinterpret_cast<bf16*>(del_s + NPAD);
     bf16* Ks = Qs + NPAD * LDR;
     bf16* Vs = Ks + NPAD * LDR;
@@ -331,7 +339,7 @@ template <int KT32>
 int launch_fwd(const bf16* q, const bf16* k, const bf16* v, bf16* out, int ldo, float* lse, int B, int H, int N,
                hipStream_t s) {
     constexpr int NPAD = 32 * KT32;
-    const int bytes = (NPAD * 72 + 64 * (NPAD + 4)) * 2;
+    const int bytes = (NPAD * ATT_LDR + 64 * (NPAD + ATT_TPAD)) * 2;
     static bool attr = false;
     if (!attr && bytes > 48 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<KT32>),
@@ -348,7 +356,7 @@ template <int KT32, bool ROWLDS>
 int launch_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* out, int ldo, const bf16* dout, int lddo,
                const float* lse, bf16* dqkv, int ld, int B, int H, int N, hipStream_t s) {
     constexpr int NPAD = 32 * KT32;
-    const int bytes = 3 * 64 * (NPAD + 4) * 2 + 2 * NPAD * 4 + (ROWLDS ? 4 * NPAD * 72 * 2 : 0);
+    const int bytes = 3 * 64 * (NPAD + ATT_TPAD) * 2 + 2 * NPAD * 4 + (ROWLDS ? 4 * NPAD * ATT_LDR * 2 : 0);
     static bool attr = false;
     if (!attr && bytes > 48 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<KT32, ROWLDS>),
