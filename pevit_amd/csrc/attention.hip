@@ -25,10 +25,11 @@
 #include "common.h"
 #include "kernels.h"
 
-// LDS paddings (elements): transposed tiles have rows of NPAD + ATT_TPAD tokens, row-major copies rows of ATT_LDR.
-#ifndef ATT_TPAD
-#define ATT_TPAD 4
-#endif
+// LDS paddings (elements): transposed tiles have rows of NPAD + att_tpad(KT32) tokens, row-major copies rows of
+// ATT_LDR.  With the tswz() swizzle below, a transposed-row length of 96 mod 128 elements makes both the scattered
+// 2-byte writes and the 8-byte fragment reads bank-conflict free (bank model + search: scripts/lds_bank_model.py);
+// that costs 32 pad columns at N <= 64, none at N <= 224, and is not affordable at N <= 288 (pad 4 there).
+constexpr int att_tpad(int kt32) { return kt32 == 2 ? 32 : (kt32 == 7 ? 0 : 4); }
 #ifndef ATT_LDR
 #define ATT_LDR 80
 #endif
@@ -95,7 +96,7 @@ template <int KT32>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
                                                        const bf16* __restrict__ v, bf16* __restrict__ out, int ldo,
                                                        float* __restrict__ lse, int H, int N) {
-    constexpr int NPAD = 32 * KT32, LDT = NPAD + ATT_TPAD, LDK = ATT_LDR;
+    constexpr int NPAD = 32 * KT32, LDT = NPAD + att_tpad(KT32), LDK = ATT_LDR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* Ks = reinterpret_cast<bf16*>(smem);                 // [NPAD][LDK] row-major, padded rows
     bf16* Vt = Ks + NPAD * LDK;                               // [64][LDT]   transposed
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
                                                        int ldo, const bf16* __restrict__ dout, int lddo,
                                                        const float* __restrict__ lse, bf16* __restrict__ dqkv, int ld,
                                                        int H, int N, int phase) {
-    constexpr int NPAD = 32 * KT32, LDT = NPAD + ATT_TPAD;
+    constexpr int NPAD = 32 * KT32, LDT = NPAD + att_tpad(KT32);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* Kt = reinterpret_cast<bf16*>(smem);
     bf16* Qt = Kt + 64 * LDT;
@@ -339,7 +340,7 @@ template <int KT32>
 int launch_fwd(const bf16* q, const bf16* k, const bf16* v, bf16* out, int ldo, float* lse, int B, int H, int N,
                hipStream_t s) {
     constexpr int NPAD = 32 * KT32;
-    const int bytes = (NPAD * ATT_LDR + 64 * (NPAD + ATT_TPAD)) * 2;
+    const int bytes = (NPAD * ATT_LDR + 64 * (NPAD + att_tpad(KT32))) * 2;
     static bool attr = false;
     if (!attr && bytes > 48 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<KT32>),
@@ -356,7 +357,7 @@ template <int KT32, bool ROWLDS>
 int launch_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* out, int ldo, const bf16* dout, int lddo,
                const float* lse, bf16* dqkv, int ld, int B, int H, int N, hipStream_t s) {
     constexpr int NPAD = 32 * KT32;
-    const int bytes = 3 * 64 * (NPAD + ATT_TPAD) * 2 + 2 * NPAD * 4 + (ROWLDS ? 4 * NPAD * ATT_LDR * 2 : 0);
+    const int bytes = 3 * 64 * (NPAD + att_tpad(KT32)) * 2 + 2 * NPAD * 4 + (ROWLDS ? 4 * NPAD * ATT_LDR * 2 : 0);
     static bool attr = false;
     if (!attr && bytes > 48 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<KT32, ROWLDS>),
