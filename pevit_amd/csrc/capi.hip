@@ -918,6 +918,7 @@ extern "C" int pevit_tune(const char* key, int value) {
     if (key && !strcmp(key, "gemm_hoist")) { pevit_gemm_set_hoist(value); return 0; }
     if (key && !strcmp(key, "gemm_ablate")) { pevit_gemm_set_ablate(value); return 0; }
     if (key && !strcmp(key, "gemm_ring")) { pevit_gemm_set_ring(value); return 0; }
+    if (key && !strcmp(key, "gemm_kswitch")) { pevit_gemm_set_kswitch(value); return 0; }
     if (key && !strcmp(key, "gemm_256")) { pevit_gemm_set_256(value); return 0; }
     if (key && !strcmp(key, "side_stream")) { g_side_stream = value; return 0; }
     if (key && !strcmp(key, "gemm_dephase")) { pevit_gemm_set_dephase(value); return 0; }

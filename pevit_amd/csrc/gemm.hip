@@ -31,6 +31,7 @@ int g_gemm_config = -1;    // -1: heuristic ; >= 0: force a tile configuration (
 int g_gemm_persistent = 1;
 int g_gemm_hoist = 1;       // hoist all fragment reads of a k-tile ahead of its MFMAs
 int g_gemm_ablate = 0;      // measurement only (GemmParams::dbg)
+int g_gemm_kswitch = 2048;  // K from which the few-tile problems use the 128x128 tile instead of 64x128
 int g_gemm_dephase = 0;     // x 512 clk start delay of the second half of the grid (0: off; helps back-to-back microbenchmarks by 7 %, costs 2 % inside the step)
 
 int num_cus() {
@@ -824,7 +825,7 @@ int pick_config(const GemmParams& p) {
     if (p.N <= 64) return 3;                      // bottleneck products: 64-wide tiles
     const long t128 = (long)ceil_div(p.M, 128) * ceil_div(p.N, 128);
     const bool hoist = g_gemm_hoist != 0;
-    if (t128 >= 700 || p.K >= 2048) return hoist ? 5 : 0;
+    if (t128 >= 700 || p.K >= g_gemm_kswitch) return hoist ? 5 : 0;
     return hoist ? 7 : 4;
 }
 
@@ -860,6 +861,7 @@ int pevit_gemm_set_hoist(int v) { const int old = g_gemm_hoist; g_gemm_hoist = v
 int pevit_gemm_set_ablate(int v) { const int old = g_gemm_ablate; g_gemm_ablate = v; return old; }
 int pevit_gemm_set_dephase(int v) { const int old = g_gemm_dephase; g_gemm_dephase = v; return old; }
 int pevit_gemm_set_256(int v) { const int old = g_gemm_256; g_gemm_256 = v; return old; }
+int pevit_gemm_set_kswitch(int v) { const int old = g_gemm_kswitch; g_gemm_kswitch = v; return old; }
 int pevit_gemm_set_ring(int v) { const int old = g_gemm_ring; g_gemm_ring = v; return old; }
 int pevit_gemm_set_persistent(int v) { const int old = g_gemm_persistent; g_gemm_persistent = v; return old; }
 

@@ -41,6 +41,7 @@ int pevit_gemm_set_persistent(int v);
 int pevit_gemm_set_hoist(int v);
 int pevit_gemm_set_ablate(int v);
 int pevit_gemm_set_ring(int v);
+int pevit_gemm_set_kswitch(int v);
 int pevit_gemm_set_256(int v);
 int pevit_gemm_set_dephase(int v);
 int pevit_gemm_set_variant(int v);   // -1: heuristic, >= 0: forced tile configuration; returns the previous value
