@@ -108,9 +108,11 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="images per GPU (BASELINE config 2: 128)")
     ap.add_argument("--method", default="kadaptation")
     ap.add_argument("--arch", default="ViT-B/32")
+    ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8"],
+                    help="frozen block weights: bf16, or e4m3 codes + per-channel scales (BASELINE config 5 with --arch ViT-L/14)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=INT",
-                    help="library tuning knob for A/B runs, e.g. gemm_hoist=0 (see pevit_tune)")
+                    help="library tuning knob for A/B runs, e.g. gemm_big=0 (see pevit_tune)")
     ap.add_argument("--pmc-calib", action="store_true",
                     help="(profiling runs only) first move a known byte count through HBM so that the FETCH_SIZE / "
                          "WRITE_SIZE counters of the same rocprofv3 pass can be calibrated (scripts/pmc_traffic.py)")
@@ -135,11 +137,12 @@ def main():
     sd = synth_state_dict(arch, seed=2, text_tower=False)
     if args.method == "compacter":      # frozen shared rule ~ U(-1,1) (compacter_model.py:511-519)
         sd["visual.transformer.phm_rule"] = torch.rand((4, 4, 4), generator=torch.Generator().manual_seed(4)) * 2 - 1
-    eng = HipEngine(arch, args.method, classes, args.batch, lora_rank=8 if args.method == "lora" else 4, device=dev)
+    eng = HipEngine(arch, args.method, classes, args.batch, lora_rank=8 if args.method == "lora" else 4, device=dev,
+                    weight_format=args.weights)
     eng.load_state_dict(sd)
     for kv in args.tune:
         key, val = kv.split("=")
-        if eng.lib.pevit_tune(key.encode(), int(val)) < 0:
+        if eng.tune(key, int(val)) < 0:
             raise SystemExit(f"unknown tuning key {key}")
     # adapters at the reference initialisation; head ~ nn.Linear default
     views = eng.param_views()
@@ -199,14 +202,19 @@ def main():
         gemm_tflops = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         algo_bytes = eng.last_profile_bytes / max(gemm_launches, 1)
         traffic, traffic_how = pmc_traffic(args.arch, args.method, args.batch)
+        headline = (args.arch, args.method, args.batch, args.weights) == ("ViT-B/32", "kadaptation", 128, "bf16")
+        metric = "images/sec fine-tune, CLIP ViT-B/32 + KAdaptation, bs=128, 1/2/4/8 GPU" if headline else \
+            f"images/sec fine-tune, CLIP {args.arch} + {args.method}, bs={args.batch}/GPU, {args.weights} weights"
         out = {
-            "metric": "images/sec fine-tune, CLIP ViT-B/32 + KAdaptation, bs=128, 1/2/4/8 GPU",
+            "metric": metric,
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"CLIP {args.arch} + {args.method} fine-tune step (fwd+CE+bwd+SGD), "
                                    f"{args.batch} images/GPU 3x{arch.resolution}x{arch.resolution}, C={classes}, "
-                                   f"synthetic OpenAI-layout checkpoint, adapters at reference init",
+                                   f"synthetic OpenAI-layout checkpoint, adapters at reference init, frozen block "
+                                   f"weights {args.weights}" + (" (e4m3 codes + per-channel scales, bf16 activations, f32 accumulate)"
+                                                                 if args.weights == "fp8" else ""),
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "train_gflop_per_image": gflop, "final_loss": final_loss},
             "roofline": {"bound": "mfma", "kernel": "gemm_bf16_nt_kernel (all epilogues / tile shapes)",

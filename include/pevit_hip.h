@@ -24,8 +24,9 @@
  * (the optional "side_stream" knob creates one stream + two events on first use, profiling its
  * events in pevit_profile_begin) -- all device memory (weight arena, workspace, parameter and gradient
  * buffers) is owned by the caller and only borrowed; all work is enqueued asynchronously on
- * the caller's hipStream_t (passed as void*); a context is re-entrant across contexts but not
- * thread-safe within one, matching the reference's single-threaded caller.
+ * the caller's hipStream_t (passed as void*); contexts are independent of each other (no
+ * mutable process-wide state on the hot path; tuning knobs live in the context) but one context
+ * is not thread-safe, matching the reference's single-threaded caller.
  *
  * Row order: the reference keeps activations sequence-first, (N, B, E).  Entry points with
  * "_nbe" arguments take and return exactly that layout; internally rows are batch-major.
@@ -50,6 +51,13 @@ enum pevit_method {
     PEVIT_NONE = 4         /* frozen tower, no adapter (linear probe)                               */
 };
 
+enum pevit_weight_format {
+    PEVIT_W_BF16 = 0,     /* frozen block weights rounded to bf16 (reference: fp32 parameters, model.py:1247-1250)    */
+    PEVIT_W_FP8_E4M3 = 1  /* OCP e4m3 codes + one power-of-two f32 scale per output channel, packed by
+                             pevit_load_block; activations stay bf16, accumulation f32 (BASELINE config 5).  Bit-identical
+                             to PEVIT_W_BF16 run on the de-quantised weights.  KAdaptation, LoRA and the frozen tower.  */
+};
+
 typedef struct pevit_dims {
     int32_t width;       /* E: visual.conv1.weight.shape[0]                 (model.py:1214) */
     int32_t layers;      /* L                                               (model.py:1215) */
@@ -59,6 +67,7 @@ typedef struct pevit_dims {
     int32_t method;      /* enum pevit_method                                               */
     int32_t lora_rank;   /* r (reference hard-codes 4: lora_model.py:461)                   */
     int32_t num_classes; /* C: DATASET.NUM_CLASSES          (kadaptation_clip.py:125)       */
+    int32_t weight_format; /* enum pevit_weight_format                                      */
 } pevit_dims;
 
 const char* pevit_last_error(void);
@@ -131,10 +140,25 @@ int pevit_op_gemm(void* stream, int epilogue, const void* A_bf16, int lda, const
                   int M, int N, int K, const float* bias, const float* resid, int ldr, float* out_f32, int ldo,
                   void* out_bf16, int ldob, void* out2_bf16, int ldob2, const void* aux_bf16, int ldaux,
                   size_t head_stride, int E, int H, int tokens);
+/* fp8 weights (PEVIT_W_FP8_E4M3): B = e4m3 codes [b_rows][ldb] as written by pevit_op_quant_fp8 (k-permuted per 128),
+ * bscale = per-output-column scale applied to the accumulator (NULL: none), oscale = per-column factor folded into the
+ * bf16 output of the DGELU epilogue (NULL: none); K % 128 == 0.  Epilogues 0..5 only. */
+int pevit_op_gemm_fp8(void* stream, int epilogue, const void* A_bf16, int lda, const void* B_codes, int ldb, int b_rows,
+                      const float* bscale, const float* oscale, int M, int N, int K, const float* bias,
+                      const float* resid, int ldr, float* out_f32, int ldo, void* out_bf16, int ldob, void* out2_bf16,
+                      int ldob2, const void* aux_bf16, int ldaux, size_t head_stride, int E, int H, int tokens);
+/* W (rows x cols f32, cols % 128 == 0) -> per-row power-of-two scales 2^ceil(log2(amax/448)), e4m3 codes [rows][cols]
+ * and (codes_t != NULL, rows % 128 == 0) the same codes transposed [cols][rows]; both k-permuted per 128 */
+int pevit_op_quant_fp8(void* stream, const float* W, int rows, int cols, void* codes, float* scales, void* codes_t);
+int pevit_op_dequant_fp8(void* stream, const void* codes, const float* scales, int rows, int cols, float* out_f32);
 int pevit_op_ln_fwd(void* stream, const float* x, const float* gamma, const float* beta, int rows, int E,
                     void* y_bf16, float* y_f32, float* mean, float* rstd);
 int pevit_op_ln_bwd(void* stream, const float* dy, const float* x, const float* mean, const float* rstd,
                     const float* gamma, const float* dres, float* dx, void* dx_bf16, int rows, int E);
+/* as pevit_op_ln_bwd, with a per-column factor on the bf16 copy only (fp8 weights: channel scales of the consuming GEMM) */
+int pevit_op_ln_bwd_scaled(void* stream, const float* dy, const float* x, const float* mean, const float* rstd,
+                           const float* gamma, const float* dres, float* dx, void* dx_bf16, int rows, int E,
+                           const float* bf16_colscale);
 int pevit_op_attn_fwd(void* stream, const void* q, const void* k, const void* v, void* out, int ldo, float* lse,
                       int B, int H, int N);
 int pevit_op_attn_bwd(void* stream, const void* q, const void* k, const void* v, const void* out, int ldo,
@@ -147,10 +171,12 @@ int pevit_op_lowrank_u(void* stream, const void* dqkv, int ld, const void* qT, f
 int pevit_op_lowrank_grad(void* stream, const void* xn, int ldx, const float* u32, const void* dqkv, int ld,
                           const float* t, float* partial, float* dbias_partial, int B, int H, int N, int E);
 int pevit_op_lowrank_chunks(int T);
-/* tuning knobs for A/B measurements: "gemm_config" (-1 = per-problem heuristic, 0..8 = force a tile configuration),
- * "gemm_persistent", "gemm_hoist", "gemm_ring" (0 off, 1 auto, 2 force the 160x128x64 ring, 5 the 128x128x32 ring),
- * "gemm_dephase", "gemm_ablate", "side_stream", "attn_bwd_phase"; returns 0, or -1 for an unknown key */
-int pevit_tune(const char* key, int value);
+/* knobs for A/B measurements, held in the context (ctx == NULL: the process-wide defaults that only the
+ * context-free pevit_op_* entry points above use): "gemm_config" (-1 = per-problem heuristic, 0..5 = force a tile
+ * configuration: 128x128, 64x128, 64x64 with 4 waves; 256x128, 256x256, 320x256 with 8 waves), "gemm_persistent",
+ * "gemm_big" (0 = never pick the 8-wave tiles), "gemm_big_bias", "gemm_kswitch", "gemm_ablate" (bit 0 skips the
+ * k-loop, bit 1 the epilogue stores), "side_stream" (ctx only); returns 0, or -1 for an unknown key */
+int pevit_tune(pevit_ctx* ctx, const char* key, int value);
 
 #ifdef __cplusplus
 }

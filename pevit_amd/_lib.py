@@ -18,7 +18,10 @@ c_void_p, c_int, c_float, c_size_t, c_char_p = C.c_void_p, C.c_int, C.c_float, C
 class PevitDims(C.Structure):
     _fields_ = [("width", C.c_int32), ("layers", C.c_int32), ("patch", C.c_int32), ("resolution", C.c_int32),
                 ("out_dim", C.c_int32), ("method", C.c_int32), ("lora_rank", C.c_int32),
-                ("num_classes", C.c_int32)]
+                ("num_classes", C.c_int32), ("weight_format", C.c_int32)]
+
+
+WEIGHT_FORMATS = {"bf16": 0, "fp8": 1}
 
 
 METHOD_IDS = {"kadaptation": 0, "lora": 1, "adapter": 2, "compacter": 3, "none": 4}
@@ -52,8 +55,13 @@ SIGNATURES = {
     "pevit_profile_end": (c_int, [P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_int)]),
     "pevit_op_gemm": (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, c_int,
                               P, c_int, P, c_int, P, c_int, c_size_t, c_int, c_int, c_int]),
+    "pevit_op_gemm_fp8": (c_int, [P, c_int, P, c_int, P, c_int, c_int, P, P, c_int, c_int, c_int, P, P, c_int, P, c_int,
+                                  P, c_int, P, c_int, P, c_int, c_size_t, c_int, c_int, c_int]),
+    "pevit_op_quant_fp8": (c_int, [P, P, c_int, c_int, P, P, P]),
+    "pevit_op_dequant_fp8": (c_int, [P, P, P, c_int, c_int, P]),
     "pevit_op_ln_fwd": (c_int, [P, P, P, P, c_int, c_int, P, P, P, P]),
     "pevit_op_ln_bwd": (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int]),
+    "pevit_op_ln_bwd_scaled": (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, P]),
     "pevit_op_attn_fwd": (c_int, [P, P, P, P, P, c_int, P, c_int, c_int, c_int]),
     "pevit_op_attn_bwd": (c_int, [P, P, P, P, P, c_int, P, c_int, P, P, c_int, c_int, c_int, c_int]),
     "pevit_op_cast_bf16": (c_int, [P, P, P, c_size_t, c_float]),
@@ -61,7 +69,7 @@ SIGNATURES = {
     "pevit_op_lowrank_u": (c_int, [P, P, c_int, P, P, P, c_int, c_int, c_int, c_int]),
     "pevit_op_lowrank_grad": (c_int, [P, P, c_int, P, P, c_int, P, P, P, c_int, c_int, c_int, c_int]),
     "pevit_op_lowrank_chunks": (c_int, [c_int]),
-    "pevit_tune": (c_int, [c_char_p, c_int]),
+    "pevit_tune": (c_int, [P, c_char_p, c_int]),
 }
 
 _lib = None

@@ -376,6 +376,7 @@ int pevit_lna_blocks(int rows) { return ceil_div(rows, LNA_ROWS); }
 int pevit_launch_prep_adapter(const float* w_down, const float* w_up, BottleneckPanels pan, int E, int layers, LayerStrides st,
                               hipStream_t s) {
     hipLaunchKernelGGL(prep_adapter_kernel, dim3(ceil_div(64 * E, 256), layers), dim3(256), 0, s, w_down, w_up, pan, E, st);
+    LAUNCH_OK("prep_adapter_kernel");
     return 0;
 }
 int pevit_launch_prep_compacter(const float* rule, const float* dWl, const float* dWr, const float* uWl, const float* uWr,
@@ -383,6 +384,7 @@ int pevit_launch_prep_compacter(const float* rule, const float* dWl, const float
     if (E % 4) { pevit_set_error("prep_compacter: width %d not divisible by 4", E); return -1; }
     hipLaunchKernelGGL(prep_compacter_kernel, dim3(ceil_div(64 * E, 256), layers), dim3(256), 0, s, rule, dWl, dWr, uWl, uWr,
                        pan, E, st);
+    LAUNCH_OK("prep_compacter_kernel");
     return 0;
 }
 int pevit_launch_tn_gemm64(const bf16* X, int ldx, const bf16* Y, int ldy, float* partial, float* csx, float* csy, int T, int E,
@@ -390,6 +392,7 @@ int pevit_launch_tn_gemm64(const bf16* X, int ldx, const bf16* Y, int ldy, float
     if (E % 64 || (ldx % 8) || (ldy % 8)) { pevit_set_error("tn_gemm64: bad shape E=%d ldx=%d ldy=%d", E, ldx, ldy); return -1; }
     hipLaunchKernelGGL(tn_gemm64_kernel, dim3(ceil_div(T, TG_ROWS) * (E / 64)), dim3(256), 0, s, X, ldx, Y, ldy, partial, csx,
                        csy, T, E);
+    LAUNCH_OK("tn_gemm64_kernel");
     return 0;
 }
 int pevit_launch_ln_bwd_affine(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
@@ -404,24 +407,28 @@ int pevit_launch_ln_bwd_affine(const float* dy, const float* x, const float* mea
     }
     hipLaunchKernelGGL(ln_bwd_affine_kernel, dim3(ceil_div(rows, LNA_ROWS)), dim3(64 * LNA_WAVES), lds, s, dy, x, mean, rstd, gamma,
                        dres, dx, dx_bf16, partial, rows, E);
+    LAUNCH_OK("ln_bwd_affine_kernel");
     return 0;
 }
 int pevit_launch_colsum_reduce(const float* partial, int chunks, int n, float* out, int layers, size_t partial_layer,
                                size_t out_layer, hipStream_t s) {
     hipLaunchKernelGGL(colsum_reduce_kernel, dim3(ceil_div(n, CR_COLS), layers), dim3(256), 0, s, partial, chunks, n, out,
                        partial_layer, out_layer);
+    LAUNCH_OK("colsum_reduce_kernel");
     return 0;
 }
 int pevit_launch_colsum_reduce3(const float* partial, int chunks, int n, float* o0, float* o1, float* o2, int layers,
                                 size_t partial_layer, size_t out_layer, hipStream_t s) {
     hipLaunchKernelGGL(colsum_reduce3_kernel, dim3(ceil_div(3 * n, CR_COLS), layers), dim3(256), 0, s, partial, chunks, n, o0, o1, o2,
                        partial_layer, out_layer);
+    LAUNCH_OK("colsum_reduce3_kernel");
     return 0;
 }
 int pevit_launch_chain_adapter(const float* Gd, const float* Gu, float* g_down, float* g_up, int E, int layers, size_t g_layer,
                                size_t param_layer, hipStream_t s) {
     hipLaunchKernelGGL(chain_adapter_kernel, dim3(ceil_div(64 * E, 256), layers), dim3(256), 0, s, Gd, Gu, g_down, g_up, E,
                        g_layer, param_layer);
+    LAUNCH_OK("chain_adapter_kernel");
     return 0;
 }
 int pevit_launch_chain_compacter(const float* Gd, const float* Gu, const float* rule, const float* params, float* grads, int E,
@@ -429,5 +436,6 @@ int pevit_launch_chain_compacter(const float* Gd, const float* Gu, const float* 
                                  size_t off_uWr, hipStream_t s) {
     hipLaunchKernelGGL(chain_compacter_kernel, dim3(4, layers, 4), dim3(256), 0, s, Gd, Gu, rule, params, grads, E, g_layer,
                        param_layer, off_dWl, off_dWr, off_uWl, off_uWr);
+    LAUNCH_OK("chain_compacter_kernel");
     return 0;
 }

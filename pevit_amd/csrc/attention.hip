@@ -334,8 +334,6 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
     }
 }
 
-int g_attn_bwd_phase = 3;   // debug knob: 1 = staging only, 2 = + pass A, 3 = full
-
 template <int KT32>
 int launch_fwd(const bf16* q, const bf16* k, const bf16* v, bf16* out, int ldo, float* lse, int B, int H, int N,
                hipStream_t s) {
@@ -350,6 +348,7 @@ int launch_fwd(const bf16* q, const bf16* k, const bf16* v, bf16* out, int ldo, 
         attr = true;
     }
     hipLaunchKernelGGL(attn_fwd_kernel<KT32>, dim3(B * H), dim3(256), bytes, s, q, k, v, out, ldo, lse, H, N);
+    LAUNCH_OK("attn_fwd_kernel");
     return 0;
 }
 
@@ -367,13 +366,12 @@ int launch_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* out, int
         attr = true;
     }
     hipLaunchKernelGGL((attn_bwd_kernel<KT32, ROWLDS>), dim3(B * H), dim3(256), bytes, s, q, k, v, out, ldo, dout, lddo, lse,
-                       dqkv, ld, H, N, g_attn_bwd_phase & 3);
+                       dqkv, ld, H, N, 3);
+    LAUNCH_OK("attn_bwd_kernel");
     return 0;
 }
 
 }  // namespace
-
-int pevit_attn_set_bwd_phase(int v) { const int o = g_attn_bwd_phase; g_attn_bwd_phase = v; return o; }
 
 int pevit_launch_attn_fwd(const bf16* q, const bf16* k, const bf16* v, bf16* out, int ldo, float* lse, int B, int H,
                           int N, hipStream_t s) {
@@ -388,9 +386,8 @@ int pevit_launch_attn_bwd(const bf16* q, const bf16* k, const bf16* v, const bf1
                           int lddo, const float* lse, bf16* dqkv, int ld, int B, int H, int N, hipStream_t s) {
     if (N < 1 || N > 288) { pevit_set_error("attn_bwd: tokens per image N=%d outside [1,288]", N); return -1; }
     if ((ldo % 8) || (lddo % 8) || (ld % 8)) { pevit_set_error("attn_bwd: leading dims must be multiples of 8"); return -1; }
-    // N <= 64: row-major copies in LDS as well (g_attn_bwd_phase bit 2 turns them off for A/B measurements)
-    if (N <= 64 && !(g_attn_bwd_phase & 4)) return launch_bwd<2, true>(q, k, v, out, ldo, dout, lddo, lse, dqkv, ld, B, H, N, s);
-    if (N <= 64) return launch_bwd<2, false>(q, k, v, out, ldo, dout, lddo, lse, dqkv, ld, B, H, N, s);
+    // N <= 64: row-major copies in LDS as well
+    if (N <= 64) return launch_bwd<2, true>(q, k, v, out, ldo, dout, lddo, lse, dqkv, ld, B, H, N, s);
     if (N <= 224) return launch_bwd<7, false>(q, k, v, out, ldo, dout, lddo, lse, dqkv, ld, B, H, N, s);
     return launch_bwd<9, false>(q, k, v, out, ldo, dout, lddo, lse, dqkv, ld, B, H, N, s);
 }

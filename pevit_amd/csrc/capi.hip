@@ -42,6 +42,8 @@ struct BlockArena {        // byte offsets inside the weight arena, one per laye
     size_t bqkv, bo, bfc, bpr, ln1w, ln1b, ln2w, ln2b;
     size_t q32, qT;
     size_t wd, wdT, wu, wuT;      // post-MLP adapter panels (bf16), rewritten every step
+    size_t wpan;                  // fp8 weights only: the 64 adapter rows P_q^T | P_v^T (bf16) of the separate t = xn P product
+    size_t sqkv, so, sfc, spr;    // fp8 weights only: per-output-channel scales (f32, powers of two)
 };
 
 struct LayerSaved {        // byte offsets inside the workspace, one per layer (kept for backward)
@@ -51,13 +53,13 @@ struct LayerSaved {        // byte offsets inside the workspace, one per layer (
 
 }  // namespace
 
-static int g_side_stream = 0;     // adapter-gradient contractions on a second stream (pevit_tune "side_stream"): +0.5 % step throughput, but it
-                                  // slows the GEMMs it overlaps by 4 %, which blurs the per-kernel roofline measurement: off by default
+static GemmTune g_default_tune;   // used by the context-free single-kernel entry points (pevit_op_*) only
 
 struct pevit_ctx {
     pevit_dims d;
     int E, L, H, N, P, R, D, C, G2, Kpatch;
     int NQ, NQpad;            // 3E+64 and its multiple-of-128 padding
+    bool fp8 = false;         // frozen block weights as e4m3 codes + per-channel scales (fp8.hip)
     float ascale;             // 160 (model.py:564) or alpha/r (lora_model.py:491)
     // arena
     BlockArena* blk = nullptr;
@@ -93,6 +95,10 @@ struct pevit_ctx {
     // first use, so that contexts can still be sized on machines without a GPU
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // A/B-measurement knobs (pevit_tune): per context, so that contexts stay independent of each other
+    GemmTune tune;
+    int side_stream = 0;      // adapter-gradient contractions on a second stream: +0.5 % step throughput, but it slows the GEMMs
+                              // it overlaps by 4 %, which blurs the per-kernel roofline measurement: off by default
 };
 
 namespace {
@@ -194,6 +200,12 @@ extern "C" int pevit_ctx_create(const pevit_dims* dims, pevit_ctx** out) {
     if (d.method == PEVIT_LORA && (d.lora_rank < 1 || d.lora_rank > 32)) {
         pevit_set_error("ctx_create: LoRA rank %d outside [1,32]", d.lora_rank); return -1;
     }
+    if (d.weight_format != PEVIT_W_BF16 && d.weight_format != PEVIT_W_FP8_E4M3) {
+        pevit_set_error("ctx_create: unknown weight_format %d", d.weight_format); return -1;
+    }
+    if (d.weight_format == PEVIT_W_FP8_E4M3 && (d.method == PEVIT_ADAPTER || d.method == PEVIT_COMPACTER)) {
+        pevit_set_error("ctx_create: fp8 weights are built for the attention-site methods (KAdaptation, LoRA) and the frozen tower"); return -1;
+    }
     if (d.out_dim <= 0 || d.out_dim % 8 != 0 || d.num_classes <= 0) {
         pevit_set_error("ctx_create: bad out_dim/num_classes %d/%d", d.out_dim, d.num_classes); return -1;
     }
@@ -206,6 +218,7 @@ extern "C" int pevit_ctx_create(const pevit_dims* dims, pevit_ctx** out) {
     c->Kpatch = (int)align_up((size_t)3 * d.patch * d.patch, 64);
     c->NQ = 3 * c->E + 64; c->NQpad = (int)align_up((size_t)c->NQ, 128);
     c->ascale = d.method == PEVIT_LORA ? 128.0f / (float)d.lora_rank : 160.0f;
+    c->fp8 = d.weight_format == PEVIT_W_FP8_E4M3;
     if (c->N > 288) { pevit_set_error("ctx_create: %d tokens per image exceeds 288", c->N); delete c; return -1; }
 
     // ---- weight arena -------------------------------------------------------------
@@ -216,11 +229,24 @@ extern "C" int pevit_ctx_create(const pevit_dims* dims, pevit_ctx** out) {
     const size_t E = c->E;
     for (int l = 0; l < c->L; ++l) {
         BlockArena& b = c->blk[l];
-        b.wqkv = cv.take((size_t)c->NQpad * E * 2);
-        b.wqkvT = cv.take(E * (size_t)c->NQ * 2);
-        b.wo = cv.take(E * E * 2);   b.woT = cv.take(E * E * 2);
-        b.wfc = cv.take(4 * E * E * 2); b.wfcT = cv.take(4 * E * E * 2);
-        b.wpr = cv.take(4 * E * E * 2); b.wprT = cv.take(4 * E * E * 2);
+        b.wpan = b.sqkv = b.so = b.sfc = b.spr = 0;
+        if (c->fp8) {
+            // one byte per weight; rows padded to the largest tile (256) so that clamped tile rows stay readable
+            const size_t r1 = align_up(E, 256), r3 = align_up(3 * E, 256), r4 = align_up(4 * E, 256);
+            b.wqkv = cv.take(r3 * E);
+            b.wpan = cv.take(128 * E * 2);
+            b.wqkvT = cv.take(E * (size_t)c->NQ * 2);          // QKV backward keeps bf16: its K mixes frozen rows with the adapter panel
+            b.wo = cv.take(r1 * E);       b.woT = cv.take(r1 * E);
+            b.wfc = cv.take(r4 * E);      b.wfcT = cv.take(r1 * 4 * E);
+            b.wpr = cv.take(r1 * 4 * E);  b.wprT = cv.take(r4 * E);
+            b.sqkv = cv.take(3 * E * 4); b.so = cv.take(E * 4); b.sfc = cv.take(4 * E * 4); b.spr = cv.take(E * 4);
+        } else {
+            b.wqkv = cv.take((size_t)c->NQpad * E * 2);
+            b.wqkvT = cv.take(E * (size_t)c->NQ * 2);
+            b.wo = cv.take(E * E * 2);   b.woT = cv.take(E * E * 2);
+            b.wfc = cv.take(4 * E * E * 2); b.wfcT = cv.take(4 * E * E * 2);
+            b.wpr = cv.take(4 * E * E * 2); b.wprT = cv.take(4 * E * E * 2);
+        }
         b.bqkv = cv.take(3 * E * 4); b.bo = cv.take(E * 4); b.bfc = cv.take(4 * E * 4); b.bpr = cv.take(E * 4);
         b.ln1w = cv.take(E * 4); b.ln1b = cv.take(E * 4); b.ln2w = cv.take(E * 4); b.ln2b = cv.take(E * 4);
         b.q32 = cv.take(E * 64 * 4); b.qT = cv.take(64 * E * 2);
@@ -328,17 +354,43 @@ extern "C" int pevit_load_block(pevit_ctx* c, void* stream, int l, const float* 
     const size_t E = c->E;
     char* A = c->arena;
     // the 1/sqrt(head_dim) of model.py:786-787 is folded into the q rows (exact: a power of two)
-    HIP_OK(hipMemsetAsync(A + b.wqkv, 0, (size_t)c->NQpad * E * 2, s));
-    CHECK(pevit_launch_cast_bf16(in_w, at<bf16>(A, b.wqkv), E * E, 0.125f, s));
-    CHECK(pevit_launch_cast_bf16(in_w + E * E, at<bf16>(A, b.wqkv) + E * E, 2 * E * E, 1.0f, s));
-    HIP_OK(hipMemsetAsync(A + b.wqkvT, 0, E * (size_t)c->NQ * 2, s));
-    CHECK(pevit_launch_transpose_bf16(in_w, 3 * (int)E, (int)E, at<bf16>(A, b.wqkvT), c->NQ, (int)E, 0.125f, s));
-    CHECK(pevit_launch_cast_bf16(out_w, at<bf16>(A, b.wo), E * E, 1.0f, s));
-    CHECK(pevit_launch_transpose_bf16(out_w, (int)E, (int)E, at<bf16>(A, b.woT), (int)E, 0, 1.0f, s));
-    CHECK(pevit_launch_cast_bf16(fc_w, at<bf16>(A, b.wfc), 4 * E * E, 1.0f, s));
-    CHECK(pevit_launch_transpose_bf16(fc_w, 4 * (int)E, (int)E, at<bf16>(A, b.wfcT), 4 * (int)E, 0, 1.0f, s));
-    CHECK(pevit_launch_cast_bf16(pr_w, at<bf16>(A, b.wpr), 4 * E * E, 1.0f, s));
-    CHECK(pevit_launch_transpose_bf16(pr_w, (int)E, 4 * (int)E, at<bf16>(A, b.wprT), (int)E, 0, 1.0f, s));
+    if (c->fp8) {
+        typedef unsigned char u8;
+        const int e = (int)E;
+        HIP_OK(hipMemsetAsync(A + b.wqkv, 0, align_up(3 * E, 256) * E, s));
+        HIP_OK(hipMemsetAsync(A + b.wpan, 0, 128 * E * 2, s));
+        HIP_OK(hipMemsetAsync(A + b.wo, 0, align_up(E, 256) * E, s));
+        HIP_OK(hipMemsetAsync(A + b.woT, 0, align_up(E, 256) * E, s));
+        HIP_OK(hipMemsetAsync(A + b.wfc, 0, align_up(4 * E, 256) * E, s));
+        HIP_OK(hipMemsetAsync(A + b.wfcT, 0, align_up(E, 256) * 4 * E, s));
+        HIP_OK(hipMemsetAsync(A + b.wpr, 0, align_up(E, 256) * 4 * E, s));
+        HIP_OK(hipMemsetAsync(A + b.wprT, 0, align_up(4 * E, 256) * E, s));
+        CHECK(pevit_launch_quant_rows_fp8(in_w, 3 * e, e, at<u8>(A, b.wqkv), e, at<float>(A, b.sqkv), e, 0.125f, s));
+        CHECK(pevit_launch_quant_rows_fp8(out_w, e, e, at<u8>(A, b.wo), e, at<float>(A, b.so), 0, 1.0f, s));
+        CHECK(pevit_launch_quant_transpose_fp8(out_w, e, e, at<float>(A, b.so), at<u8>(A, b.woT), e, 0, 1.0f, s));
+        CHECK(pevit_launch_quant_rows_fp8(fc_w, 4 * e, e, at<u8>(A, b.wfc), e, at<float>(A, b.sfc), 0, 1.0f, s));
+        CHECK(pevit_launch_quant_transpose_fp8(fc_w, 4 * e, e, at<float>(A, b.sfc), at<u8>(A, b.wfcT), 4 * e, 0, 1.0f, s));
+        CHECK(pevit_launch_quant_rows_fp8(pr_w, e, 4 * e, at<u8>(A, b.wpr), 4 * e, at<float>(A, b.spr), 0, 1.0f, s));
+        CHECK(pevit_launch_quant_transpose_fp8(pr_w, e, 4 * e, at<float>(A, b.spr), at<u8>(A, b.wprT), e, 0, 1.0f, s));
+        // QKV backward (bf16): the transposed copy holds the DE-QUANTISED weights, exactly representable in bf16
+        HIP_OK(hipMemsetAsync(A + b.wqkvT, 0, E * (size_t)c->NQ * 2, s));
+        float* tmp = at<float>(c->ws, 0);       // 3E*E floats of the (not yet used) workspace
+        if ((size_t)3 * E * E * 4 > c->ws_bytes_for_max) { pevit_set_error("load_block: workspace too small for the fp8 packing scratch"); return -1; }
+        CHECK(pevit_launch_dequant_rows_fp8(at<u8>(A, b.wqkv), e, at<float>(A, b.sqkv), 3 * e, e, tmp, s));
+        CHECK(pevit_launch_transpose_bf16(tmp, 3 * e, e, at<bf16>(A, b.wqkvT), c->NQ, 0, 1.0f, s));
+    } else {
+        HIP_OK(hipMemsetAsync(A + b.wqkv, 0, (size_t)c->NQpad * E * 2, s));
+        CHECK(pevit_launch_cast_bf16(in_w, at<bf16>(A, b.wqkv), E * E, 0.125f, s));
+        CHECK(pevit_launch_cast_bf16(in_w + E * E, at<bf16>(A, b.wqkv) + E * E, 2 * E * E, 1.0f, s));
+        HIP_OK(hipMemsetAsync(A + b.wqkvT, 0, E * (size_t)c->NQ * 2, s));
+        CHECK(pevit_launch_transpose_bf16(in_w, 3 * (int)E, (int)E, at<bf16>(A, b.wqkvT), c->NQ, (int)E, 0.125f, s));
+        CHECK(pevit_launch_cast_bf16(out_w, at<bf16>(A, b.wo), E * E, 1.0f, s));
+        CHECK(pevit_launch_transpose_bf16(out_w, (int)E, (int)E, at<bf16>(A, b.woT), (int)E, 0, 1.0f, s));
+        CHECK(pevit_launch_cast_bf16(fc_w, at<bf16>(A, b.wfc), 4 * E * E, 1.0f, s));
+        CHECK(pevit_launch_transpose_bf16(fc_w, 4 * (int)E, (int)E, at<bf16>(A, b.wfcT), 4 * (int)E, 0, 1.0f, s));
+        CHECK(pevit_launch_cast_bf16(pr_w, at<bf16>(A, b.wpr), 4 * E * E, 1.0f, s));
+        CHECK(pevit_launch_transpose_bf16(pr_w, (int)E, 4 * (int)E, at<bf16>(A, b.wprT), (int)E, 0, 1.0f, s));
+    }
     // biases and LN affines stay f32; the q third of in_proj_bias carries the same 1/8
     HIP_OK(hipMemcpyAsync(A + b.bqkv, in_b, 3 * E * 4, hipMemcpyDeviceToDevice, s));
     CHECK(pevit_launch_scale_f32(at<float>(A, b.bqkv), E, 0.125f, s));
@@ -367,7 +419,7 @@ int check_ready(pevit_ctx* c, int B, const char* who) {
 AdapterPanels panels(pevit_ctx* c, int l) {
     const BlockArena& b = c->blk[l];
     AdapterPanels p;
-    p.w_aug_rows = at<bf16>(c->arena, b.wqkv) + (size_t)3 * c->E * c->E;
+    p.w_aug_rows = c->fp8 ? at<bf16>(c->arena, b.wpan) : at<bf16>(c->arena, b.wqkv) + (size_t)3 * c->E * c->E;
     p.ldw = c->E;
     p.wT_aug_cols = at<bf16>(c->arena, b.wqkvT) + 3 * c->E;
     p.ldwT = c->NQ;
@@ -407,7 +459,7 @@ int prep_adapters(pevit_ctx* c, hipStream_t s) {
 int gemm(pevit_ctx* c, int epi, const GemmParams& p, hipStream_t s) {
     const bool rec = c->prof_on && c->prof_n < c->prof_cap;
     if (rec) (void)hipEventRecord(c->prof_ev[2 * c->prof_n], s);
-    const int rc = pevit_launch_gemm(epi, p, s);
+    const int rc = pevit_launch_gemm(epi, p, c->tune, s);
     if (rec) {
         (void)hipEventRecord(c->prof_ev[2 * c->prof_n + 1], s);
         c->prof_flops[c->prof_n] = 2.0 * (double)p.M * (double)p.N * (double)p.K;
@@ -425,6 +477,17 @@ GemmParams gp(const bf16* A, int lda, const bf16* B, int ldb, int Nb, int M, int
     GemmParams p;
     memset(&p, 0, sizeof(p));
     p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.Nb = Nb; p.M = M; p.N = N; p.K = K;
+    return p;
+}
+
+// frozen weight operand of layer-l products: bf16, or e4m3 codes + channel scales (ctx->fp8).  `scale_off` = arena offset
+// of the per-output-channel scales for the FORWARD products, 0 for the dX products (their scales ride on the A operand).
+GemmParams gpw(const pevit_ctx* c, const bf16* A, int lda, size_t w_off, int ldb, int Nb, int M, int N, int K, size_t scale_off) {
+    GemmParams p = gp(A, lda, at<bf16>(c->arena, w_off), ldb, c->fp8 ? (int)align_up((size_t)Nb, 256) : Nb, M, N, K);
+    if (c->fp8) {
+        p.b_fp8 = 1;
+        p.bscale = scale_off ? at<float>(c->arena, scale_off) : nullptr;
+    }
     return p;
 }
 
@@ -450,11 +513,21 @@ int blocks_forward(pevit_ctx* c, hipStream_t s, int B, bool cls_only) {
         // x = x + attn(ln_1(x))                                         model.py:973
         CHECK(pevit_launch_ln_fwd(x_in, at<float>(A, b.ln1w), at<float>(A, b.ln1b), T, E, at<bf16>(W, v.xn1), nullptr,
                                   at<float>(W, v.mean1), at<float>(W, v.rstd1), s));
-        {
+        if (!c->fp8) {
             GemmParams p = gp(at<bf16>(W, v.xn1), E, at<bf16>(A, b.wqkv), E, c->NQpad, T, site ? c->NQ : 3 * E, E);
             p.bias = at<float>(A, b.bqkv); p.outb = qkv; p.head_stride = plane; p.outf = at<float>(W, v.t); p.ldo = 64;
             p.E = E; p.H = H; p.Ntok = N;
             CHECK(gemm(c, EPI_QKV_HEADS, p, s));
+        } else {
+            // fp8 codes for the 3E frozen rows; the 64 trainable adapter rows stay bf16 and get their own small product
+            GemmParams p = gpw(c, at<bf16>(W, v.xn1), E, b.wqkv, E, 3 * E, T, 3 * E, E, b.sqkv);
+            p.bias = at<float>(A, b.bqkv); p.outb = qkv; p.head_stride = plane; p.E = E; p.H = H; p.Ntok = N;
+            CHECK(gemm(c, EPI_QKV_HEADS, p, s));
+            if (site) {
+                GemmParams q = gp(at<bf16>(W, v.xn1), E, at<bf16>(A, b.wpan), E, 128, T, 64, E);
+                q.outf = at<float>(W, v.t); q.ldo = 64;
+                CHECK(gemm(c, EPI_F32, q, s));
+            }
         }
         if (site) {
             const float* bias = nullptr;
@@ -470,7 +543,7 @@ int blocks_forward(pevit_ctx* c, hipStream_t s, int B, bool cls_only) {
         const int R = cls ? B : T;
         const int rs = cls ? N * E : E;            // row stride of [T][E] buffers
         {
-            GemmParams p = gp(at<bf16>(W, v.attn_out), rs, at<bf16>(A, b.wo), E, E, R, E, E);
+            GemmParams p = gpw(c, at<bf16>(W, v.attn_out), rs, b.wo, E, E, R, E, E, b.so);
             p.bias = at<float>(A, b.bo); p.resid = x_in; p.ldr = rs; p.outf = x_mid; p.ldo = rs;
             CHECK(gemm(c, EPI_BIAS_RESID_F32, p, s));
         }
@@ -478,19 +551,19 @@ int blocks_forward(pevit_ctx* c, hipStream_t s, int B, bool cls_only) {
         CHECK(pevit_launch_ln_fwd(x_mid, at<float>(A, b.ln2w), at<float>(A, b.ln2b), R, E, at<bf16>(W, c->w_xn2), nullptr,
                                   at<float>(W, v.mean2), at<float>(W, v.rstd2), s, (size_t)rs));
         {
-            GemmParams p = gp(at<bf16>(W, c->w_xn2), E, at<bf16>(A, b.wfc), E, 4 * E, R, 4 * E, E);
+            GemmParams p = gpw(c, at<bf16>(W, c->w_xn2), E, b.wfc, E, 4 * E, R, 4 * E, E, b.sfc);
             p.bias = at<float>(A, b.bfc); p.outb = at<bf16>(W, v.h); p.ldob = 4 * E; p.outb2 = at<bf16>(W, c->w_g);
             p.ldob2 = 4 * E;
             CHECK(gemm(c, EPI_BIAS_GELU, p, s));
         }
         if (cls) {
-            GemmParams p = gp(at<bf16>(W, c->w_g), 4 * E, at<bf16>(A, b.wpr), 4 * E, E, R, E, 4 * E);
+            GemmParams p = gpw(c, at<bf16>(W, c->w_g), 4 * E, b.wpr, 4 * E, E, R, E, 4 * E, b.spr);
             p.bias = at<float>(A, b.bpr); p.resid = x_mid; p.ldr = rs; p.outf = x_out; p.ldo = rs;
             CHECK(gemm(c, EPI_BIAS_RESID_F32, p, s));
             continue;
         }
         if (!post_mlp(c)) {
-            GemmParams p = gp(at<bf16>(W, c->w_g), 4 * E, at<bf16>(A, b.wpr), 4 * E, E, T, E, 4 * E);
+            GemmParams p = gpw(c, at<bf16>(W, c->w_g), 4 * E, b.wpr, 4 * E, E, T, E, 4 * E, b.spr);
             p.bias = at<float>(A, b.bpr); p.resid = x_mid; p.ldr = E; p.outf = x_out; p.ldo = E;
             CHECK(gemm(c, EPI_BIAS_RESID_F32, p, s));
         } else {
@@ -541,7 +614,7 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0, bool cls_
     bf16* dyb = at<bf16>(W, c->w_dyb);
     float* dxn = at<float>(W, c->w_dxn);
     bf16* dqkv = at<bf16>(W, c->w_dqkv);
-    const bool use_side = g_side_stream && site;
+    const bool use_side = c->side_stream && site;
     bool side_pending = false;
     if (use_side && !c->side) {
         HIP_OK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
@@ -587,20 +660,24 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0, bool cls_
         const int rs = cls ? N * E : E;            // row stride of [T][E] buffers
         // ---- MLP branch: d h = (dy W_proj) * gelu'(h) ; d xn2 = d h W_fc
         {
-            GemmParams p = gp(mlp_dy, rs, at<bf16>(A, b.wprT), E, 4 * E, R, 4 * E, E);
+            // fp8: mlp_dy arrives with c_proj's channel scales folded in, and leaves with c_fc's (for the next product)
+            GemmParams p = gpw(c, mlp_dy, rs, b.wprT, E, 4 * E, R, 4 * E, E, 0);
             p.aux = at<bf16>(W, v.h); p.ldaux = 4 * E; p.outb = at<bf16>(W, c->w_dh); p.ldob = 4 * E;
+            if (c->fp8) p.oscale = at<float>(A, b.sfc);
             CHECK(gemm(c, EPI_DGELU_BF16, p, s));
         }
         {
-            GemmParams p = gp(at<bf16>(W, c->w_dh), 4 * E, at<bf16>(A, b.wfcT), 4 * E, E, R, E, 4 * E);
+            GemmParams p = gpw(c, at<bf16>(W, c->w_dh), 4 * E, b.wfcT, 4 * E, E, R, E, 4 * E, 0);
             p.outf = dxn; p.ldo = E;
             CHECK(gemm(c, EPI_F32, p, s));
         }
+        // fp8: the bf16 copy feeds the out-projection backward, whose contraction runs over out_proj's output channels
         CHECK(pevit_launch_ln_bwd(dxn, at<float>(W, v.x_mid), at<float>(W, v.mean2), at<float>(W, v.rstd2),
-                                  at<float>(A, b.ln2w), dxa, dxb, dyb, R, E, s, (size_t)rs));
+                                  at<float>(A, b.ln2w), dxa, dxb, dyb, R, E, s, (size_t)rs,
+                                  c->fp8 ? at<float>(A, b.so) : nullptr));
         // ---- attention branch
         {
-            GemmParams p = gp(dyb, rs, at<bf16>(A, b.woT), E, E, R, E, E);
+            GemmParams p = gpw(c, dyb, rs, b.woT, E, E, R, E, E, 0);
             p.outb = at<bf16>(W, c->w_dO); p.ldob = rs;
             CHECK(gemm(c, EPI_BF16, p, s));
         }
@@ -627,8 +704,10 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0, bool cls_
             GemmParams p = gp(dqkv, c->NQ, at<bf16>(A, b.wqkvT), c->NQ, E, T, E, site ? c->NQ : 3 * E);
             p.outf = dxn; p.ldo = E;
             CHECK(gemm(c, EPI_F32, p, s));
+            // fp8: this bf16 copy is the upstream gradient of layer l-1's c_proj backward
             CHECK(pevit_launch_ln_bwd(dxn, at<float>(W, v.x_in), at<float>(W, v.mean1), at<float>(W, v.rstd1),
-                                      at<float>(A, b.ln1w), dxb, dxa, dyb, T, E, s));
+                                      at<float>(A, b.ln1w), dxb, dxa, dyb, T, E, s, 0,
+                                      (c->fp8 && l > 0) ? at<float>(A, c->blk[l - 1].spr) : nullptr));
         }
     }
     if (side_pending) HIP_OK(hipStreamWaitEvent(s, c->ev_join, 0));
@@ -684,7 +763,11 @@ extern "C" int pevit_transformer_backward(pevit_ctx* c, void* stream, const floa
     hipStream_t s = (hipStream_t)stream;
     const size_t n = (size_t)B * c->N * c->E;
     CHECK(pevit_launch_permute_rows(dy_nbe, at<float>(c->ws, c->w_dxa), c->N, B, c->E, 1, s));
-    CHECK(pevit_launch_cast_bf16(at<float>(c->ws, c->w_dxa), at<bf16>(c->ws, c->w_dyb), n, 1.0f, s));
+    if (c->fp8)
+        CHECK(pevit_launch_cast_bf16_cols(at<float>(c->ws, c->w_dxa), at<bf16>(c->ws, c->w_dyb), (size_t)B * c->N, c->E,
+                                          at<float>(c->arena, c->blk[c->L - 1].spr), s));
+    else
+        CHECK(pevit_launch_cast_bf16(at<float>(c->ws, c->w_dxa), at<bf16>(c->ws, c->w_dyb), n, 1.0f, s));
     CHECK(blocks_backward(c, s, B, dx_nbe != nullptr, false));
     if (dx_nbe) CHECK(pevit_launch_permute_rows(at<float>(c->ws, c->w_dxa), dx_nbe, c->N, B, c->E, 0, s));
     return 0;
@@ -789,7 +872,8 @@ extern "C" int pevit_visual_backward(pevit_ctx* c, void* stream, const float* df
     }
     CHECK(pevit_launch_ln_bwd(at<float>(W, c->w_dxpost), at<float>(W, c->w_xfinal), at<float>(W, c->w_pmean),
                               at<float>(W, c->w_prstd), at<float>(A, c->a_lnpost_w), nullptr, at<float>(W, c->w_dxa),
-                              at<bf16>(W, c->w_dyb), B, E, s, (size_t)N * E));
+                              at<bf16>(W, c->w_dyb), B, E, s, (size_t)N * E,
+                              c->fp8 ? at<float>(A, c->blk[c->L - 1].spr) : nullptr));
     CHECK(blocks_backward(c, s, B, false, cls));
     return 0;
 }
@@ -874,7 +958,28 @@ extern "C" int pevit_op_gemm(void* stream, int epi, const void* A, int lda, cons
     p.bias = bias; p.resid = resid; p.ldr = ldr; p.outf = outf; p.ldo = ldo; p.outb = (bf16*)outb; p.ldob = ldob;
     p.outb2 = (bf16*)outb2; p.ldob2 = ldob2; p.aux = (const bf16*)aux; p.ldaux = ldaux; p.head_stride = head_stride;
     p.E = E; p.H = H; p.Ntok = tokens;
-    return pevit_launch_gemm(epi, p, (hipStream_t)stream);
+    return pevit_launch_gemm(epi, p, g_default_tune, (hipStream_t)stream);
+}
+extern "C" int pevit_op_gemm_fp8(void* stream, int epi, const void* A, int lda, const void* Bcodes, int ldb, int b_rows,
+                                 const float* bscale, const float* oscale, int M, int N, int K, const float* bias,
+                                 const float* resid, int ldr, float* outf, int ldo, void* outb, int ldob, void* outb2,
+                                 int ldob2, const void* aux, int ldaux, size_t head_stride, int E, int H, int tokens) {
+    GemmParams p = gp((const bf16*)A, lda, (const bf16*)Bcodes, ldb, b_rows, M, N, K);
+    p.b_fp8 = 1; p.bscale = bscale; p.oscale = oscale;
+    p.bias = bias; p.resid = resid; p.ldr = ldr; p.outf = outf; p.ldo = ldo; p.outb = (bf16*)outb; p.ldob = ldob;
+    p.outb2 = (bf16*)outb2; p.ldob2 = ldob2; p.aux = (const bf16*)aux; p.ldaux = ldaux; p.head_stride = head_stride;
+    p.E = E; p.H = H; p.Ntok = tokens;
+    return pevit_launch_gemm(epi, p, g_default_tune, (hipStream_t)stream);
+}
+extern "C" int pevit_op_quant_fp8(void* stream, const float* W, int rows, int cols, void* codes, float* scales,
+                                  void* codes_t) {
+    CHECK(pevit_launch_quant_rows_fp8(W, rows, cols, (unsigned char*)codes, cols, scales, 0, 1.0f, (hipStream_t)stream));
+    if (codes_t)
+        CHECK(pevit_launch_quant_transpose_fp8(W, rows, cols, scales, (unsigned char*)codes_t, rows, 0, 1.0f, (hipStream_t)stream));
+    return 0;
+}
+extern "C" int pevit_op_dequant_fp8(void* stream, const void* codes, const float* scales, int rows, int cols, float* out) {
+    return pevit_launch_dequant_rows_fp8((const unsigned char*)codes, cols, scales, rows, cols, out, (hipStream_t)stream);
 }
 extern "C" int pevit_op_ln_fwd(void* stream, const float* x, const float* gamma, const float* beta, int rows, int E,
                                void* y_bf16, float* y_f32, float* mean, float* rstd) {
@@ -883,6 +988,11 @@ extern "C" int pevit_op_ln_fwd(void* stream, const float* x, const float* gamma,
 extern "C" int pevit_op_ln_bwd(void* stream, const float* dy, const float* x, const float* mean, const float* rstd,
                                const float* gamma, const float* dres, float* dx, void* dx_bf16, int rows, int E) {
     return pevit_launch_ln_bwd(dy, x, mean, rstd, gamma, dres, dx, (bf16*)dx_bf16, rows, E, (hipStream_t)stream);
+}
+extern "C" int pevit_op_ln_bwd_scaled(void* stream, const float* dy, const float* x, const float* mean, const float* rstd,
+                                      const float* gamma, const float* dres, float* dx, void* dx_bf16, int rows, int E,
+                                      const float* bf16_colscale) {
+    return pevit_launch_ln_bwd(dy, x, mean, rstd, gamma, dres, dx, (bf16*)dx_bf16, rows, E, (hipStream_t)stream, 0, bf16_colscale);
 }
 extern "C" int pevit_op_attn_fwd(void* stream, const void* q, const void* k, const void* v, void* out, int ldo,
                                  float* lse, int B, int H, int N) {
@@ -912,17 +1022,15 @@ extern "C" int pevit_op_lowrank_grad(void* stream, const void* xn, int ldx, cons
                                      pevit_lowrank_chunks(B * N), B, H, N, E, (hipStream_t)stream);
 }
 extern "C" int pevit_op_lowrank_chunks(int T) { return pevit_lowrank_chunks(T); }
-extern "C" int pevit_tune(const char* key, int value) {
-    if (key && !strcmp(key, "gemm_config")) { pevit_gemm_set_variant(value); return 0; }
-    if (key && !strcmp(key, "gemm_persistent")) { pevit_gemm_set_persistent(value); return 0; }
-    if (key && !strcmp(key, "gemm_hoist")) { pevit_gemm_set_hoist(value); return 0; }
-    if (key && !strcmp(key, "gemm_ablate")) { pevit_gemm_set_ablate(value); return 0; }
-    if (key && !strcmp(key, "gemm_ring")) { pevit_gemm_set_ring(value); return 0; }
-    if (key && !strcmp(key, "gemm_kswitch")) { pevit_gemm_set_kswitch(value); return 0; }
-    if (key && !strcmp(key, "gemm_256")) { pevit_gemm_set_256(value); return 0; }
-    if (key && !strcmp(key, "side_stream")) { g_side_stream = value; return 0; }
-    if (key && !strcmp(key, "gemm_dephase")) { pevit_gemm_set_dephase(value); return 0; }
-    if (key && !strcmp(key, "attn_bwd_phase")) { pevit_attn_set_bwd_phase(value); return 0; }
+extern "C" int pevit_tune(pevit_ctx* c, const char* key, int value) {
+    GemmTune& t = c ? c->tune : g_default_tune;
+    if (key && !strcmp(key, "gemm_config")) { t.config = value; return 0; }
+    if (key && !strcmp(key, "gemm_persistent")) { t.persistent = value; return 0; }
+    if (key && !strcmp(key, "gemm_ablate")) { t.ablate = value; return 0; }
+    if (key && !strcmp(key, "gemm_kswitch")) { t.kswitch = value; return 0; }
+    if (key && !strcmp(key, "gemm_big")) { t.big = value; return 0; }
+    if (key && !strcmp(key, "gemm_big_bias")) { t.big_bias = value; return 0; }
+    if (key && c && !strcmp(key, "side_stream")) { c->side_stream = value; return 0; }
     pevit_set_error("tune: unknown key %s", key ? key : "(null)");
     return -1;
 }

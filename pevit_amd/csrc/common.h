@@ -26,6 +26,17 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 extern "C" void pevit_set_error(const char* fmt, ...);
 
+// after every kernel launch: a failed launch (bad grid, LDS over-subscription, ...) must not return 0
+// through the C ABI.  hipGetLastError also clears the sticky error.
+#define LAUNCH_OK(what)                                                               \
+    do {                                                                              \
+        hipError_t _e = hipGetLastError();                                            \
+        if (_e != hipSuccess) {                                                       \
+            pevit_set_error("%s: kernel launch failed: %s", what, hipGetErrorString(_e)); \
+            return -1;                                                                \
+        }                                                                             \
+    } while (0)
+
 __device__ __forceinline__ float bf2f(bf16 v) { return (float)v; }
 __device__ __forceinline__ bf16 f2bf(float v) { return (bf16)v; }
 

@@ -20,7 +20,10 @@ enum GemmEpilogue {
 
 struct GemmParams {
     const bf16* A; int lda;
-    const bf16* B; int ldb; int Nb;   // Nb = readable rows of B (>= N)
+    const void* B; int ldb; int Nb;   // Nb = readable rows of B (>= N); ldb in elements (bf16, or fp8 codes)
+    int b_fp8;                        // B holds e4m3 codes, k-permuted per 128 (fp8_kperm), K % 128 == 0
+    const float* bscale;              // fp8 B: per-output-channel (power-of-two) scale, applied to the accumulator
+    const float* oscale;              // EPI_DGELU_BF16 only: per-column factor folded into the bf16 output (or null)
     int M, N, K;
     const float* bias;
     const float* resid; int ldr;
@@ -32,19 +35,21 @@ struct GemmParams {
     // head-layout epilogue
     size_t head_stride;   // elements between the q, k and v planes
     int E, H, Ntok;
-    int dbg;              // measurement only: bit 0 skips the k-loop, bit 1 skips the epilogue stores
-    int dephase;          // start delay (x 512 clk) of the second half of the grid, see gemm.hip
+    int dbg;              // measurement only: bit 0 skips the k-loop, bit 1 the epilogue stores, bit 2 the operand stream, bit 3 ds_read + MFMA
 };
 
-int pevit_launch_gemm(int epi, const GemmParams& p, hipStream_t stream);
-int pevit_gemm_set_persistent(int v);
-int pevit_gemm_set_hoist(int v);
-int pevit_gemm_set_ablate(int v);
-int pevit_gemm_set_ring(int v);
-int pevit_gemm_set_kswitch(int v);
-int pevit_gemm_set_256(int v);
-int pevit_gemm_set_dephase(int v);
-int pevit_gemm_set_variant(int v);   // -1: heuristic, >= 0: forced tile configuration; returns the previous value
+// A/B-measurement knobs.  They live in the context (pevit_tune(ctx, ...)); the single-kernel pevit_op_* entry
+// points use one process-wide default instance.
+struct GemmTune {
+    int config = -1;      // -1: per-problem heuristic, >= 0: force a tile configuration (gemm.hip kConfigs)
+    int persistent = 1;
+    int ablate = 0;       // GemmParams::dbg
+    int kswitch = 2048;   // K from which the few-tile problems use the 128x128 tile instead of 64x128
+    int big = 1;          // allow the 8-wave tiles
+    int big_bias = 100;   // the 8-wave tile is taken when its stream cost is below big_bias % of the 128x128 tiling's
+};
+
+int pevit_launch_gemm(int epi, const GemmParams& p, const GemmTune& t, hipStream_t stream);
 
 // ---- norm.hip --------------------------------------------------------------------
 // y = LN(x) * gamma + beta over the last dim (eps 1e-5, f32 statistics: model.py:154-160)
@@ -54,7 +59,7 @@ int pevit_launch_ln_fwd(const float* x, const float* gamma, const float* beta, i
 // dx_out = dres + LN-backward(dy)   (gamma/beta frozen: no parameter grads)
 int pevit_launch_ln_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
                         const float* gamma, const float* dres, float* dx_out, bf16* dx_bf16, int rows, int E,
-                        hipStream_t s, size_t xstride = 0);
+                        hipStream_t s, size_t xstride = 0, const float* bf16_colscale = nullptr);
 
 // ---- attention.hip ---------------------------------------------------------------
 // q,k,v: (B*H, N, 64) bf16 (q pre-scaled by 1/8, deltas already added); out: rows (b*N+n), cols h*64+d
@@ -64,8 +69,6 @@ int pevit_launch_attn_fwd(const bf16* q, const bf16* k, const bf16* v, bf16* out
 int pevit_launch_attn_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* out, int ldo,
                           const bf16* dout, int lddo, const float* lse, bf16* dqkv, int ld,
                           int B, int H, int N, hipStream_t s);
-
-int pevit_attn_set_bwd_phase(int v);
 
 // ---- lowrank.hip -----------------------------------------------------------------
 struct AdapterPanels {      // per layer, rewritten every step from the f32 master parameters
@@ -115,6 +118,15 @@ int pevit_launch_permute_rows(const float* src, float* dst, int N, int B, int E,
 int pevit_launch_scale_f32(float* p, size_t n, float scale, hipStream_t s);
 int pevit_launch_sgd(float* p, const float* g, float* mom, const unsigned char* has_grad, size_t n,
                      float lr, float momentum, float wd, int first_step, float grad_scale, hipStream_t s);
+
+// ---- fp8.hip (e4m3 codes + power-of-two channel scales of the frozen weights) -----------------
+int pevit_launch_quant_rows_fp8(const float* W, int rows, int cols, unsigned char* out, int ldo, float* scale, int scaled_rows,
+                                float pre, hipStream_t s);
+int pevit_launch_quant_transpose_fp8(const float* W, int rows, int cols, const float* scale, unsigned char* outT, int ldo,
+                                     int scaled_rows, float pre, hipStream_t s);
+int pevit_launch_cast_bf16_cols(const float* src, bf16* dst, size_t rows, int cols, const float* colscale, hipStream_t s);
+int pevit_launch_dequant_rows_fp8(const unsigned char* codes, int ldc, const float* scale, int rows, int cols, float* out,
+                                  hipStream_t s);
 
 // ---- stem_head.hip -----------------------------------------------------------------
 int pevit_launch_im2col(const float* img, bf16* out, int B, int R, int P, int Kp, hipStream_t s);

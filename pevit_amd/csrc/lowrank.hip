@@ -459,6 +459,7 @@ int pevit_launch_prep_kadapt(const float* rule1_l, const float* rule1_r, const f
     if (E % 32) { pevit_set_error("prep_kadapt: width %d not divisible by phm_dim 32", E); return -1; }
     hipLaunchKernelGGL(prep_kadapt_kernel, dim3(ceil_div(E * 32, 256), layers), dim3(256), 0, s, rule1_l, rule1_r,
                        rule2_l, rule2_r, q_left, q_right, pan, E, ascale, st);
+    LAUNCH_OK("prep_kadapt_kernel");
     return 0;
 }
 
@@ -467,6 +468,7 @@ int pevit_launch_prep_lora(const float* a1q, const float* a2q, const float* a1v,
     if (r < 1 || r > 32) { pevit_set_error("prep_lora: rank %d outside [1,32]", r); return -1; }
     hipLaunchKernelGGL(prep_lora_kernel, dim3(ceil_div(E * 32, 256), layers), dim3(256), 0, s, a1q, a2q, a1v, a2v, r,
                        pan, E, ascale, st);
+    LAUNCH_OK("prep_lora_kernel");
     return 0;
 }
 
@@ -477,6 +479,7 @@ int pevit_launch_delta_add(bf16* qbuf, bf16* vbuf, const float* t, const float* 
     const int waves = ceil_div(T, 16 * DA_RG) * (E / DA_COLS);
     hipLaunchKernelGGL(delta_add_kernel, dim3(ceil_div(waves, 4), 2), dim3(256), 0, s, qbuf, vbuf, t, q32, bias, ascale,
                        B, N, E);
+    LAUNCH_OK("delta_add_kernel");
     return 0;
 }
 
@@ -485,6 +488,7 @@ int pevit_launch_lowrank_u(const bf16* dqkv, int ld, const bf16* qT, float* u32,
     const int T = B * N;
     hipLaunchKernelGGL(lowrank_u_kernel, dim3(ceil_div(T, 16)), dim3(256), 0, s, dqkv, ld, qT, u32, u_bf16_cols, B, H,
                        N, E);
+    LAUNCH_OK("lowrank_u_kernel");
     return 0;
 }
 
@@ -498,6 +502,7 @@ int pevit_launch_lowrank_grad(const bf16* xn, int ldx, const float* u32, const b
     if (E % 64) { pevit_set_error("lowrank_grad: width %d must be a multiple of 64", E); return -1; }
     hipLaunchKernelGGL(lowrank_grad_kernel, dim3(chunks * (E / 64) * 3), dim3(256), 0, s, xn, ldx, u32, dqkv, ld, t,
                        partial, dbias_partial, B, H, N, E);
+    LAUNCH_OK("lowrank_grad_kernel");
     return 0;
 }
 
@@ -509,12 +514,15 @@ int pevit_launch_chain_kadapt(const float* partial, size_t partial_layer, const 
     float* g_b = grads + p_layer0 + 4 * (size_t)E;
     hipLaunchKernelGGL(lowrank_reduce_kernel, dim3(ceil_div(4 * E * 32, 256), layers), dim3(256), 0, s, partial,
                        dbias_partial, chunks, G, g_b, E, partial_layer, dbias_layer, p_layer_stride);
+    LAUNCH_OK("lowrank_reduce_kernel");
     const float* r = params;
     const float* lp = params + p_layer0;
     float* lg = grads + p_layer0;
     hipLaunchKernelGGL(chain_kadapt_kernel, dim3(32, layers), dim3(256), 4 * E * sizeof(float), s, G, ascale, r, r + 1024,
                        r + 2048, r + 3072, lp, lp + E, rule_scratch, lg, lg + E, E, p_layer_stride);
+    LAUNCH_OK("chain_kadapt_kernel");
     hipLaunchKernelGGL(rule_sum_kernel, dim3(16), dim3(256), 0, s, rule_scratch, grads, layers);
+    LAUNCH_OK("rule_sum_kernel");
     return 0;
 }
 
@@ -522,9 +530,11 @@ int pevit_launch_chain_lora(const float* partial, size_t partial_layer, int chun
                             float* G, float* grads, size_t p_layer0, size_t p_layer_stride, int E, hipStream_t s) {
     hipLaunchKernelGGL(lowrank_reduce_kernel, dim3(ceil_div(4 * E * 32, 256), layers), dim3(256), 0, s, partial,
                        (const float*)nullptr, chunks, G, (float*)nullptr, E, partial_layer, (size_t)0, (size_t)0);
+    LAUNCH_OK("lowrank_reduce_kernel");
     const size_t rE = (size_t)r * E;
     float* lg = grads + p_layer0;
     hipLaunchKernelGGL(chain_lora_kernel, dim3(ceil_div(E * r, 256), layers), dim3(256), 0, s, G, ascale, r, lg, lg + rE,
                        lg + 2 * rE, lg + 3 * rE, E, p_layer_stride);
+    LAUNCH_OK("chain_lora_kernel");
     return 0;
 }

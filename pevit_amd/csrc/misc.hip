@@ -73,6 +73,7 @@ int pevit_launch_cast_bf16(const float* src, bf16* dst, size_t n, float scale, h
     const int blocks = (int)((n / 4 + 255) / 256);
     hipLaunchKernelGGL(cast_bf16_kernel, dim3(blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks)), dim3(256), 0, s, src,
                        dst, n, scale);
+    LAUNCH_OK("cast_bf16_kernel");
     return 0;
 }
 
@@ -80,18 +81,21 @@ int pevit_launch_transpose_bf16(const float* src, int rows, int cols, bf16* dst,
                                 hipStream_t s) {
     hipLaunchKernelGGL(transpose_bf16_kernel, dim3(ceil_div(cols, 32), ceil_div(rows, 32)), dim3(256), 0, s, src, rows,
                        cols, dst, ldd, scaled_rows, scale);
+    LAUNCH_OK("transpose_bf16_kernel");
     return 0;
 }
 
 int pevit_launch_permute_rows(const float* src, float* dst, int N, int B, int E, int to_internal, hipStream_t s) {
     if (E % 4) { pevit_set_error("permute_rows: width %d must be a multiple of 4", E); return -1; }
     hipLaunchKernelGGL(permute_rows_kernel, dim3(N * B), dim3(192), 0, s, src, dst, N, B, E, to_internal);
+    LAUNCH_OK("permute_rows_kernel");
     return 0;
 }
 
 int pevit_launch_scale_f32(float* p, size_t n, float scale, hipStream_t s) {
     if (n == 0) return 0;
     hipLaunchKernelGGL(scale_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, n, scale);
+    LAUNCH_OK("scale_f32_kernel");
     return 0;
 }
 
@@ -100,5 +104,6 @@ int pevit_launch_sgd(float* p, const float* g, float* mom, const unsigned char* 
     if (n == 0) return 0;
     hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, g, mom, has_grad, n, lr,
                        momentum, wd, first_step, grad_scale);
+    LAUNCH_OK("sgd_kernel");
     return 0;
 }

@@ -68,7 +68,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                      const float* __restrict__ gamma, const float* dres,
-                                                     float* dx, bf16* __restrict__ dx_bf16, int rows, int E, size_t xstride) {
+                                                     float* dx, bf16* __restrict__ dx_bf16, int rows, int E, size_t xstride,
+                                                     const float* __restrict__ bscale) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -107,6 +108,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
             }
             *reinterpret_cast<float4*>(dx + xb + c) = o;
             if (dx_bf16) {
+                // fp8 weights: the consuming GEMM contracts over these columns; their power-of-two channel
+                // scales are folded into its bf16 operand here (exact), the f32 stream stays unscaled
+                if (bscale) {
+                    const float4 sc = *reinterpret_cast<const float4*>(bscale + c);
+                    o.x *= sc.x; o.y *= sc.y; o.z *= sc.z; o.w *= sc.w;
+                }
                 bf16x4 ob;
                 ob[0] = f2bf(o.x); ob[1] = f2bf(o.y); ob[2] = f2bf(o.z); ob[3] = f2bf(o.w);
                 *reinterpret_cast<bf16x4*>(dx_bf16 + xb + c) = ob;
@@ -124,16 +131,18 @@ int pevit_launch_ln_fwd(const float* x, const float* gamma, const float* beta, i
     if (rows <= 0) return 0;
     hipLaunchKernelGGL(ln_fwd_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, s, x, gamma, beta, rows, E, xstride,
                        y_bf16, y_f32, mean, rstd);
+    LAUNCH_OK("ln_fwd_kernel");
     return 0;
 }
 
 int pevit_launch_ln_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                         const float* dres, float* dx_out, bf16* dx_bf16, int rows, int E, hipStream_t s,
-                        size_t xstride) {
+                        size_t xstride, const float* bf16_colscale) {
     if (xstride == 0) xstride = (size_t)E;
     if (E % 4 != 0 || E > 256 * MAXV) { pevit_set_error("ln_bwd: unsupported width %d", E); return -1; }
     if (rows <= 0) return 0;
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, s, dy, x, mean, rstd, gamma, dres,
-                       dx_out, dx_bf16, rows, E, xstride);
+                       dx_out, dx_bf16, rows, E, xstride, bf16_colscale);
+    LAUNCH_OK("ln_bwd_kernel");
     return 0;
 }

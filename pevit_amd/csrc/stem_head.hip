@@ -217,14 +217,17 @@ int pevit_launch_im2col(const float* img, bf16* out, int B, int R, int P, int Kp
     const size_t total = (size_t)B * (R / P) * (R / P) * (Kp / 2);
     const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
     hipLaunchKernelGGL(im2col_kernel, dim3(blocks), dim3(256), 0, s, img, out, B, R, P, Kp);
+    LAUNCH_OK("im2col_kernel");
     return 0;
 }
 int pevit_launch_conv_weight(const float* w, bf16* out, int E, int K, int Kp, hipStream_t s) {
     hipLaunchKernelGGL(conv_weight_kernel, dim3((unsigned)(((size_t)E * Kp + 255) / 256)), dim3(256), 0, s, w, out, E, K, Kp);
+    LAUNCH_OK("conv_weight_kernel");
     return 0;
 }
 int pevit_launch_cls_row(const float* cls, const float* pos, float* x, int B, int N, int E, hipStream_t s) {
     hipLaunchKernelGGL(cls_row_kernel, dim3(B), dim3(256), 0, s, cls, pos, x, B, N, E);
+    LAUNCH_OK("cls_row_kernel");
     return 0;
 }
 int pevit_launch_head(const float* feat, const int64_t* labels, const float* W, const float* bias, float* gW, float* gb,
@@ -232,22 +235,29 @@ int pevit_launch_head(const float* feat, const int64_t* labels, const float* W, 
                       float* dlogits, float* dybn, float* loss, float* dfeat, int B, int D, int Cc, hipStream_t s) {
     hipLaunchKernelGGL(bn_fwd_kernel, dim3(ceil_div(D, 64)), dim3(256), 0, s, feat, ybn, rstd, running_mean, running_var,
                        training, B, D);
+    LAUNCH_OK("bn_fwd_kernel");
     {   // logits[b][c] = ybn[b] . W[c] + bias[c]
         SmallGemm g{ybn, D, 1, W, 1, D, logits, Cc, bias, nullptr, B, Cc, D, 0};
         hipLaunchKernelGGL(small_gemm_kernel, dim3(ceil_div(Cc, 32), ceil_div(B, 32)), dim3(256), 0, s, g);
+        LAUNCH_OK("small_gemm_kernel");
     }
     if (!labels) return 0;
     float* rowloss = dybn;      // dybn is written later (by the dgrad product); reuse its head as scratch
     hipLaunchKernelGGL(ce_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, s, logits, labels, dlogits, rowloss, B, Cc);
+    LAUNCH_OK("ce_kernel");
     hipLaunchKernelGGL(loss_mean_kernel, dim3(1), dim3(64), 0, s, rowloss, loss, B);
+    LAUNCH_OK("loss_mean_kernel");
     if (gW) {   // gW[c][d] += sum_b dl[b][c] ybn[b][d] ; gb[c] += sum_b dl[b][c]
         SmallGemm g{dlogits, 1, Cc, ybn, D, 1, gW, D, nullptr, gb, Cc, D, B, 1};
         hipLaunchKernelGGL(small_gemm_kernel, dim3(ceil_div(D, 32), ceil_div(Cc, 32)), dim3(256), 0, s, g);
+        LAUNCH_OK("small_gemm_kernel");
     }
     if (dfeat) {   // dybn[b][d] = sum_c dl[b][c] W[c][d]
         SmallGemm g{dlogits, Cc, 1, W, D, 1, dybn, D, nullptr, nullptr, B, D, Cc, 0};
         hipLaunchKernelGGL(small_gemm_kernel, dim3(ceil_div(D, 32), ceil_div(B, 32)), dim3(256), 0, s, g);
+        LAUNCH_OK("small_gemm_kernel");
         hipLaunchKernelGGL(bn_bwd_kernel, dim3(ceil_div(D, 64)), dim3(256), 0, s, dybn, ybn, rstd, dfeat, training, B, D);
+        LAUNCH_OK("bn_bwd_kernel");
     }
     return 0;
 }

@@ -76,16 +76,19 @@ def _numel(shape):
 
 class HipEngine:
     def __init__(self, arch: VitArch, method: str, num_classes: int, max_batch: int, lora_rank: int = 4,
-                 device: str | torch.device = "cuda:0"):
+                 device: str | torch.device = "cuda:0", weight_format: str = "bf16"):
         if not torch.cuda.is_available():
             raise _lib.PevitError("HipEngine needs a ROCm GPU (gfx950); there is no CPU fallback")
         self.lib = _lib.load()
         self.arch, self.method, self.num_classes = arch, method, num_classes
         self.lora_rank, self.max_batch = lora_rank, max_batch
+        if weight_format not in _lib.WEIGHT_FORMATS:
+            raise ValueError(f"weight_format {weight_format!r}: expected one of {sorted(_lib.WEIGHT_FORMATS)}")
+        self.weight_format = weight_format
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
         dims = _lib.PevitDims(arch.width, arch.layers, arch.patch, arch.resolution, arch.embed_dim,
-                              _lib.METHOD_IDS[method], lora_rank, num_classes)
+                              _lib.METHOD_IDS[method], lora_rank, num_classes, _lib.WEIGHT_FORMATS[weight_format])
         self._ctx = C.c_void_p()
         _lib.check(self.lib.pevit_ctx_create(C.byref(dims), C.byref(self._ctx)), "pevit_ctx_create")
         self.arena = torch.zeros(self.lib.pevit_arena_bytes(self._ctx), dtype=torch.uint8, device=self.device)
@@ -122,6 +125,10 @@ class HipEngine:
                 self._ctx = None
         except Exception:
             pass
+
+    def tune(self, key: str, value: int) -> int:
+        """A/B-measurement knob of THIS context (include/pevit_hip.h: pevit_tune)."""
+        return self.lib.pevit_tune(self._ctx, key.encode(), int(value))
 
     def ensure_batch(self, batch: int):
         """Grow the activation workspace so that steps of ``batch`` images fit (re-binds; weights stay)."""

@@ -1,0 +1,264 @@
+"""fp8 frozen weights (BASELINE config 5: ViT-L/14 + KAdaptation, e4m3 codes with per-output-channel scales, bf16
+activations, f32 accumulation).
+
+Parity statement of BASELINE.md section 3: "fp8-weight config compared against a bf16 run of the same de-quantised
+weights".  Because the channel scales are powers of two, de-quantisation is exact in bf16 and commutes with every
+rounding on the path, so the comparison is held to BIT-IDENTITY -- kernel level (GEMM, every tile configuration and
+epilogue the fp8 path uses) and step level (logits, loss, every gradient) up to the full ViT-L/14 at the per-GPU shard
+size of config 5.  The packing itself is checked against torch.float8_e4m3fn, and the fp8 engine additionally against
+the CPU oracle run on the de-quantised weights (same calibrated bf16 gates as tests/test_gpu_tower.py).
+"""
+import ctypes as C
+
+import pytest
+import torch
+
+from conftest import max_rel, rel_err
+
+pytestmark = pytest.mark.gpu
+
+EPI = dict(QKV=0, BIAS_RESID=1, BIAS_GELU=2, DGELU=3, F32=4, BF16=5)
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from pevit_amd import _lib
+    return _lib.load()
+
+
+def P(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def S():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ok(lib, rc):
+    assert rc == 0, lib.pevit_last_error().decode()
+
+
+def rnd(*shape, scale=1.0, seed=0, dtype=torch.float32):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).cuda()
+
+
+def quant(lib, W, transposed=False):
+    rows, cols = W.shape
+    pad = (rows + 255) // 256 * 256
+    codes = torch.zeros((pad, cols), dtype=torch.uint8, device="cuda")
+    scales = torch.zeros(rows, device="cuda")
+    codes_t = torch.zeros(((cols + 255) // 256 * 256, rows), dtype=torch.uint8, device="cuda") if transposed else None
+    ok(lib, lib.pevit_op_quant_fp8(S(), P(W), rows, cols, P(codes), P(scales), P(codes_t)))
+    torch.cuda.synchronize()
+    return codes, scales, codes_t
+
+
+@pytest.mark.parametrize("rows,cols", [(128, 128), (384, 256), (1024, 4096)])
+def test_packing_matches_torch_float8(lib, rows, cols):
+    from pevit_amd import fp8
+    W = rnd(rows, cols, seed=3) * torch.logspace(-4, 2, rows, device="cuda")[:, None]
+    W[5] = 0.0
+    codes, scales, codes_t = quant(lib, W, transposed=True)
+    ref_codes, ref_scales = fp8.quantize_rows(W.cpu())
+    assert torch.equal(scales.cpu(), ref_scales)
+    perm = fp8.kperm(cols)
+    unperm = torch.empty_like(codes[:rows].cpu())
+    unperm[:, torch.arange(cols)] = codes[:rows].cpu()[:, perm]
+    # e4m3 has +0 and -0: compare as values, and as codes wherever the value is non-zero
+    a, b = unperm.view(torch.float8_e4m3fn).float(), ref_codes.view(torch.float8_e4m3fn).float()
+    assert torch.equal(a, b)
+    permr = fp8.kperm(rows)
+    t = codes_t[:cols].cpu()[:, permr].view(torch.float8_e4m3fn).float()
+    assert torch.equal(t, b.T)
+    out = torch.empty((rows, cols), device="cuda")
+    ok(lib, lib.pevit_op_dequant_fp8(S(), P(codes), P(scales), rows, cols, P(out)))
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), fp8.dequantize_rows(ref_codes, ref_scales))
+
+
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 3, 4, 5])
+@pytest.mark.parametrize("M,N,K", [(700, 640, 256), (6400, 768, 768), (257, 384, 128), (1300, 1024, 1024)])
+def test_gemm_fp8_is_bit_identical_to_bf16_on_dequantised_weights(lib, cfg, M, N, K):
+    from pevit_amd import fp8
+    A = rnd(M, K, seed=1, dtype=torch.bfloat16)
+    W = rnd(N, K, seed=2, scale=0.05) * torch.logspace(-2, 1, N, device="cuda")[:, None]
+    bias = rnd(N, seed=5, scale=0.1)
+    resid = rnd(M, N, seed=6)
+    codes, scales, _ = quant(lib, W)
+    Wd = fp8.dequantize_rows(*fp8.quantize_rows(W.cpu())).cuda()
+    Wb = torch.zeros((codes.shape[0], K), dtype=torch.bfloat16, device="cuda")
+    Wb[:N] = Wd.to(torch.bfloat16)
+    assert torch.equal(Wb[:N].float(), Wd)
+    assert lib.pevit_tune(None, b"gemm_config", cfg) == 0
+    try:
+        def both(epi, **kw):
+            outs = []
+            for f8 in (True, False):
+                o = {k: (v.clone() if v is not None else None) for k, v in kw.items()}
+                if f8:
+                    ok(lib, lib.pevit_op_gemm_fp8(S(), epi, P(A), K, P(codes), K, codes.shape[0], P(scales), P(o.get("oscale")),
+                                                  M, N, K, P(bias), P(resid), N, P(o.get("outf")), N, P(o.get("outb")), N,
+                                                  P(o.get("outb2")), N, P(o.get("aux")), N, 0, 0, 0, 0))
+                else:
+                    ok(lib, lib.pevit_op_gemm(S(), epi, P(A), K, P(Wb), K, Wb.shape[0], M, N, K, P(bias), P(resid), N,
+                                              P(o.get("outf")), N, P(o.get("outb")), N, P(o.get("outb2")), N, P(o.get("aux")), N,
+                                              0, 0, 0, 0))
+                torch.cuda.synchronize()
+                outs.append(o)
+            return outs
+        z32 = torch.full((M, N), float("nan"), device="cuda")
+        z16 = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
+        f, b = both(EPI["BIAS_RESID"], outf=z32)
+        assert torch.equal(f["outf"], b["outf"])
+        assert max_rel(f["outf"].cpu(), (A.float() @ Wd.T + bias + resid).cpu()) < 2e-4
+        f, b = both(EPI["BIAS_GELU"], outb=z16, outb2=z16)
+        assert torch.equal(f["outb"], b["outb"]) and torch.equal(f["outb2"], b["outb2"])
+        f, b = both(EPI["F32"], outf=z32)
+        assert torch.equal(f["outf"], b["outf"])
+        f, b = both(EPI["BF16"], outb=z16)
+        assert torch.equal(f["outb"], b["outb"])
+        aux = rnd(M, N, seed=9, dtype=torch.bfloat16)
+        f, b = both(EPI["DGELU"], outb=z16, aux=aux)
+        assert torch.equal(f["outb"], b["outb"])
+    finally:
+        lib.pevit_tune(None, b"gemm_config", -1)
+
+
+def test_backward_form_column_scales_ride_on_the_a_operand(lib):
+    """dX = dY W through the transposed code matrix: the contraction runs over W's output channels, whose power-of-two
+    scales are folded into dY by its producer (the DGELU epilogue's `oscale`, LayerNorm backward's column scale).
+    Result must equal the bf16 product with the de-quantised W, bit for bit."""
+    from pevit_amd import fp8
+    M, Nout, Kin = 900, 512, 384            # W: [Nout][Kin]; dY: [M][Nout]; dX: [M][Kin]
+    W = rnd(Nout, Kin, seed=2, scale=0.05) * torch.logspace(-1, 1, Nout, device="cuda")[:, None]
+    codes, scales, codes_t = quant(lib, W, transposed=True)
+    Wd = fp8.dequantize_rows(*fp8.quantize_rows(W.cpu())).cuda()
+    dY = rnd(M, Nout, seed=4)
+    # producer 1: LayerNorm backward with the column scale on its bf16 output
+    x = rnd(M, Nout, seed=5); gamma = rnd(Nout, seed=6) + 1.0
+    mean = x.mean(1); rstd = (x.var(1, unbiased=False) + 1e-5).rsqrt()
+    dx = torch.empty_like(x); dxb_s = torch.zeros((M, Nout), dtype=torch.bfloat16, device="cuda"); dxb = torch.zeros_like(dxb_s)
+    ok(lib, lib.pevit_op_ln_bwd_scaled(S(), P(dY), P(x), P(mean), P(rstd), P(gamma), None, P(dx), P(dxb_s), M, Nout, P(scales)))
+    ok(lib, lib.pevit_op_ln_bwd(S(), P(dY), P(x), P(mean), P(rstd), P(gamma), None, P(dx), P(dxb), M, Nout))
+    torch.cuda.synchronize()
+    assert torch.equal(dxb_s.float(), dxb.float() * scales)            # exact: powers of two
+    out8 = torch.zeros((M, Kin), device="cuda"); out16 = torch.zeros_like(out8)
+    ok(lib, lib.pevit_op_gemm_fp8(S(), EPI["F32"], P(dxb_s), Nout, P(codes_t), Nout, codes_t.shape[0], None, None, M, Kin, Nout,
+                                  None, None, 0, P(out8), Kin, None, 0, None, 0, None, 0, 0, 0, 0, 0))
+    WdT = torch.zeros((codes_t.shape[0], Nout), dtype=torch.bfloat16, device="cuda")
+    WdT[:Kin] = Wd.T.to(torch.bfloat16)
+    ok(lib, lib.pevit_op_gemm(S(), EPI["F32"], P(dxb), Nout, P(WdT), Nout, WdT.shape[0], M, Kin, Nout, None, None, 0, P(out16), Kin,
+                              None, 0, None, 0, None, 0, 0, 0, 0, 0))
+    torch.cuda.synchronize()
+    assert torch.equal(out8, out16)
+
+
+def _engines(arch_name, method, B, classes=10, lora_r=4, seed=2):
+    """(fp8 engine on sd, bf16 engine on the de-quantised sd, de-quantised sd)"""
+    from pevit_amd import fp8
+    from pevit_amd.engine import HipEngine, adapter_param_spec
+    from pevit_amd.synth import ARCHS, randomize_adapters, synth_state_dict
+    arch = ARCHS[arch_name]
+    sd = {k: v for k, v in synth_state_dict(arch, seed=seed, text_tower=False).items() if k.startswith("visual.")}
+    ad = [(n, torch.zeros(s)) for n, s, _ in adapter_param_spec(method, arch.width, arch.layers, lora_r)]
+    randomize_adapters(ad, seed=3)
+    sd.update(dict(ad))
+    sdq = fp8.dequantized_state_dict(sd)
+    e8 = HipEngine(arch, method, classes, B, lora_rank=lora_r, weight_format="fp8")
+    e8.load_state_dict(sd)
+    e16 = HipEngine(arch, method, classes, B, lora_rank=lora_r)
+    e16.load_state_dict(sdq)
+    g = torch.Generator().manual_seed(5)
+    D = arch.embed_dim
+    hw = ((torch.rand((classes, D), generator=g) * 2 - 1) / D ** 0.5).cuda()
+    hb = ((torch.rand((classes,), generator=g) * 2 - 1) / D ** 0.5).cuda()
+    for e in (e8, e16):
+        v = e.param_views()
+        with torch.no_grad():
+            v["layers.0.weight"].copy_(hw); v["layers.0.bias"].copy_(hb)
+    return arch, e8, e16, sdq, hw, hb
+
+
+@pytest.mark.parametrize("arch_name,method,B", [("tiny-128", "kadaptation", 6), ("tiny-256", "lora", 5), ("tiny-n257", "kadaptation", 8),
+                                                 ("tiny-256", "none", 4)])
+def test_fp8_step_is_bit_identical_to_bf16_step_on_dequantised_weights(arch_name, method, B):
+    from pevit_amd.synth import synth_batch
+    arch, e8, e16, sdq, hw, hb = _engines(arch_name, method, B)
+    images, labels = synth_batch(B, arch.resolution, 10, seed_img=3, seed_lbl=4)
+    images, labels = images.cuda(), labels.cuda()
+    l8, loss8 = e8.forward_backward(images, labels); l8 = l8.clone(); loss8 = float(loss8)
+    l16, loss16 = e16.forward_backward(images, labels)
+    torch.cuda.synchronize()
+    assert torch.equal(l8, l16) and loss8 == float(loss16)
+    assert torch.equal(e8.grads, e16.grads)
+    assert float(e8.grads.abs().max()) > 0
+    # and the operator seam (Transformer.forward / backward, (N,B,E) rows) incl. dX
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(arch.tokens, B, arch.width, generator=g).cuda()
+    dy = torch.randn(arch.tokens, B, arch.width, generator=g).cuda()
+    y8, y16 = e8.transformer_forward(x), e16.transformer_forward(x)
+    e8.zero_grad(); e16.zero_grad()
+    dx8, dx16 = e8.transformer_backward(dy), e16.transformer_backward(dy)
+    torch.cuda.synchronize()
+    assert torch.equal(y8, y16) and torch.equal(dx8, dx16) and torch.equal(e8.grads, e16.grads)
+
+
+def test_fp8_rejects_post_mlp_adapters():
+    from pevit_amd import _lib
+    from pevit_amd.engine import HipEngine
+    from pevit_amd.synth import ARCHS
+    with pytest.raises(_lib.PevitError, match="fp8 weights"):
+        HipEngine(ARCHS["tiny-128"], "adapter", 10, 4, weight_format="fp8")
+
+
+def test_config5_vit_l14_fp8_bs8_vs_bf16_engine_and_oracle():
+    """BASELINE config 5 architecture at full width/depth (1024 x 24 layers, N=257, patch 14), KAdaptation, batch 8:
+    fp8 engine == bf16 engine on the de-quantised weights (bit-identical), and both within the calibrated bf16 gates of
+    the CPU oracle run in f32 on those same de-quantised weights."""
+    from test_gpu_tower import bf16_noise, tol, DEEP_LOGIT_TOL, DEEP_GRAD_TOL
+    from pevit_amd.synth import synth_batch
+    B, C = 8, 10
+    arch, e8, e16, sdq, hw, hb = _engines("ViT-L/14", "kadaptation", B, classes=C)
+    images, labels = synth_batch(B, arch.resolution, C, seed_img=3, seed_lbl=4)
+    l8, loss8 = e8.forward_backward(images.cuda(), labels.cuda()); l8 = l8.clone(); loss8 = float(loss8)
+    l16, loss16 = e16.forward_backward(images.cuda(), labels.cuda())
+    torch.cuda.synchronize()
+    assert torch.equal(l8, l16) and loss8 == float(loss16) and torch.equal(e8.grads, e16.grads)
+    tr, ref_logits, ref_loss, logit_noise, noise = bf16_noise(sdq, "kadaptation", C, images, labels, hw.cpu(), hb.cpu())
+    assert max_rel(l8.cpu(), ref_logits) < tol(DEEP_LOGIT_TOL, logit_noise)
+    # mean cross-entropy is 2-Lipschitz in the sup norm of the logits: the loss may move by at most twice what the
+    # (gated) logits moved -- on this random-weight 24-layer tower bf16 operand rounding alone moves them by ~10 %
+    assert abs(loss8 - float(ref_loss)) <= 2.0 * float((l8.cpu() - ref_logits).abs().max()) + 1e-5
+    gv = e8.grad_views()
+    worst = max(noise.values())
+    for k in tr.names:
+        if tr.p[k].grad is None:
+            assert float(gv[k].abs().max()) == 0.0
+        else:
+            err = rel_err(gv[k].cpu(), tr.p[k].grad)
+            assert err < tol(DEEP_GRAD_TOL, noise[k], worst), (k, err, noise[k])
+
+
+def test_config5_vit_l14_fp8_per_gpu_shard_bs32():
+    """The per-GPU shard of config 5 (256 / 8 = 32 images): fp8 == bf16-on-dequantised bit for bit at the full size, the
+    step is deterministic, and a few SGD steps reduce the loss."""
+    from pevit_amd.synth import reference_init_, synth_batch
+    B, C = 32, 100
+    arch, e8, e16, sdq, hw, hb = _engines("ViT-L/14", "kadaptation", B, classes=C)
+    images, labels = synth_batch(B, arch.resolution, C)
+    images, labels = images.cuda(), labels.cuda()
+    l8, loss8 = e8.forward_backward(images, labels); l8 = l8.clone(); g8 = e8.grads.clone(); loss8 = float(loss8)
+    l16, loss16 = e16.forward_backward(images, labels)
+    torch.cuda.synchronize()
+    assert torch.equal(l8, l16) and loss8 == float(loss16) and torch.equal(g8, e16.grads)
+    del e16
+    l8b, _ = e8.forward_backward(images, labels)
+    assert torch.equal(l8, l8b) and torch.equal(g8, e8.grads)
+    reference_init_(e8.param_views().items(), "kadaptation")
+    with torch.no_grad():
+        e8.param_views()["layers.0.bias"].zero_()
+    losses = [float(e8.train_step(images, labels, lr=0.05, momentum=0.9, weight_decay=0.0)[1]) for _ in range(6)]
+    assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < 0.7 * losses[0], losses

@@ -66,6 +66,33 @@ def test_gemm_f32_and_bf16(lib, M, N, K):
     assert max_rel(outb.float().cpu(), ref.cpu()) < 1e-2
 
 
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("M,N,K", [(6400, 768, 768), (700, 2368, 256), (257, 136, 64), (1300, 640, 1024)])
+def test_gemm_every_tile_config_is_bit_identical(lib, cfg, M, N, K):
+    """The six tile configurations (4-wave 128x128 / 64x128 / 64x64, 8-wave 256x128 / 256x256 / 320x256) walk K in the
+    same order, so forcing any of them must reproduce the heuristic's result bit for bit -- partial tiles in M and N,
+    several tiles per persistent workgroup (M=6400 at 64x64) and the fused epilogues included."""
+    A = rnd(M, K, seed=1, dtype=torch.bfloat16)
+    B = rnd(N, K, seed=2, scale=0.05, dtype=torch.bfloat16)
+    bias = rnd(N, seed=5, scale=0.1)
+    resid = rnd(M, N, seed=6)
+    ref = A.float() @ B.float().T
+    outs = []
+    for c in (cfg, -1):
+        assert lib.pevit_tune(None, b"gemm_config", c) == 0
+        try:
+            o1 = torch.full((M, N), float("nan"), device="cuda")
+            gemm(lib, EPI["BIAS_RESID"], A, B, M, N, K, bias=bias, resid=resid, outf=o1)
+            h = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda"); g = torch.zeros_like(h)
+            gemm(lib, EPI["BIAS_GELU"], A, B, M, N, K, bias=bias, outb=h, outb2=g)
+        finally:
+            lib.pevit_tune(None, b"gemm_config", -1)
+        outs.append((o1, h, g))
+    assert max_rel(outs[0][0].cpu(), (ref + bias + resid).cpu()) < 2e-4
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 def test_gemm_detects_transposes_with_identity(lib):
     """A = I (padded) with an asymmetric B must reproduce B^T exactly (cdna guide: asymmetric check)."""
     K = 128

@@ -57,10 +57,11 @@ def bf16_noise(sd, method, classes, images, labels, head_w, head_b):
             lg, ls = tr.loss_and_grads(images, labels)
         return tr, lg, ls
     f32, l32, loss32 = run(False)
-    emu, lemu, _ = run(True)
+    emu, lemu, lemu_loss = run(True)
     errs = {n: rel_err(emu.p[n].grad, f32.p[n].grad) for n in f32.names if f32.p[n].grad is not None}
     errs["layers.0.weight"] = rel_err(emu.head_w.grad, f32.head_w.grad)
     errs["layers.0.bias"] = rel_err(emu.head_b.grad, f32.head_b.grad)
+    bf16_noise.last_loss_err = abs(float(lemu_loss) - float(loss32))      # same measure for the scalar loss
     return f32, l32, loss32, max_rel(lemu, l32), errs
 
 
