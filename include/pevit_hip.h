@@ -173,9 +173,11 @@ int pevit_op_lowrank_grad(void* stream, const void* xn, int ldx, const float* u3
 int pevit_op_lowrank_chunks(int T);
 /* knobs for A/B measurements, held in the context (ctx == NULL: the process-wide defaults that only the
  * context-free pevit_op_* entry points above use): "gemm_config" (-1 = per-problem heuristic, 0..5 = force a tile
- * configuration: 128x128, 64x128, 64x64 with 4 waves; 256x128, 256x256, 320x256 with 8 waves), "gemm_persistent",
- * "gemm_big" (0 = never pick the 8-wave tiles), "gemm_big_bias", "gemm_kswitch", "gemm_ablate" (bit 0 skips the
- * k-loop, bit 1 the epilogue stores), "side_stream" (ctx only); returns 0, or -1 for an unknown key */
+ * configuration: 128x128, 64x128, 64x64 with 4 waves; 256x128, 256x256, 320x256 with 8 waves; 6 = 128x64 with 4 waves),
+ * "gemm_persistent", "gemm_big" (0 = never pick the 8-wave tiles), "gemm_big_bias", "gemm_kswitch", "gemm_cfg_longk" /
+ * "gemm_cfg_shortk" (configuration of the few-tile problems above / below kswitch), "gemm_ablate" (bit 0 skips the
+ * k-loop, bit 1 the epilogue stores, bit 2 the operand stream, bit 3 ds_read + MFMA), "side_stream" (ctx only);
+ * returns 0, or -1 for an unknown key */
 int pevit_tune(pevit_ctx* ctx, const char* key, int value);
 
 #ifdef __cplusplus

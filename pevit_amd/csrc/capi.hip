@@ -1029,6 +1029,8 @@ extern "C" int pevit_tune(pevit_ctx* c, const char* key, int value) {
     if (key && !strcmp(key, "gemm_ablate")) { t.ablate = value; return 0; }
     if (key && !strcmp(key, "gemm_kswitch")) { t.kswitch = value; return 0; }
     if (key && !strcmp(key, "gemm_big")) { t.big = value; return 0; }
+    if (key && !strcmp(key, "gemm_cfg_longk")) { t.cfg_longk = value; return 0; }
+    if (key && !strcmp(key, "gemm_cfg_shortk")) { t.cfg_shortk = value; return 0; }
     if (key && !strcmp(key, "gemm_big_bias")) { t.big_bias = value; return 0; }
     if (key && c && !strcmp(key, "side_stream")) { c->side_stream = value; return 0; }
     pevit_set_error("tune: unknown key %s", key ? key : "(null)");

@@ -218,7 +218,7 @@ typedef __attribute__((ext_vector_type(4))) int i32x4;
 // WGM x WGN waves, each owning WM x WN fragments of 32x32.  MINW = waves per SIMD the register
 // allocation must allow (= workgroups per CU x waves per workgroup / 4).
 // LDS: [A stage 0][B stage 0][A stage 1][B stage 1], rows of 128 bytes (64 bf16 / 128 fp8).
-template <int EPI, int WGM, int WGN, int WM, int WN, int MINW, bool HOIST, bool BF8>
+template <int EPI, int WGM, int WGN, int WM, int WN, int MINW, bool HOIST, bool BF8, bool SPREAD>
 __global__ __launch_bounds__(WGM * WGN * 64, MINW) void gemm_kernel(GemmParams p, int ntiles) {
     constexpr int NW = WGM * WGN;
     constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32, BK = 64;
@@ -303,6 +303,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, MINW) void gemm_kernel(GemmParams p
             constexpr int NG = KS * WM, NP = PA + PB;       // MFMA groups per k-tile, pieces per wave
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            if constexpr (ISSUE && !SPREAD) issue_tile(kt + 1);
             const char* sa = smem + (kt & 1) * STAGE_BYTES;
             const char* sb = smem + ((BF8 ? (kt >> 1) : kt) & 1) * STAGE_BYTES;
             if (p.dbg & 8) {                                // measurement only: operand stream without ds_read / MFMA
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, MINW) void gemm_kernel(GemmParams p
                 for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                     for (int i = 0; i < WM; ++i) {
-                        if constexpr (ISSUE) {
+                        if constexpr (ISSUE && SPREAD) {
 #pragma unroll
                             for (int q = 0; q < NP; ++q)
                                 if (q * NG / NP == ks * WM + i) issue_piece(kt + 1, q);
@@ -360,7 +361,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, MINW) void gemm_kernel(GemmParams p
                     }
 #pragma unroll
                     for (int i = 0; i < WM; ++i) {
-                        if constexpr (ISSUE) {
+                        if constexpr (ISSUE && SPREAD) {
 #pragma unroll
                             for (int q = 0; q < NP; ++q)
                                 if (q * NG / NP == ks * WM + i) issue_piece(kt + 1, q);
@@ -419,14 +420,18 @@ __global__ __launch_bounds__(WGM * WGN * 64, MINW) void gemm_kernel(GemmParams p
 }
 
 // wgm x wgn waves of wm x wn fragments; wgs = workgroups per CU the LDS and registers are sized for
-struct TileConfig { int wgm, wgn, wm, wn, wgs; bool hoist; };
+struct TileConfig { int wgm, wgn, wm, wn, wgs; bool hoist, spread; };
 constexpr TileConfig kConfigs[] = {
-    {2, 2, 2, 2, 2, true},    // 0: 128x128, 4 waves, 64 KiB, 2 workgroups / CU
-    {2, 2, 1, 2, 3, true},    // 1:  64x128, 4 waves, 48 KiB, 3 workgroups / CU
-    {2, 2, 1, 1, 4, false},   // 2:  64x64,  4 waves, 32 KiB, 4 workgroups / CU (bottleneck products, N <= 64)
-    {4, 2, 2, 2, 1, true},    // 3: 256x128, 8 waves, 96 KiB, 1 workgroup / CU
-    {2, 4, 4, 2, 1, false},   // 4: 256x256, 8 waves, 128 KiB
-    {2, 4, 5, 2, 1, false},   // 5: 320x256, 8 waves, 144 KiB
+    // 4-wave tiles request the next k-tile in one burst: with 2-4 workgroups per CU another workgroup computes while
+    // this one sits in its issue slots, and in the step the burst measured 3 % faster than the spread order
+    // (5.59 vs 5.75 ms per step, profiles/r02_step_ab.md); the 8-wave tiles (one workgroup per CU) spread it.
+    {2, 2, 2, 2, 2, true, false},   // 0: 128x128, 4 waves, 64 KiB, 2 workgroups / CU
+    {2, 2, 1, 2, 3, true, false},   // 1:  64x128, 4 waves, 48 KiB, 3 workgroups / CU
+    {2, 2, 1, 1, 4, false, false},  // 2:  64x64,  4 waves, 32 KiB, 4 workgroups / CU (bottleneck products, N <= 64)
+    {4, 2, 2, 2, 1, true, true},    // 3: 256x128, 8 waves, 96 KiB, 1 workgroup / CU
+    {2, 4, 4, 2, 1, false, true},   // 4: 256x256, 8 waves, 128 KiB
+    {2, 4, 5, 2, 1, false, true},   // 5: 320x256, 8 waves, 144 KiB
+    {2, 2, 2, 1, 3, true, false},   // 6: 128x64,  4 waves, 48 KiB, 3 workgroups / CU
 };
 constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 constexpr int cfg_bm(int c) { return kConfigs[c].wgm * kConfigs[c].wm * 32; }
@@ -438,7 +443,7 @@ int launch_cfg(const GemmParams& p, const GemmTune& t, hipStream_t stream) {
     constexpr int nw = c.wgm * c.wgn, bm = cfg_bm(CFG), bn = cfg_bn(CFG);
     constexpr int lds = 2 * (bm + bn) * 128;
     constexpr int minw = c.wgs * nw / 4;
-    auto kern = gemm_kernel<EPI, c.wgm, c.wgn, c.wm, c.wn, minw, c.hoist, BF8>;
+    auto kern = gemm_kernel<EPI, c.wgm, c.wgn, c.wm, c.wn, minw, c.hoist, BF8, c.spread>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
@@ -490,8 +495,8 @@ int pick_config(const GemmParams& p, const GemmTune& t) {
         }
     }
     const long t128 = (long)ceil_div(p.M, 128) * ceil_div(p.N, 128);
-    if (t128 >= 700 || p.K >= t.kswitch) return 0;
-    return 1;
+    if (t128 >= 700) return 0;
+    return p.K >= t.kswitch ? t.cfg_longk : t.cfg_shortk;
 }
 
 template <int EPI, bool BF8>
@@ -502,6 +507,7 @@ int launch_epi(const GemmParams& p, const GemmTune& t, hipStream_t stream) {
         case 2: return launch_cfg<EPI, 2, BF8>(p, t, stream);
         case 3: return launch_cfg<EPI, 3, BF8>(p, t, stream);
         case 4: return launch_cfg<EPI, 4, BF8>(p, t, stream);
+        case 6: return launch_cfg<EPI, 6, BF8>(p, t, stream);
         default: return launch_cfg<EPI, 5, BF8>(p, t, stream);
     }
 }

@@ -46,6 +46,7 @@ struct GemmTune {
     int ablate = 0;       // GemmParams::dbg
     int kswitch = 2048;   // K from which the few-tile problems use the 128x128 tile instead of 64x128
     int big = 1;          // allow the 8-wave tiles
+    int cfg_longk = 0, cfg_shortk = 1;   // tile configuration of the few-tile problems (N = 768 at M = 6400): K >= kswitch / K < kswitch
     int big_bias = 100;   // the 8-wave tile is taken when its stream cost is below big_bias % of the 128x128 tiling's
 };
 

@@ -79,7 +79,7 @@ def test_packing_matches_torch_float8(lib, rows, cols):
     assert torch.equal(out.cpu(), fp8.dequantize_rows(ref_codes, ref_scales))
 
 
-@pytest.mark.parametrize("cfg", [-1, 0, 1, 3, 4, 5])
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 3, 4, 5, 6])
 @pytest.mark.parametrize("M,N,K", [(700, 640, 256), (6400, 768, 768), (257, 384, 128), (1300, 1024, 1024)])
 def test_gemm_fp8_is_bit_identical_to_bf16_on_dequantised_weights(lib, cfg, M, N, K):
     from pevit_amd import fp8
