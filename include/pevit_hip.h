@@ -115,6 +115,14 @@ int pevit_transformer_backward(pevit_ctx* ctx, void* stream, const float* dy_nbe
 int pevit_visual_forward(pevit_ctx* ctx, void* stream, const float* images, float* feat, int batch,
                          int save_for_backward);
 int pevit_visual_backward(pevit_ctx* ctx, void* stream, const float* dfeat, int batch);
+/* the same backward cut at a block boundary: blocks layer_hi-1 .. layer_lo, whose adapter gradients are complete in
+ * the flat buffer when the call's work has run (data parallelism all-reduces them while the next part runs).  The part
+ * with layer_hi == layers takes dfeat; parts must be issued top-down and cover [0, layers) exactly once.  The shared
+ * phm_rule gradients (KAdaptation) are complete after the part with layer_lo == 0. */
+int pevit_visual_backward_part(pevit_ctx* ctx, void* stream, const float* dfeat_or_null, int batch, int layer_hi,
+                               int layer_lo);
+/* float offset of block `layer`'s parameters in the flat buffer (layer == layers: the head weight) */
+size_t pevit_param_layer_offset(const pevit_ctx* ctx, int layer);
 /* BatchNorm1d(D, affine=False) -> Linear(D, C) -> mean cross-entropy, forward + backward.
  * bn_training: batch statistics + running-stat update (momentum 0.1); else running stats.
  * Writes logits (B x C), loss (1), dfeat (B x D); accumulates head grads into the flat buffer. */
@@ -171,6 +179,27 @@ int pevit_op_lowrank_u(void* stream, const void* dqkv, int ld, const void* qT, f
 int pevit_op_lowrank_grad(void* stream, const void* xn, int ldx, const float* u32, const void* dqkv, int ld,
                           const float* t, float* partial, float* dbias_partial, int B, int H, int N, int E);
 int pevit_op_lowrank_chunks(int T);
+/* post-MLP bottleneck adapters (adapter_model.py:264-282, compacter_model.py:302-308,432-448), one layer:
+ * G[e][j] = sum_r X[r][e] Y[r][j] as per-chunk partials [chunks][E][64] (+ column sums of X / Y, may be NULL) */
+int pevit_op_tn_chunks(int T);
+int pevit_op_tn_gemm64(void* stream, const void* X_bf16, int ldx, const void* Y_bf16, int ldy, float* partial, float* csx,
+                       float* csy, int T, int E);
+/* LayerNorm backward with trainable affine: dx = dres + LN'(dy); partial[blocks][3][E] = sums of dy*xhat, dy, dres */
+int pevit_op_lna_blocks(int rows);
+int pevit_op_ln_bwd_affine(void* stream, const float* dy, const float* x, const float* mean, const float* rstd,
+                           const float* gamma, const float* dres, float* dx, void* dx_bf16, float* partial, int rows, int E);
+/* out0[i] += sum_c partial[c][i]  (i < n), or with three outputs partial[c][3][n] -> out0/1/2; deterministic */
+int pevit_op_colsum_reduce(void* stream, const float* partial, int chunks, int n, float* out0, float* out1, float* out2);
+/* f32 master parameters -> bf16 panels wd [64][E], wdT [E][64], wu [E][64], wuT [64][E].  Adapter: p0 = down.weight
+ * (64,E), p1 = up.weight (E,64).  Compacter: rule (4,4,4), p0..p3 = down.W_left, down.W_right, up.W_left, up.W_right */
+int pevit_op_prep_bottleneck(void* stream, int method, const float* rule, const float* p0, const float* p1, const float* p2,
+                             const float* p3, void* wd, void* wdT, void* wu, void* wuT, int E);
+/* chain rule from the dense panel gradients Gd, Gu ([E][64] each) onto the reference's tensors inside `grads`
+ * (accumulating) at float offsets off0.. (Adapter: down.weight, up.weight; Compacter: the four W_left / W_right) */
+int pevit_op_chain_bottleneck(void* stream, int method, const float* Gd, const float* Gu, const float* rule,
+                              const float* params, float* grads, int E, size_t off0, size_t off1, size_t off2, size_t off3);
+/* images (B,3,R,R) f32 -> patches [B*(R/P)^2][Kpad] bf16, k = c*P*P + py*P + px, zero padded (conv1, model.py:1036) */
+int pevit_op_im2col(void* stream, const float* images, void* patches_bf16, int B, int R, int P, int Kpad);
 /* knobs for A/B measurements, held in the context (ctx == NULL: the process-wide defaults that only the
  * context-free pevit_op_* entry points above use): "gemm_config" (-1 = per-problem heuristic, 0..5 = force a tile
  * configuration: 128x128, 64x128, 64x64 with 4 waves; 256x128, 256x256, 320x256 with 8 waves; 6 = 128x64 with 4 waves),

@@ -47,6 +47,8 @@ SIGNATURES = {
     "pevit_transformer_backward": (c_int, [P, P, P, P, c_int]),
     "pevit_visual_forward": (c_int, [P, P, P, P, c_int, c_int]),
     "pevit_visual_backward": (c_int, [P, P, P, c_int]),
+    "pevit_visual_backward_part": (c_int, [P, P, P, c_int, c_int, c_int]),
+    "pevit_param_layer_offset": (c_size_t, [P, c_int]),
     "pevit_head_forward_backward": (c_int, [P, P, P, P, P, P, c_int, P, P, P, c_int]),
     "pevit_zero_grads": (c_int, [P, P]),
     "pevit_sgd_step": (c_int, [P, P, c_float, c_float, c_float, c_float, c_int]),
@@ -69,6 +71,14 @@ SIGNATURES = {
     "pevit_op_lowrank_u": (c_int, [P, P, c_int, P, P, P, c_int, c_int, c_int, c_int]),
     "pevit_op_lowrank_grad": (c_int, [P, P, c_int, P, P, c_int, P, P, P, c_int, c_int, c_int, c_int]),
     "pevit_op_lowrank_chunks": (c_int, [c_int]),
+    "pevit_op_tn_chunks": (c_int, [c_int]),
+    "pevit_op_tn_gemm64": (c_int, [P, P, c_int, P, c_int, P, P, P, c_int, c_int]),
+    "pevit_op_lna_blocks": (c_int, [c_int]),
+    "pevit_op_ln_bwd_affine": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int]),
+    "pevit_op_colsum_reduce": (c_int, [P, P, c_int, c_int, P, P, P]),
+    "pevit_op_prep_bottleneck": (c_int, [P, c_int, P, P, P, P, P, P, P, P, P, c_int]),
+    "pevit_op_chain_bottleneck": (c_int, [P, c_int, P, P, P, P, P, c_int, c_size_t, c_size_t, c_size_t, c_size_t]),
+    "pevit_op_im2col": (c_int, [P, P, P, c_int, c_int, c_int, c_int]),
     "pevit_tune": (c_int, [P, c_char_p, c_int]),
 }
 

@@ -85,6 +85,7 @@ struct pevit_ctx {
     size_t p_layer0 = 0, p_layer_stride = 0;     // offsets in floats
     size_t p_head_w = 0, p_head_b = 0;
     int saved_batch = 0;
+    int saved_kind = 0;       // which forward the saved activations belong to: 1 = transformer seam, 2 = visual (class-token pruned)
     // optional per-GEMM timing (HIP events on the caller's stream), see pevit_profile_begin
     bool prof_on = false;
     int prof_n = 0, prof_cap = 0;
@@ -312,6 +313,11 @@ extern "C" size_t pevit_workspace_bytes(const pevit_ctx* c, int batch) {
 }
 extern "C" size_t pevit_num_tower_params(const pevit_ctx* c) { return c ? c->n_tower : 0; }
 extern "C" size_t pevit_num_params(const pevit_ctx* c) { return c ? c->n_total : 0; }
+extern "C" size_t pevit_param_layer_offset(const pevit_ctx* c, int layer) {
+    if (!c) return 0;
+    if (layer >= c->L) return c->n_tower;
+    return c->p_layer0 + c->p_layer_stride * (size_t)(layer < 0 ? 0 : layer);
+}
 
 extern "C" int pevit_param_grad_mask(const pevit_ctx* c, unsigned char* m, size_t n) {
     if (!c || !m || n != c->n_total) { pevit_set_error("param_grad_mask: size mismatch"); return -1; }
@@ -603,7 +609,10 @@ int blocks_forward(pevit_ctx* c, hipStream_t s, int B, bool cls_only) {
 // On exit ws+w_dxa holds dL/dx_0 if need_dx0.
 // cls_only mirrors blocks_forward: on entry only the class-token rows of dxa / dyb are defined (and
 // read); dxb and dO must have been zeroed by the caller.
-int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0, bool cls_only) {
+// Layers l_hi-1 .. l_lo are processed (the whole tower: L, 0) and the adapter gradients of exactly these layers are
+// reduced and chained onto the reference's tensors at the end -- data parallelism runs the tower in two halves so that
+// the all-reduce of the upper half's gradients overlaps the backward of the lower half.
+int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0, bool cls_only, int l_hi, int l_lo) {
     const int E = c->E, T = B * c->N, H = c->H, N = c->N;
     cls_only = cls_only && !post_mlp(c);
     char* W = c->ws; char* A = c->arena;
@@ -621,7 +630,7 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0, bool cls_
         HIP_OK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         HIP_OK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     }
-    for (int l = c->L - 1; l >= 0; --l) {
+    for (int l = l_hi - 1; l >= l_lo; --l) {
         const BlockArena& b = c->blk[l];
         const LayerSaved& v = c->sav[l];
         bf16* qkv = at<bf16>(W, v.qkv);
@@ -711,33 +720,42 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0, bool cls_
         }
     }
     if (side_pending) HIP_OK(hipStreamWaitEvent(s, c->ev_join, 0));
-    // adapter gradients of all layers: reduce the partials and chain onto the reference's tensors
+    // adapter gradients of layers [l_lo, l_hi): reduce the partials and chain onto the reference's tensors
+    const int nl = l_hi - l_lo;
+    const size_t pl0 = c->p_layer0 + c->p_layer_stride * l_lo;          // first float of layer l_lo's parameters
+    if (nl <= 0) return 0;
     if (c->d.method == PEVIT_KADAPTATION) {
-        CHECK(pevit_launch_chain_kadapt(at<float>(W, c->w_partial), c->partial_layer / 4, at<float>(W, c->w_dbias),
-                                        c->dbias_layer / 4, chunks, c->ascale, c->L, at<float>(W, c->w_G),
-                                        at<float>(W, c->w_rule), c->params, c->grads, c->p_layer0, c->p_layer_stride, E, s));
+        CHECK(pevit_launch_chain_kadapt(at<float>(W, c->w_partial + (size_t)l_lo * c->partial_layer), c->partial_layer / 4,
+                                        at<float>(W, c->w_dbias + (size_t)l_lo * c->dbias_layer), c->dbias_layer / 4, chunks,
+                                        c->ascale, nl, at<float>(W, c->w_G) + (size_t)l_lo * 4 * E * 32,
+                                        at<float>(W, c->w_rule) + (size_t)l_lo * 4096, c->params, c->grads, pl0, c->p_layer_stride, E, s));
+        // the shared rule factors collect from every layer: summed once, in layer order, when the last range is done
+        if (l_lo == 0) CHECK(pevit_launch_rule_sum(at<float>(W, c->w_rule), c->grads, c->L, s));
     } else if (c->d.method == PEVIT_LORA) {
-        CHECK(pevit_launch_chain_lora(at<float>(W, c->w_partial), c->partial_layer / 4, chunks, c->ascale, c->d.lora_rank,
-                                      c->L, at<float>(W, c->w_G), c->grads, c->p_layer0, c->p_layer_stride, E, s));
+        CHECK(pevit_launch_chain_lora(at<float>(W, c->w_partial + (size_t)l_lo * c->partial_layer), c->partial_layer / 4, chunks,
+                                      c->ascale, c->d.lora_rank, nl, at<float>(W, c->w_G) + (size_t)l_lo * 4 * E * 32, c->grads, pl0,
+                                      c->p_layer_stride, E, s));
     } else if (post_mlp(c)) {
         const int tch = pevit_tn_chunks(T), lnb = pevit_lna_blocks(T);
         const size_t ps = c->p_layer_stride, gl = (size_t)E * 64;
-        float* g0 = c->grads + c->p_layer0;
-        HIP_OK(hipMemsetAsync(W + c->w_Gd, 0, (size_t)c->L * gl * 4 * 2, s));       // Gd and Gu are adjacent
-        CHECK(pevit_launch_colsum_reduce(at<float>(W, c->w_tnD), tch, (int)gl, at<float>(W, c->w_Gd), c->L, c->tn_layer / 4, gl, s));
-        CHECK(pevit_launch_colsum_reduce(at<float>(W, c->w_tnU), tch, (int)gl, at<float>(W, c->w_Gu), c->L, c->tn_layer / 4, gl, s));
+        float* g0 = c->grads + pl0;
+        float* Gd = at<float>(W, c->w_Gd) + (size_t)l_lo * gl;
+        float* Gu = at<float>(W, c->w_Gu) + (size_t)l_lo * gl;
+        HIP_OK(hipMemsetAsync(Gd, 0, (size_t)nl * gl * 4, s));
+        HIP_OK(hipMemsetAsync(Gu, 0, (size_t)nl * gl * 4, s));
+        CHECK(pevit_launch_colsum_reduce(at<float>(W, c->w_tnD + (size_t)l_lo * c->tn_layer), tch, (int)gl, Gd, nl, c->tn_layer / 4, gl, s));
+        CHECK(pevit_launch_colsum_reduce(at<float>(W, c->w_tnU + (size_t)l_lo * c->tn_layer), tch, (int)gl, Gu, nl, c->tn_layer / 4, gl, s));
         // biases and LayerNorm affine: straight column sums into the flat gradient buffer
         // d b_up from the f32 column sums of the upstream gradient (third plane of the LN partials)
-        CHECK(pevit_launch_colsum_reduce(at<float>(W, c->w_csy), tch, 64, g0 + c->o_db, c->L, c->csy_layer / 4, ps, s));
-        CHECK(pevit_launch_colsum_reduce3(at<float>(W, c->w_lnp), lnb, E, g0 + c->o_nw, g0 + c->o_nb, g0 + c->o_ub, c->L,
-                                          c->lnp_layer / 4, ps, s));
+        CHECK(pevit_launch_colsum_reduce(at<float>(W, c->w_csy + (size_t)l_lo * c->csy_layer), tch, 64, g0 + c->o_db, nl,
+                                         c->csy_layer / 4, ps, s));
+        CHECK(pevit_launch_colsum_reduce3(at<float>(W, c->w_lnp + (size_t)l_lo * c->lnp_layer), lnb, E, g0 + c->o_nw, g0 + c->o_nb,
+                                          g0 + c->o_ub, nl, c->lnp_layer / 4, ps, s));
         if (c->d.method == PEVIT_ADAPTER) {
-            CHECK(pevit_launch_chain_adapter(at<float>(W, c->w_Gd), at<float>(W, c->w_Gu), g0 + c->o_dw, g0 + c->o_uw, E, c->L, gl,
-                                             ps, s));
+            CHECK(pevit_launch_chain_adapter(Gd, Gu, g0 + c->o_dw, g0 + c->o_uw, E, nl, gl, ps, s));
         } else {
-            CHECK(pevit_launch_chain_compacter(at<float>(W, c->w_Gd), at<float>(W, c->w_Gu), at<float>(c->arena, c->a_phm),
-                                               c->params + c->p_layer0, g0, E, c->L, gl, ps, c->o_dWl, c->o_dWr, c->o_uWl,
-                                               c->o_uWr, s));
+            CHECK(pevit_launch_chain_compacter(Gd, Gu, at<float>(c->arena, c->a_phm), c->params + pl0, g0, E, nl, gl, ps, c->o_dWl,
+                                               c->o_dWr, c->o_uWl, c->o_uWr, s));
         }
     }
     return 0;
@@ -753,13 +771,17 @@ extern "C" int pevit_transformer_forward(pevit_ctx* c, void* stream, const float
     CHECK(pevit_launch_permute_rows(x_nbe, at<float>(c->ws, c->sav[0].x_in), c->N, B, c->E, 1, s));
     CHECK(blocks_forward(c, s, B, false));
     CHECK(pevit_launch_permute_rows(at<float>(c->ws, c->w_xfinal), y_nbe, c->N, B, c->E, 0, s));
-    c->saved_batch = save_for_backward ? B : 0;
+    c->saved_batch = save_for_backward ? B : 0; c->saved_kind = 1;
     return 0;
 }
 
 extern "C" int pevit_transformer_backward(pevit_ctx* c, void* stream, const float* dy_nbe, float* dx_nbe, int B) {
     CHECK(check_ready(c, B, "transformer_backward"));
-    if (c->saved_batch != B) { pevit_set_error("transformer_backward: no saved forward for batch %d", B); return -1; }
+    if (c->saved_batch != B || c->saved_kind != 1) {
+        pevit_set_error("transformer_backward: the saved activations are not those of a transformer_forward with batch %d "
+                        "(saved: batch %d, %s)", B, c->saved_batch, c->saved_kind == 2 ? "visual_forward" : "none");
+        return -1;
+    }
     hipStream_t s = (hipStream_t)stream;
     const size_t n = (size_t)B * c->N * c->E;
     CHECK(pevit_launch_permute_rows(dy_nbe, at<float>(c->ws, c->w_dxa), c->N, B, c->E, 1, s));
@@ -768,7 +790,7 @@ extern "C" int pevit_transformer_backward(pevit_ctx* c, void* stream, const floa
                                           at<float>(c->arena, c->blk[c->L - 1].spr), s));
     else
         CHECK(pevit_launch_cast_bf16(at<float>(c->ws, c->w_dxa), at<bf16>(c->ws, c->w_dyb), n, 1.0f, s));
-    CHECK(blocks_backward(c, s, B, dx_nbe != nullptr, false));
+    CHECK(blocks_backward(c, s, B, dx_nbe != nullptr, false, c->L, 0));
     if (dx_nbe) CHECK(pevit_launch_permute_rows(at<float>(c->ws, c->w_dxa), dx_nbe, c->N, B, c->E, 0, s));
     return 0;
 }
@@ -841,41 +863,55 @@ extern "C" int pevit_visual_forward(pevit_ctx* c, void* stream, const float* ima
         p.outf = feat ? feat : at<float>(W, c->w_feat); p.ldo = c->D;
         CHECK(gemm(c, EPI_F32, p, s));
     }
-    c->saved_batch = save_for_backward ? B : 0;
+    c->saved_batch = save_for_backward ? B : 0; c->saved_kind = 2;
     return 0;
 }
 
-// dfeat (B,D) f32 -> adapter gradients (nothing below the first block is trainable)
-extern "C" int pevit_visual_backward(pevit_ctx* c, void* stream, const float* dfeat, int B) {
+// dfeat (B,D) f32 -> adapter gradients (nothing below the first block is trainable).
+// Layers l_hi-1 .. l_lo; the entry work (proj^T, ln_post backward) belongs to the part that starts at L.  Data
+// parallelism calls (L, L/2) then (L/2, 0) and all-reduces the first part's gradients while the second runs.
+extern "C" int pevit_visual_backward_part(pevit_ctx* c, void* stream, const float* dfeat, int B, int l_hi, int l_lo) {
     CHECK(check_ready(c, B, "visual_backward"));
-    if (c->saved_batch != B) { pevit_set_error("visual_backward: no saved forward for batch %d", B); return -1; }
+    if (c->saved_batch != B || c->saved_kind != 2) {
+        pevit_set_error("visual_backward: the saved activations are not those of a visual_forward with batch %d (saved: batch %d, %s)",
+                        B, c->saved_batch, c->saved_kind == 1 ? "transformer_forward" : "none");
+        return -1;
+    }
+    if (l_lo < 0 || l_hi > c->L || l_lo >= l_hi) { pevit_set_error("visual_backward: bad layer range [%d, %d)", l_lo, l_hi); return -1; }
     if (c->d.method == PEVIT_NONE) return 0;
     hipStream_t s = (hipStream_t)stream;
     char* W = c->ws; char* A = c->arena;
     const int E = c->E, N = c->N, T = B * N;
-    CHECK(pevit_launch_cast_bf16(dfeat, at<bf16>(W, c->w_dfeatb), (size_t)B * c->D, 1.0f, s));
-    {
-        GemmParams p = gp(at<bf16>(W, c->w_dfeatb), c->D, at<bf16>(A, c->a_projT), c->D, E, B, E, c->D);
-        p.outf = at<float>(W, c->w_dxpost); p.ldo = E;
-        CHECK(gemm(c, EPI_F32, p, s));
-    }
-    // dL/dx_final is zero except on the class-token rows.  With class-token pruning of the last block
-    // only those rows of dxa / dyb are ever read; the full-size buffers the last block's attention and
-    // LN1 backward consume (dO, dxb) are zeroed instead.
     const bool cls = !post_mlp(c);
-    if (cls) {
-        HIP_OK(hipMemsetAsync(W + c->w_dxb, 0, (size_t)T * E * 4, s));
-        HIP_OK(hipMemsetAsync(W + c->w_dO, 0, (size_t)T * E * 2, s));
-    } else {
-        HIP_OK(hipMemsetAsync(W + c->w_dxa, 0, (size_t)T * E * 4, s));
-        HIP_OK(hipMemsetAsync(W + c->w_dyb, 0, (size_t)T * E * 2, s));
+    if (l_hi == c->L) {
+        if (!dfeat) { pevit_set_error("visual_backward: dfeat is required for the part that starts at the last block"); return -1; }
+        CHECK(pevit_launch_cast_bf16(dfeat, at<bf16>(W, c->w_dfeatb), (size_t)B * c->D, 1.0f, s));
+        {
+            GemmParams p = gp(at<bf16>(W, c->w_dfeatb), c->D, at<bf16>(A, c->a_projT), c->D, E, B, E, c->D);
+            p.outf = at<float>(W, c->w_dxpost); p.ldo = E;
+            CHECK(gemm(c, EPI_F32, p, s));
+        }
+        // dL/dx_final is zero except on the class-token rows.  With class-token pruning of the last block
+        // only those rows of dxa / dyb are ever read; the full-size buffers the last block's attention and
+        // LN1 backward consume (dO, dxb) are zeroed instead.
+        if (cls) {
+            HIP_OK(hipMemsetAsync(W + c->w_dxb, 0, (size_t)T * E * 4, s));
+            HIP_OK(hipMemsetAsync(W + c->w_dO, 0, (size_t)T * E * 2, s));
+        } else {
+            HIP_OK(hipMemsetAsync(W + c->w_dxa, 0, (size_t)T * E * 4, s));
+            HIP_OK(hipMemsetAsync(W + c->w_dyb, 0, (size_t)T * E * 2, s));
+        }
+        CHECK(pevit_launch_ln_bwd(at<float>(W, c->w_dxpost), at<float>(W, c->w_xfinal), at<float>(W, c->w_pmean),
+                                  at<float>(W, c->w_prstd), at<float>(A, c->a_lnpost_w), nullptr, at<float>(W, c->w_dxa),
+                                  at<bf16>(W, c->w_dyb), B, E, s, (size_t)N * E,
+                                  c->fp8 ? at<float>(A, c->blk[c->L - 1].spr) : nullptr));
     }
-    CHECK(pevit_launch_ln_bwd(at<float>(W, c->w_dxpost), at<float>(W, c->w_xfinal), at<float>(W, c->w_pmean),
-                              at<float>(W, c->w_prstd), at<float>(A, c->a_lnpost_w), nullptr, at<float>(W, c->w_dxa),
-                              at<bf16>(W, c->w_dyb), B, E, s, (size_t)N * E,
-                              c->fp8 ? at<float>(A, c->blk[c->L - 1].spr) : nullptr));
-    CHECK(blocks_backward(c, s, B, false, cls));
+    CHECK(blocks_backward(c, s, B, false, cls, l_hi, l_lo));
     return 0;
+}
+
+extern "C" int pevit_visual_backward(pevit_ctx* c, void* stream, const float* dfeat, int B) {
+    return pevit_visual_backward_part(c, stream, dfeat, B, c ? c->L : 0, 0);
 }
 
 extern "C" int pevit_head_forward_backward(pevit_ctx* c, void* stream, const float* feat, const int64_t* labels,
@@ -1022,6 +1058,48 @@ extern "C" int pevit_op_lowrank_grad(void* stream, const void* xn, int ldx, cons
                                      pevit_lowrank_chunks(B * N), B, H, N, E, (hipStream_t)stream);
 }
 extern "C" int pevit_op_lowrank_chunks(int T) { return pevit_lowrank_chunks(T); }
+// ---- post-MLP adapter kernels (adapter.hip), one layer at a time
+extern "C" int pevit_op_tn_chunks(int T) { return pevit_tn_chunks(T); }
+extern "C" int pevit_op_lna_blocks(int rows) { return pevit_lna_blocks(rows); }
+extern "C" int pevit_op_tn_gemm64(void* stream, const void* X, int ldx, const void* Y, int ldy, float* partial, float* csx,
+                                  float* csy, int T, int E) {
+    return pevit_launch_tn_gemm64((const bf16*)X, ldx, (const bf16*)Y, ldy, partial, csx, csy, T, E, (hipStream_t)stream);
+}
+extern "C" int pevit_op_ln_bwd_affine(void* stream, const float* dy, const float* x, const float* mean, const float* rstd,
+                                      const float* gamma, const float* dres, float* dx, void* dx_bf16, float* partial,
+                                      int rows, int E) {
+    return pevit_launch_ln_bwd_affine(dy, x, mean, rstd, gamma, dres, dx, (bf16*)dx_bf16, partial, rows, E, (hipStream_t)stream);
+}
+extern "C" int pevit_op_colsum_reduce(void* stream, const float* partial, int chunks, int n, float* out0, float* out1,
+                                      float* out2) {
+    if (out1 || out2) {
+        if (!out1 || !out2) { pevit_set_error("colsum_reduce: give one output or three"); return -1; }
+        return pevit_launch_colsum_reduce3(partial, chunks, n, out0, out1, out2, 1, 0, 0, (hipStream_t)stream);
+    }
+    return pevit_launch_colsum_reduce(partial, chunks, n, out0, 1, 0, 0, (hipStream_t)stream);
+}
+extern "C" int pevit_op_prep_bottleneck(void* stream, int method, const float* rule, const float* p0, const float* p1,
+                                        const float* p2, const float* p3, void* wd, void* wdT, void* wu, void* wuT, int E) {
+    BottleneckPanels pan{(bf16*)wd, (bf16*)wdT, (bf16*)wu, (bf16*)wuT};
+    LayerStrides st{0, 0};
+    if (method == PEVIT_ADAPTER) return pevit_launch_prep_adapter(p0, p1, pan, E, 1, st, (hipStream_t)stream);
+    if (method == PEVIT_COMPACTER) return pevit_launch_prep_compacter(rule, p0, p1, p2, p3, pan, E, 1, st, (hipStream_t)stream);
+    pevit_set_error("prep_bottleneck: method %d is not a post-MLP adapter", method);
+    return -1;
+}
+extern "C" int pevit_op_chain_bottleneck(void* stream, int method, const float* Gd, const float* Gu, const float* rule,
+                                         const float* params, float* grads, int E, size_t off0, size_t off1, size_t off2,
+                                         size_t off3) {
+    if (method == PEVIT_ADAPTER)
+        return pevit_launch_chain_adapter(Gd, Gu, grads + off0, grads + off1, E, 1, 0, 0, (hipStream_t)stream);
+    if (method == PEVIT_COMPACTER)
+        return pevit_launch_chain_compacter(Gd, Gu, rule, params, grads, E, 1, 0, 0, off0, off1, off2, off3, (hipStream_t)stream);
+    pevit_set_error("chain_bottleneck: method %d is not a post-MLP adapter", method);
+    return -1;
+}
+extern "C" int pevit_op_im2col(void* stream, const float* images, void* patches_bf16, int B, int R, int P, int Kpad) {
+    return pevit_launch_im2col(images, (bf16*)patches_bf16, B, R, P, Kpad, (hipStream_t)stream);
+}
 extern "C" int pevit_tune(pevit_ctx* c, const char* key, int value) {
     GemmTune& t = c ? c->tune : g_default_tune;
     if (key && !strcmp(key, "gemm_config")) { t.config = value; return 0; }

@@ -106,6 +106,7 @@ int pevit_lowrank_chunks(int T);
 int pevit_launch_chain_kadapt(const float* partial, size_t partial_layer, const float* dbias_partial, size_t dbias_layer,
                               int chunks, float ascale, int layers, float* G, float* rule_scratch, const float* params,
                               float* grads, size_t p_layer0, size_t p_layer_stride, int E, hipStream_t s);
+int pevit_launch_rule_sum(const float* rule_scratch, float* grads, int layers, hipStream_t s);
 int pevit_launch_chain_lora(const float* partial, size_t partial_layer, int chunks, float ascale, int r, int layers,
                             float* G, float* grads, size_t p_layer0, size_t p_layer_stride, int E, hipStream_t s);
 

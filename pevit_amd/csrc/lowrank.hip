@@ -521,6 +521,11 @@ int pevit_launch_chain_kadapt(const float* partial, size_t partial_layer, const 
     hipLaunchKernelGGL(chain_kadapt_kernel, dim3(32, layers), dim3(256), 4 * E * sizeof(float), s, G, ascale, r, r + 1024,
                        r + 2048, r + 3072, lp, lp + E, rule_scratch, lg, lg + E, E, p_layer_stride);
     LAUNCH_OK("chain_kadapt_kernel");
+    return 0;
+}
+
+// shared phm_rule factors: g_rule[0:4096] += sum over ALL layers (fixed order), once per step after the last chain call
+int pevit_launch_rule_sum(const float* rule_scratch, float* grads, int layers, hipStream_t s) {
     hipLaunchKernelGGL(rule_sum_kernel, dim3(16), dim3(256), 0, s, rule_scratch, grads, layers);
     LAUNCH_OK("rule_sum_kernel");
     return 0;

@@ -180,13 +180,24 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(SmallGemm p) {
     }
 }
 
-// one wave per row: log-softmax, row loss, dlogits = (softmax - onehot)/B
+// torch.nn.CrossEntropyLoss(reduction="mean") semantics for class-index targets: rows whose target equals the default
+// ignore_index (-100) contribute nothing and the mean runs over the remaining rows; any other target outside [0, C) is an
+// error in torch (device assert) and poisons the loss with NaN here instead of reading out of bounds.
+constexpr int CE_IGNORE = -100;
+__device__ __forceinline__ float ce_valid_rows(const int64_t* __restrict__ labels, int B, int lane) {
+    float n = 0.f;
+    for (int b = lane; b < B; b += 64) n += labels[b] != CE_IGNORE ? 1.f : 0.f;
+    return wave_sum(n);
+}
+
+// one wave per row: log-softmax, row loss, dlogits = (softmax - onehot) / (number of non-ignored rows)
 __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
                                                  float* __restrict__ dlogits, float* __restrict__ rowloss, int B,
                                                  int Cc) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
+    const float nvalid = ce_valid_rows(labels, B, lane);
     const float* lr = logits + (size_t)b * Cc;
     float m = -3.0e38f;
     for (int c = lane; c < Cc; c += 64) m = fmaxf(m, lr[c]);
@@ -195,20 +206,26 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logit
     for (int c = lane; c < Cc; c += 64) s += __expf(lr[c] - m);
     s = wave_sum(s);
     const float lse = m + __logf(s);
-    const int lab = (int)labels[b];
+    const int64_t lab64 = labels[b];
+    const bool ignored = lab64 == CE_IGNORE, bad = !ignored && (lab64 < 0 || lab64 >= Cc);
+    const int lab = (int)lab64;
+    const float nanv = __builtin_nanf("");
     for (int c = lane; c < Cc; c += 64) {
         const float pr = __expf(lr[c] - lse);
-        dlogits[(size_t)b * Cc + c] = (pr - (c == lab ? 1.f : 0.f)) / (float)B;
+        const float g = (pr - (c == lab ? 1.f : 0.f)) / nvalid;
+        dlogits[(size_t)b * Cc + c] = ignored ? 0.f : (bad ? nanv : g);
     }
-    if (lane == 0) rowloss[b] = lse - lr[lab];
+    if (lane == 0) rowloss[b] = ignored ? 0.f : (bad ? nanv : lse - lr[lab]);
 }
 
-// loss = mean(rowloss): one wave, fixed summation order
-__global__ void loss_mean_kernel(const float* __restrict__ rowloss, float* __restrict__ loss, int B) {
+// loss = sum(rowloss) / (number of non-ignored rows): one wave, fixed summation order
+__global__ void loss_mean_kernel(const float* __restrict__ rowloss, const int64_t* __restrict__ labels,
+                                 float* __restrict__ loss, int B) {
     float s = 0.f;
     for (int b = threadIdx.x; b < B; b += 64) s += rowloss[b];
     s = wave_sum(s);
-    if (threadIdx.x == 0) loss[0] = s / (float)B;
+    const float nvalid = ce_valid_rows(labels, B, threadIdx.x);
+    if (threadIdx.x == 0) loss[0] = s / nvalid;
 }
 
 }  // namespace
@@ -245,7 +262,7 @@ int pevit_launch_head(const float* feat, const int64_t* labels, const float* W, 
     float* rowloss = dybn;      // dybn is written later (by the dgrad product); reuse its head as scratch
     hipLaunchKernelGGL(ce_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, s, logits, labels, dlogits, rowloss, B, Cc);
     LAUNCH_OK("ce_kernel");
-    hipLaunchKernelGGL(loss_mean_kernel, dim3(1), dim3(64), 0, s, rowloss, loss, B);
+    hipLaunchKernelGGL(loss_mean_kernel, dim3(1), dim3(64), 0, s, rowloss, labels, loss, B);
     LAUNCH_OK("loss_mean_kernel");
     if (gW) {   // gW[c][d] += sum_b dl[b][c] ybn[b][d] ; gb[c] += sum_b dl[b][c]
         SmallGemm g{dlogits, 1, Cc, ybn, D, 1, gW, D, nullptr, gb, Cc, D, B, 1};

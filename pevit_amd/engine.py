@@ -115,6 +115,7 @@ class HipEngine:
         if total != self.n_tower:
             raise _lib.PevitError(f"host/engine parameter layout mismatch: {total} vs {self.n_tower}")
         self._steps = 0
+        self.forward_generation = 0      # bumped by EVERY forward: each one overwrites the single activation workspace
         self._logits = torch.empty((max_batch, num_classes), dtype=torch.float32, device=self.device)
         self._loss = torch.zeros(1, dtype=torch.float32, device=self.device)
 
@@ -203,8 +204,27 @@ class HipEngine:
                     v.copy_(sd[name].to(device=self.device, dtype=torch.float32).view_as(v))
 
     # ------------------------------------------------------------------ hot path
+    def _check_batch(self, images, labels=None):
+        """The C ABI takes raw pointers: reject anything that is not what it will read (f32 NCHW images and int64 class
+        indices, contiguous, on this engine's device)."""
+        a = self.arch
+        if images.device != self.device or images.dtype != torch.float32 or not images.is_contiguous() or \
+                tuple(images.shape[1:]) != (3, a.resolution, a.resolution):
+            raise _lib.PevitError(f"images must be a contiguous float32 tensor (B,3,{a.resolution},{a.resolution}) on {self.device}; "
+                                  f"got {tuple(images.shape)} {images.dtype} on {images.device}")
+        if images.shape[0] > self.max_batch:
+            raise _lib.PevitError(f"batch {images.shape[0]} exceeds the bound workspace ({self.max_batch}): call ensure_batch")
+        if labels is not None and (labels.device != self.device or labels.dtype != torch.int64 or not labels.is_contiguous()
+                                   or tuple(labels.shape) != (images.shape[0],)):
+            raise _lib.PevitError(f"labels must be a contiguous int64 tensor ({images.shape[0]},) on {self.device}; "
+                                  f"got {tuple(labels.shape)} {labels.dtype} on {labels.device}")
+
     def transformer_forward(self, x_nbe: torch.Tensor, save: bool = True) -> torch.Tensor:
         N, B, E = x_nbe.shape
+        if (N, E) != (self.arch.tokens, self.arch.width) or x_nbe.device != self.device:
+            raise _lib.PevitError(f"transformer_forward expects ({self.arch.tokens}, B, {self.arch.width}) on {self.device}, "
+                                  f"got {tuple(x_nbe.shape)} on {x_nbe.device}")
+        self.forward_generation += 1
         x = x_nbe.contiguous().float()
         y = torch.empty_like(x)
         _lib.check(self.lib.pevit_transformer_forward(self._ctx, _lib.stream_ptr(), _lib.ptr(x), _lib.ptr(y), B, int(save)),
@@ -222,6 +242,8 @@ class HipEngine:
     def visual_forward(self, images: torch.Tensor, save: bool = True) -> torch.Tensor:
         B = images.shape[0]
         img = images.contiguous().float()
+        self._check_batch(img)
+        self.forward_generation += 1
         feat = torch.empty((B, self.arch.embed_dim), dtype=torch.float32, device=self.device)
         _lib.check(self.lib.pevit_visual_forward(self._ctx, _lib.stream_ptr(), _lib.ptr(img), _lib.ptr(feat), B, int(save)),
                    "pevit_visual_forward")
@@ -251,6 +273,8 @@ class HipEngine:
         (logits, loss) as device tensors without synchronising (the reference's
         ``loss.item()`` per step, kadaptation_clip.py:354, is the caller's choice)."""
         B = images.shape[0]
+        self._check_batch(images, labels)
+        self.forward_generation += 1
         _lib.check(self.lib.pevit_train_forward_backward(
             self._ctx, _lib.stream_ptr(), _lib.ptr(images), _lib.ptr(labels), _lib.ptr(self.running_mean),
             _lib.ptr(self.running_var), int(bn_training), _lib.ptr(self._logits), _lib.ptr(self._loss), B),
@@ -301,22 +325,53 @@ class HipEngine:
         return logits, loss
 
     def forward_backward_dp(self, images, labels, bn_training=True, process_group=None):
-        """forward_backward() split at the head so that the head-gradient all-reduce overlaps the tower backward;
-        leaves the SUM over ranks in ``self.grads``.  The same three C entry points as the fused call, in the
-        same order, so a single rank reproduces forward_backward() bit for bit."""
+        """forward_backward() cut into stages so that the gradient exchange overlaps the backward; leaves the
+        SUM over ranks in ``self.grads``.  Three buckets of the flat buffer, each all-reduced asynchronously as soon as its
+        gradients are final:  head (after the head backward) | blocks L/2..L-1 (after the upper half of the tower backward)
+        | shared rules + blocks 0..L/2-1 (at the end).  Same kernels in the same order as the fused call, so a single rank
+        reproduces forward_backward() bit for bit."""
         import torch.distributed as dist
         B = images.shape[0]
+        self._check_batch(images, labels)
         self.zero_grad()
         feat = self.visual_forward(images, save=True)
         _lib.check(self.lib.pevit_head_forward_backward(
             self._ctx, _lib.stream_ptr(), _lib.ptr(feat), _lib.ptr(labels), _lib.ptr(self.running_mean),
             _lib.ptr(self.running_var), int(bn_training), _lib.ptr(self._logits), _lib.ptr(self._loss),
             _lib.ptr(self._dfeat(B)), B), "pevit_head_forward_backward")
-        head = dist.all_reduce(self.grads[self.n_tower:], op=dist.ReduceOp.SUM, group=process_group, async_op=True)
-        self.visual_backward(self._dfeat(B))
-        dist.all_reduce(self.grads[:self.n_tower], op=dist.ReduceOp.SUM, group=process_group)
-        head.wait()
+        L = self.arch.layers
+        mid = L // 2
+        cut = self.lib.pevit_param_layer_offset(self._ctx, mid)
+        work = [dist.all_reduce(self.grads[self.n_tower:], op=dist.ReduceOp.SUM, group=process_group, async_op=True)]
+        if self.n_tower == 0:                                  # frozen tower (linear probe): nothing below the head trains
+            work[0].wait()
+            return self._logits[:B], self._loss
+        dfeat = self._dfeat(B)
+        if mid > 0:
+            _lib.check(self.lib.pevit_visual_backward_part(self._ctx, _lib.stream_ptr(), _lib.ptr(dfeat), B, L, mid),
+                       "pevit_visual_backward_part")
+            work.append(dist.all_reduce(self.grads[cut:self.n_tower], op=dist.ReduceOp.SUM, group=process_group, async_op=True))
+            _lib.check(self.lib.pevit_visual_backward_part(self._ctx, _lib.stream_ptr(), None, B, mid, 0),
+                       "pevit_visual_backward_part")
+            work.append(dist.all_reduce(self.grads[:cut], op=dist.ReduceOp.SUM, group=process_group, async_op=True))
+        else:
+            self.visual_backward(dfeat)
+            work.append(dist.all_reduce(self.grads[:self.n_tower], op=dist.ReduceOp.SUM, group=process_group, async_op=True))
+        for w in work:
+            w.wait()
         return self._logits[:B], self._loss
+
+    def sync_replicas(self, process_group=None, src: int = 0):
+        """Make every rank's trainable state identical to rank ``src``'s (parameters, momentum, BatchNorm running
+        statistics, step counter semantics): call once after the engines have been loaded and before the first DP step."""
+        import torch.distributed as dist
+        for t in (self.params, self.momentum, self.running_mean, self.running_var):
+            dist.broadcast(t, src=src, group=process_group)
+
+    def average_bn_buffers(self, process_group=None):
+        """BatchNorm running statistics follow the LOCAL shards; average them across ranks before validation or a
+        checkpoint (dp.average_bn_buffers)."""
+        dp.average_bn_buffers(self.running_mean, self.running_var, process_group)
 
     def _dfeat(self, B):
         if getattr(self, "_dfeat_buf", None) is None or self._dfeat_buf.shape[0] < B:

@@ -104,7 +104,7 @@ def _read_state_dict(model_path: str):
     try:
         sd = torch.jit.load(model_path, map_location="cpu").eval().state_dict()      # OpenAI releases are JIT archives
     except RuntimeError:
-        sd = torch.load(model_path, map_location="cpu")
+        sd = torch.load(model_path, map_location="cpu", weights_only=True)      # tensors only: no pickled code
     if isinstance(sd, dict) and "state_dict" in sd and "visual.proj" not in sd:
         sd = sd["state_dict"]
     _SD_CACHE.clear()

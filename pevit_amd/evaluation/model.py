@@ -135,6 +135,54 @@ class _EngineCache:
 _ENGINES = _EngineCache()
 
 
+def _check_generation(eng, generation):
+    """The engine keeps the activations of ONE forward.  A backward through an older graph (gradient accumulation
+    over two live graphs, two image batches in one loss, a grad-enabled validation forward in between) would silently
+    differentiate the wrong activations: fail instead."""
+    if eng.forward_generation != generation:
+        raise _lib.PevitError("backward through a forward whose activations the engine no longer holds: another forward "
+                              "ran in between (the HIP engine keeps one activation workspace, which every forward -- with or without "
+                              "grad -- overwrites; call backward before the next forward of this tower)")
+
+
+class _TransformerFn(torch.autograd.Function):
+    """The operator seam of the reference, Transformer.forward(x: (N,B,E)) -> (N,B,E) (model.py:1013), on the engine."""
+
+    @staticmethod
+    def forward(ctx, x, visual, save, *params):
+        eng = visual._engine
+        y = eng.transformer_forward(x, save=save)
+        ctx.visual, ctx.generation, ctx.need_dx = visual, eng.forward_generation, x.requires_grad
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        eng = ctx.visual._engine
+        _check_generation(eng, ctx.generation)
+        eng.grads[:eng.n_tower].zero_()
+        dx = eng.transformer_backward(dy, need_dx=ctx.need_dx)
+        views = eng.param_views(eng.grads.clone())
+        mask = ctx.visual._has_grad
+        grads = [views["visual." + n] if mask[n] else None for n in ctx.visual._trainable_names]
+        return (dx, None, None, *grads)
+
+
+class _Transformer(_Params):
+    """visual.transformer: owner of the shared phm_rule* factors and of resblocks (model.py:978-1014), callable like the
+    reference's module.  ``kdropout`` mirrors MultiheadAttention.kdropout = Dropout(0.5) (model.py:516,582): the reference
+    never leaves eval mode, where it is the identity; the engine has no dropout, so train mode is refused (see
+    VisionTransformer.train)."""
+    kdropout = 0.5
+
+    def forward(self, x):
+        visual = self._owner()
+        eng = visual.engine()
+        eng.ensure_batch(x.shape[1])
+        params = visual._trainable_params()
+        save = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+        return _TransformerFn.apply(x.contiguous().float(), visual, save, *params)
+
+
 class _VisualFn(torch.autograd.Function):
     """images -> features through the HIP engine; gradients of the trainable tensors come back as
     the engine's flat-buffer views (the reference gets them from autograd over aten ops)."""
@@ -143,12 +191,13 @@ class _VisualFn(torch.autograd.Function):
     def forward(ctx, images, visual, save, *params):
         eng = visual._engine
         feat = eng.visual_forward(images, save=save)
-        ctx.visual, ctx.n = visual, len(params)
+        ctx.visual, ctx.n, ctx.generation = visual, len(params), eng.forward_generation
         return feat
 
     @staticmethod
     def backward(ctx, dfeat):
         eng = ctx.visual._engine
+        _check_generation(eng, ctx.generation)
         eng.grads[:eng.n_tower].zero_()
         eng.visual_backward(dfeat)
         views = eng.param_views(eng.grads.clone())         # ONE copy; autograd takes views of it as the gradients
@@ -176,7 +225,8 @@ class VisionTransformer(nn.Module):
         self.register_parameter("proj", nn.Parameter(scale * torch.randn(E, arch.embed_dim), requires_grad=False))
         self.conv1 = _Params(); self.conv1.add("weight", torch.zeros(E, 3, arch.patch, arch.patch))
         self.ln_pre = _Params(); self.ln_pre.add("weight", torch.ones(E)); self.ln_pre.add("bias", torch.zeros(E))
-        self.transformer = _Params()
+        self.transformer = _Transformer()
+        object.__setattr__(self.transformer, "_owner", weakref.ref(self))     # not a submodule edge: no cycle in the module tree
         for n, (s, tr) in shapes.items():              # shared rules live on the Transformer (model.py:987-999)
             if n.startswith("transformer.phm_rule"):
                 self.transformer.add(n[len("transformer."):], torch.zeros(s), tr)
@@ -198,6 +248,14 @@ class VisionTransformer(nn.Module):
             self.transformer.resblocks.add_module(str(i), blk)
         self.ln_post = _Params(); self.ln_post.add("weight", torch.ones(E)); self.ln_post.add("bias", torch.zeros(E))
         self._has_grad = {n: True for n in self._trainable_names}
+
+    def train(self, mode: bool = True):
+        if mode and self.method == "kadaptation":
+            raise _lib.PevitError("the KAdaptation tower has kdropout = Dropout(0.5) on the Kronecker weights in train mode "
+                                  "(model.py:516,582); the reference never enters it (build_model returns .eval(), "
+                                  "kadaptation_clip.py never calls .train()) and the HIP engine does not implement it: keep the "
+                                  "backbone in eval mode")
+        return super().train(mode)
 
     # -- engine life cycle ---------------------------------------------------------------
     def _apply(self, fn, *a, **kw):
@@ -226,6 +284,7 @@ class VisionTransformer(nn.Module):
         does."""
         num_classes = num_classes or getattr(self, "_num_classes", 1)
         max_batch = max_batch or getattr(self, "_max_batch", 128)
+        object.__setattr__(self.transformer, "_owner", weakref.ref(self))     # (a deep copy carries the original's reference)
         sd = {"visual." + k: v for k, v in self.state_dict().items()}
         eng = _ENGINES.acquire(self, torch.device(device), num_classes, max_batch)
         if eng is None:

@@ -44,6 +44,8 @@ ARCHS = {
     "ViT-B/32": VitArch("ViT-B/32", 768, 12, 32, 224, 512),
     "ViT-B/16": VitArch("ViT-B/16", 768, 12, 16, 224, 512),
     "ViT-L/14": VitArch("ViT-L/14", 1024, 24, 14, 224, 768, text_width=768),
+    # ViT-B/32 geometry (width 768, 50 tokens, patch 32) cut to two blocks (whole-step parity tests at B = 128)
+    "ViT-B/32-2L": VitArch("ViT-B/32-2L", 768, 2, 32, 224, 512),
     # small legal shapes for tests (head_dim stays 64, the only value CLIP uses)
     "tiny-128": VitArch("tiny-128", 128, 2, 16, 48, 64, text_width=64, text_layers=1,
                         context_length=8, vocab_size=32),

@@ -218,3 +218,89 @@ def test_batches_larger_than_configured_grow_the_workspace(ckpt):
         feat = ref_cpu.visual_forward(images.cpu(), golden_param_dict(meta, t), "lora")
         ref = (feat / (1.0 + 1e-5) ** 0.5) @ t["head_w"].T + t["head_b"]
     assert max_rel(out.cpu(), ref) < LOGIT_TOL
+
+
+@pytest.mark.parametrize("method", ["kadaptation", "adapter"])
+def test_transformer_module_seam_matches_oracle(method, ckpt):
+    """model.visual.transformer(x) with x: (N,B,E) -- the reference's Transformer.forward seam (model.py:1013) -- through
+    autograd: output, dL/dx and adapter gradients against the oracle."""
+    from oracle import ref_cpu
+    from pevit_amd.evaluation.model import build_peft_model
+    from pevit_amd.synth import randomize_adapters
+    sd = load_tiny_sd()
+    model = build_peft_model(dict(sd), method).cuda()
+    named = [(n, p) for n, p in model.visual.named_parameters() if ref_cpu.is_trainable(method, "visual." + n)]
+    model.visual.engine()
+    randomize_adapters([(n, p) for n, p in named], seed=4)
+    for _, p in named:
+        p.requires_grad_(True)
+    N, B, E = 10, 5, 128
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, B, E, generator=g); dy = torch.randn(N, B, E, generator=g)
+    xg = x.cuda().requires_grad_(True)
+    y = model.visual.transformer(xg)
+    y.backward(dy.cuda())
+    torch.cuda.synchronize()
+    p = {k: v.clone().float() for k, v in sd.items()}
+    for n, q in model.visual.named_parameters():
+        p["visual." + n] = q.detach().cpu().clone()
+    names = ref_cpu.trainable_names(p, method)
+    for k in names:
+        p[k].requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    yr = ref_cpu.transformer_forward(xr, p, 2, 2, method)
+    yr.backward(dy)
+    assert max_rel(y.detach().cpu(), yr.detach()) < LOGIT_TOL
+    assert rel_err(xg.grad.cpu(), xr.grad) < GRAD_TOL
+    got = dict(model.visual.named_parameters())
+    for k in names:
+        q = got[k[len("visual."):]]
+        if p[k].grad is None:
+            assert q.grad is None or float(q.grad.abs().max()) == 0.0
+        else:
+            assert rel_err(q.grad.cpu(), p[k].grad) < GRAD_TOL, k
+
+
+def test_backward_through_a_stale_graph_fails_loudly(ckpt):
+    """The engine keeps ONE set of saved activations: a second grad-enabled forward before the first backward must make
+    that backward fail, not differentiate the wrong activations (round-1 advisor finding)."""
+    from pevit_amd import _lib
+    from pevit_amd.evaluation.model import build_peft_model
+    model = build_peft_model(dict(load_tiny_sd()), "lora").cuda()
+    for n, p in model.visual.named_parameters():
+        p.requires_grad_("adapter" in n)
+    img = torch.randn(4, 3, 48, 48).cuda()
+    f1 = model.encode_image(img)
+    f2 = model.encode_image(img * 0.5)
+    with pytest.raises(_lib.PevitError, match="no longer holds"):
+        f1.sum().backward()
+    f2.sum().backward()                                    # the latest graph is fine
+    f3 = model.encode_image(img)
+    with torch.no_grad():
+        model.encode_image(img)                            # ANY forward overwrites the activation workspace
+    with pytest.raises(_lib.PevitError, match="no longer holds"):
+        f3.sum().backward()
+    # the C ABI checks the same thing one level down: transformer activations cannot feed visual_backward
+    eng = model.visual.engine()
+    eng.transformer_forward(torch.randn(10, 4, 128).cuda())
+    with pytest.raises(_lib.PevitError, match="not those of a visual_forward"):
+        eng.visual_backward(torch.zeros(4, 64).cuda())
+
+
+def test_engine_rejects_inputs_it_would_misread(ckpt):
+    from pevit_amd import _lib
+    from pevit_amd.engine import HipEngine
+    from pevit_amd.synth import ARCHS
+    eng = HipEngine(ARCHS["tiny-128"], "lora", 10, 4)
+    img = torch.randn(4, 3, 48, 48).cuda(); lab = torch.zeros(4, dtype=torch.int64).cuda()
+    for bad_img, bad_lab in ((img.cpu(), lab), (img.double(), lab), (img, lab.int()), (img, lab.cpu()), (img[:, :, ::2], lab),
+                             (img, lab[:3]), (torch.randn(8, 3, 48, 48).cuda(), torch.zeros(8, dtype=torch.int64).cuda())):
+        with pytest.raises(_lib.PevitError):
+            eng.forward_backward(bad_img, bad_lab)
+    # CrossEntropyLoss semantics for the default ignore_index: ignored rows drop out of the mean; other invalid targets poison
+    eng.forward_backward(img, lab)
+    lg, loss = eng.forward_backward(img, torch.tensor([1, -100, 3, -100]).cuda())
+    ref = torch.nn.functional.cross_entropy(lg.float(), torch.tensor([1, -100, 3, -100]).cuda())
+    assert abs(float(loss) - float(ref)) < 1e-5
+    _, loss = eng.forward_backward(img, torch.tensor([1, 10, 3, 2]).cuda())
+    assert not torch.isfinite(loss).all()

@@ -353,10 +353,10 @@ def _full_size_case(arch_name, method, lora_r, seed=2):
     return arch, sd
 
 
-@pytest.mark.parametrize("arch_name,method,lora_r", [("ViT-B/32", "lora", 8), ("ViT-B/16", "compacter", 4),
-                                                      ("ViT-L/14", "kadaptation", 4)])
+@pytest.mark.parametrize("arch_name,method,lora_r", [("ViT-B/32", "kadaptation", 4), ("ViT-B/32", "lora", 8),
+                                                      ("ViT-B/16", "compacter", 4), ("ViT-L/14", "kadaptation", 4)])
 def test_baseline_config_architectures_vs_oracle(arch_name, method, lora_r):
-    """BASELINE configs 3 (ViT-B/32 + LoRA r=8), 4 (ViT-B/16 + Compacter, N=197) and 5 (ViT-L/14 + KAdaptation,
+    """BASELINE configs 2 (the headline: ViT-B/32 + KAdaptation), 3 (ViT-B/32 + LoRA r=8), 4 (ViT-B/16 + Compacter, N=197) and 5 (ViT-L/14 + KAdaptation,
     width 1024, 24 layers, N=257, patch 14) at their real width and depth, batch 8 (what the CPU oracle finishes
     in seconds): whole step against the live oracle.  Same gates as the 12-layer fixture test, widened per
     tensor only where bf16 operand rounding alone exceeds them (24 layers accumulate more of it)."""
@@ -382,7 +382,9 @@ def test_baseline_config_architectures_vs_oracle(arch_name, method, lora_r):
     torch.cuda.synchronize()
     assert torch.isfinite(logits).all() and torch.isfinite(eng.grads).all()
     assert max_rel(logits.cpu(), ref_logits) < tol(DEEP_LOGIT_TOL, logit_noise)
-    assert abs(float(loss) - float(ref_loss)) < 5e-2
+    # mean cross-entropy is 2-Lipschitz in the sup norm of the logits: the loss may move by at most twice what the gated
+    # logits moved (24 random-weight layers move them by ~10 % under bf16 operand rounding alone)
+    assert abs(float(loss) - float(ref_loss)) <= max(5e-2, 2.0 * float((logits.cpu() - ref_logits).abs().max()))
     gv = eng.grad_views()
     worst = max(noise.values())
     for k in tr.names:
@@ -391,6 +393,49 @@ def test_baseline_config_architectures_vs_oracle(arch_name, method, lora_r):
         else:
             err = rel_err(gv[k].cpu(), tr.p[k].grad)
             assert err < tol(DEEP_GRAD_TOL, noise[k], worst), (k, err, noise[k])
+    for k, ref in (("layers.0.weight", tr.head_w.grad), ("layers.0.bias", tr.head_b.grad)):
+        assert rel_err(gv[k].cpu(), ref) < tol(DEEP_GRAD_TOL, noise[k], worst), k
+
+
+@pytest.mark.parametrize("method", ["kadaptation", "lora"])
+def test_whole_train_step_at_b128_vs_oracle(method):
+    """BASELINE config 2's batch (B = 128, 6400 token rows, the tile shapes and grid sizes bench.py runs) through the WHOLE
+    step -- images -> loss -> every gradient -> SGD update -- against the CPU oracle, on a tower with ViT-B/32's width,
+    patch and token count cut to two blocks so that the oracle finishes in seconds.  Full tensors, not norms."""
+    from oracle import ref_cpu
+    from pevit_amd.engine import HipEngine
+    from pevit_amd.synth import synth_batch
+    arch, sd = _full_size_case("ViT-B/32-2L", method, 8 if method == "lora" else 4)
+    B, C = 128, 100
+    images, labels = synth_batch(B, arch.resolution, C, seed_img=3, seed_lbl=4)
+    g = torch.Generator().manual_seed(5)
+    D = arch.embed_dim
+    head_w = (torch.rand((C, D), generator=g) * 2 - 1) / D ** 0.5
+    head_b = (torch.rand((C,), generator=g) * 2 - 1) / D ** 0.5
+    tr, ref_logits, ref_loss, logit_noise, noise = bf16_noise(sd, method, C, images, labels, head_w, head_b)
+    eng = HipEngine(arch, method, C, B, lora_rank=8 if method == "lora" else 4)
+    eng.load_state_dict(sd)
+    v = eng.param_views()
+    with torch.no_grad():
+        v["layers.0.weight"].copy_(head_w); v["layers.0.bias"].copy_(head_b)
+    p_before = eng.params.clone()
+    logits, loss = eng.train_step(images.cuda(), labels.cuda(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    torch.cuda.synchronize()
+    assert max_rel(logits.cpu(), ref_logits) < LOGIT_TOL
+    assert abs(float(loss) - float(ref_loss)) < LOSS_TOL
+    gv = eng.grad_views()
+    for k in tr.names:
+        if tr.p[k].grad is None:
+            assert float(gv[k].abs().max()) == 0.0
+        else:
+            err = rel_err(gv[k].cpu(), tr.p[k].grad)
+            assert err < tol(GRAD_TOL, noise[k]), (k, err, noise[k])          # no "worst tensor" widening here
+    assert rel_err(gv["layers.0.weight"].cpu(), tr.head_w.grad) < GRAD_TOL
+    # the update itself: first SGD step = p - lr * (g + wd * p) on every tensor that has a gradient
+    upd = p_before - 0.01 * (eng.grads + 1e-4 * p_before)
+    mask = eng.grad_mask.bool()
+    assert max_rel(eng.params[mask].cpu(), upd[mask].cpu()) < 1e-6
+    assert torch.equal(eng.params[~mask], p_before[~mask])
 
 
 @pytest.mark.parametrize("arch_name,method,lora_r,B", [("ViT-B/32", "lora", 8, 128), ("ViT-B/16", "compacter", 4, 64),

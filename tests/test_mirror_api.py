@@ -319,3 +319,39 @@ def test_consecutive_classifiers_reuse_the_backbone(ckpt):
     assert 0.0 < float(named["visual.transformer.phm_rule1_left"].abs().max()) <= 0.01
     assert [n for n, p in c.named_parameters() if p.requires_grad][-2:] == ["layers.0.weight", "layers.0.bias"]
     _harness._BACKBONES.clear()
+
+
+def test_script_path_launchers_exist_and_parse(tmp_path):
+    """reference scripts/*.sh do `cd ../vision_benchmark; python commands/<name>.py --ds resources/datasets/<d>.yaml
+    --model resources/model/<m>.yaml ...` (scripts/kadapter_clip.sh:65-70): the launchers and the two yaml files must be
+    at those relative paths and accept the reference's flags."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    vb = os.path.join(root, "vision_benchmark")
+    for name in ("kronecker_adaptation_clip", "lora_clip", "compacter_clip", "adapter_clip"):
+        assert os.path.isfile(os.path.join(vb, "commands", name + ".py"))
+    out = subprocess.run([sys.executable, "commands/kronecker_adaptation_clip.py", "--help"], cwd=vb, capture_output=True, text=True)
+    assert out.returncode == 0 and "--no-tuning" in out.stdout and "--ds" in out.stdout
+    from pevit_amd.config import update_config
+    cfg = default_config()
+    for rel in ("resources/datasets/cifar100.yaml", "resources/model/vitb32_CLIP.yaml"):
+        update_config(cfg, types.SimpleNamespace(cfg=os.path.join(vb, rel), opts=[]))
+    assert cfg.MODEL.NAME == "ViT-B/32" and cfg.DATASET.NUM_CLASSES == 100 and cfg.TRAIN.END_EPOCH == 10
+
+
+def test_transformer_seam_is_callable_and_train_mode_is_refused():
+    """model.visual.transformer is the reference's operator seam (model.py:1013): a module with forward(x: (N,B,E)); the
+    KAdaptation tower carries kdropout (model.py:516,582), which only acts in train mode -- the reference never enters it
+    and the engine refuses it instead of silently differing."""
+    model = build_model(load_tiny_sd())
+    tr = model.visual.transformer
+    assert callable(tr) and type(tr).forward is not torch.nn.Module.forward and tr.kdropout == 0.5
+    assert not model.training and not model.visual.training
+    with pytest.raises(_lib.PevitError, match="kdropout"):
+        model.train()
+    model.eval()
+    with pytest.raises(_lib.PevitError, match="no PyTorch/CPU fallback"):
+        tr(torch.zeros(10, 2, 128))                       # CPU tensors: the seam runs only in the HIP engine
+    lora = build_peft_model(load_tiny_sd(), "lora")
+    lora.train(); lora.eval()                             # no dropout on the other methods' paths
