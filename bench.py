@@ -85,6 +85,33 @@ def cpu_model():
     return "unknown CPU"
 
 
+def kernels_hash():
+    """sha256 over the kernel sources the library is built from: a PMC pass is only valid for the kernels it profiled."""
+    import hashlib
+    d = os.path.join(ROOT, "pevit_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")) or name == "Makefile":
+            h.update(name.encode()); h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def measured_attainable_peak(dev):
+    """What a vendor-library bf16 GEMM reaches on THIS device right now (4096^3, torch.matmul -> hipBLASLt): the practical
+    ceiling next to the 2.5 PFLOP/s nominal peak.  Measurement only -- the product path never calls a BLAS library."""
+    n = 4096
+    a = torch.randn(n, n, device=dev, dtype=torch.bfloat16); b = torch.randn(n, n, device=dev, dtype=torch.bfloat16)
+    for _ in range(3):
+        a @ b
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        a @ b
+    e1.record(); torch.cuda.synchronize(dev)
+    return 10 * 2.0 * n ** 3 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+
+
 def pmc_traffic(arch, method, batch):
     """HBM bytes per GEMM launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE and
     WRITE_SIZE cannot share a pass and cannot be read from inside this process; scripts/pmc_traffic.py
@@ -97,6 +124,9 @@ def pmc_traffic(arch, method, batch):
         entry = None
     if not entry:
         return None, "no PMC pass committed for this workload"
+    if entry.get("kernels_hash") != kernels_hash():
+        return None, ("the committed PMC pass (profiles/hbm_traffic.json, kernels %s) was taken with different kernel sources "
+                      "than this build (%s): re-run scripts/run_pmc_passes.sh" % (entry.get("kernels_hash"), kernels_hash()))
     return entry["gemm"]["hbm_bytes_per_launch"], entry["how"]
 
 
@@ -201,7 +231,8 @@ def main():
         step_tflops = value / world * gflop / 1e3      # whole-step algorithmic TFLOP/s per GPU
         gemm_tflops = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         algo_bytes = eng.last_profile_bytes / max(gemm_launches, 1)
-        traffic, traffic_how = pmc_traffic(args.arch, args.method, args.batch)
+        traffic, traffic_how = pmc_traffic(args.arch, args.method, args.batch) if args.weights == "bf16" else (None, "no PMC pass for fp8 weights")
+        attainable = measured_attainable_peak(dev)
         headline = (args.arch, args.method, args.batch, args.weights) == ("ViT-B/32", "kadaptation", 128, "bf16")
         metric = "images/sec fine-tune, CLIP ViT-B/32 + KAdaptation, bs=128, 1/2/4/8 GPU" if headline else \
             f"images/sec fine-tune, CLIP {args.arch} + {args.method}, bs={args.batch}/GPU, {args.weights} weights"
@@ -220,9 +251,10 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "gemm_bf16_nt_kernel (all epilogues / tile shapes)",
                          "achieved": gemm_tflops, "peak": PEAK_TFLOPS_BF16, "unit": "TFLOP/s",
                          "frac": gemm_tflops / PEAK_TFLOPS_BF16, "traffic": traffic, "traffic_unit": "bytes/launch",
-                         "peak_attainable_measured": {"value": 1422.0, "unit": "TFLOP/s",
-                                                      "how": "vendor library bf16 4096^3 on this hardware, round 1 "
-                                                             "(scripts/ref_gemm_torch.py, profiles/r01_l2_fetch_bound.md)"},
+                         "peak_attainable_measured": {"value": attainable, "unit": "TFLOP/s",
+                                                      "how": "vendor-library bf16 GEMM 4096^3 (torch.matmul), measured in this run "
+                                                             "after the timed region; not used by the product path"},
+                         "kernels_hash": kernels_hash(),
                          "traffic_how": traffic_how, "algorithmic_bytes_per_launch": algo_bytes,
                          "launches_per_step": gemm_launches / prof_steps,
                          "avg_launch_us": gemm_ms * 1e3 / max(gemm_launches, 1),
@@ -231,7 +263,11 @@ def main():
                          "how": "2*M*N*K of every GEMM launch / HIP-event duration of that launch (events on the "
                                 "launch stream), summed over %d steps" % prof_steps,
                          "whole_step": {"achieved": step_tflops, "frac": step_tflops / PEAK_TFLOPS_BF16,
-                                        "how": "images/s x algorithmic GFLOP/image (SURVEY 8d) / peak"}},
+                                        "how": "images/s x algorithmic GFLOP/image (SURVEY 8d) / peak",
+                                        # the last block runs its post-attention products on the class-token rows only
+                                        # (identical results): the matrix-core work actually executed per step is lower
+                                        "executed_gemm_tflop_per_step": gemm_flops / prof_steps / 1e12,
+                                        "executed_gemm_frac_of_peak": gemm_flops / prof_steps / 1e12 / (ms * 1e-3) / PEAK_TFLOPS_BF16}},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

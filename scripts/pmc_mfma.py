@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Matrix-core utilisation per kernel from a rocprofv3 PMC pass with SQ_VALU_MFMA_BUSY_CYCLES, SQ_BUSY_CYCLES and
+GRBM_GUI_ACTIVE (rocpd database).  MI355X_MICROARCH.md: SQ_VALU_MFMA_BUSY_CYCLES counts cycles (32 per
+v_mfma_f32_32x32x16_bf16 per SIMD); summed over the chip's 256 CUs x 4 SIMDs, utilisation = busy / (4 * 256 * active
+cycles), with GRBM_GUI_ACTIVE the kernel's active GPU cycles.  usage: pmc_mfma.py results.db"""
+import sqlite3, sys
+
+db = sqlite3.connect(sys.argv[1])
+rows = list(db.execute("select kernel_name, counter_name, count(*), sum(value) from counters_collection group by kernel_name, counter_name"))
+per = {}
+for k, c, n, v in rows:
+    per.setdefault(k, {})[c] = (n, v)
+print("| kernel | dispatches | MFMA busy cycles / dispatch | GPU active cycles / dispatch | MFMA utilisation (busy / (1024 SIMDs x active)) |")
+print("|---|---|---|---|---|")
+tot_busy = tot_act = 0.0
+fam_busy = fam_act = 0.0
+for k, d in sorted(per.items(), key=lambda kv: -kv[1].get("SQ_VALU_MFMA_BUSY_CYCLES", (0, 0))[1]):
+    if "SQ_VALU_MFMA_BUSY_CYCLES" not in d or "GRBM_GUI_ACTIVE" not in d:
+        continue
+    n, busy = d["SQ_VALU_MFMA_BUSY_CYCLES"]; _, act = d["GRBM_GUI_ACTIVE"]
+    tot_busy += busy; tot_act += act
+    if "gemm_kernel<" in k:
+        fam_busy += busy; fam_act += act
+    if busy <= 0:
+        continue
+    short = k.replace("(anonymous namespace)::", "")
+    print(f"| {short[:80]} | {n} | {busy / n:.3e} | {act / n:.3e} | {busy / (1024.0 * act):.3f} |")
+if fam_act:
+    print(f"\nGEMM family: {fam_busy / (1024.0 * fam_act):.3f} of the matrix-core cycles busy while its kernels run")
+if tot_act:
+    print(f"all kernels: {tot_busy / (1024.0 * tot_act):.3f}")

@@ -56,8 +56,8 @@ def main():
     w_counter = calib(write_db, "WRITE_SIZE", cal_w[0])
     read_factor = CAL_ELEMS * 4 / f_counter
     write_factor = CAL_ELEMS * 2 / w_counter
-    gn_f, gf = family(fetch, "gemm_bf16_nt_kernel")
-    gn_w, gw = family(write, "gemm_bf16_nt_kernel")
+    gn_f, gf = family(fetch, "gemm_kernel<")
+    gn_w, gw = family(write, "gemm_kernel<")
     assert gn_f == gn_w and gn_f > 0, (gn_f, gn_w)
     rd = gf * 1024.0 / gn_f * read_factor
     wr = gw * 1024.0 / gn_w * write_factor
@@ -66,10 +66,13 @@ def main():
                  "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr},
         "calibration": {"kernel": "cast_f32_to_bf16 over 2^28 elements (1 GiB read, 0.5 GiB written)",
                         "read_factor_true_over_counter": read_factor, "write_factor_true_over_counter": write_factor},
-        "how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, KiB), summed over every gemm_bf16_nt_kernel "
+        "how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, KiB), summed over every gemm_kernel<...> "
                "dispatch of `bench.py --steps 3 --warmup 1`, / dispatches, x the true/counter factor measured in the same pass "
                "on a 1 GiB streaming cast (read %.3f, write %.3f)" % (read_factor, write_factor),
     }
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from bench import kernels_hash
+    entry["kernels_hash"] = kernels_hash()          # bench.py reports `traffic` only while the kernel sources still match
     try:
         with open(out_path) as f:
             allv = json.load(f)

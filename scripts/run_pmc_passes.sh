@@ -1,12 +1,23 @@
+#!/bin/bash
+# rocprofv3 passes behind bench.py's roofline object: kernel trace + stats, HBM-side traffic (FETCH_SIZE and WRITE_SIZE in
+# separate passes, each self-calibrated on a known 1 GiB stream), and matrix-core utilisation (SQ_VALU_MFMA_BUSY_CYCLES).
+# PMC passes carry --kernel-trace only (gpurun refuses PMC combined with the API trace domains).
+# usage (on the GPU box, from the repo root):  bash scripts/run_pmc_passes.sh [tag]
 set -x
 export TMPDIR=/tmp
 R=$PWD
-mkdir -p $R/gpurun_out/pmc_fetch $R/gpurun_out/pmc_write $R/gpurun_out/ktrace
+TAG=${1:-r02}
+O=$R/gpurun_out/pmc_$TAG
+rm -rf $O; mkdir -p $O/fetch $O/write $O/ktrace $O/mfma
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/pmc_fetch -o f -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --pmc-calib > $R/gpurun_out/pmc_fetch.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/pmc_write -o w -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --pmc-calib > $R/gpurun_out/pmc_write.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/ktrace -o k -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $R/gpurun_out/ktrace.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o f -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --pmc-calib > $O/fetch.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o w -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --pmc-calib > $O/write.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/mfma -o m -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/mfma.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/ktrace -o k -- python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline > $O/ktrace.log 2>&1
 cd $R
-python bench.py --no-cpu-baseline > gpurun_out/bench_now.log 2>&1
-tail -2 gpurun_out/pmc_fetch.log | cut -c1-600; tail -1 gpurun_out/bench_now.log | cut -c1-1500
-find gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/ktrace -name "*.db" | head
+F=$(find $O/fetch -name "*.db" | head -1); W=$(find $O/write -name "*.db" | head -1); K=$(find $O/ktrace -name "*.db" | head -1); M=$(find $O/mfma -name "*.db" | head -1)
+python scripts/pmc_traffic.py $F $W "ViT-B/32|kadaptation|bs128" profiles/hbm_traffic.json > $O/traffic.txt 2>&1
+python scripts/prof_summary.py $K 35 > $O/kernel_stats.md 2>&1
+python scripts/pmc_mfma.py $M > $O/mfma_util.md 2>&1
+python bench.py > $O/bench_line.json 2>$O/bench_err.log
+tail -3 $O/traffic.txt; head -12 $O/mfma_util.md; head -8 $O/kernel_stats.md; cut -c1-900 $O/bench_line.json
