@@ -53,9 +53,14 @@ enum pevit_method {
 
 enum pevit_weight_format {
     PEVIT_W_BF16 = 0,     /* frozen block weights rounded to bf16 (reference: fp32 parameters, model.py:1247-1250)    */
-    PEVIT_W_FP8_E4M3 = 1  /* OCP e4m3 codes + one power-of-two f32 scale per output channel, packed by
+    PEVIT_W_FP8_E4M3 = 1, /* OCP e4m3 codes + one power-of-two f32 scale per output channel, packed by
                              pevit_load_block; activations stay bf16, accumulation f32 (BASELINE config 5).  Bit-identical
                              to PEVIT_W_BF16 run on the de-quantised weights.  KAdaptation, LoRA and the frozen tower.  */
+    PEVIT_W_F32_VERIFY = 2 /* f32-class VERIFICATION mode, not a production format: weights and every activation kept in
+                             f32, the matrix-core contractions run as plain f32 kernels (csrc/verify.hip) inside the same
+                             launch sequences, layouts and index arithmetic.  Used by the parity tests to assert the stated
+                             gates against the reference's fixtures without bf16 operand rounding; ~20x slower; workspace
+                             and arena are twice the size.  KAdaptation, LoRA and the frozen tower.                     */
 };
 
 typedef struct pevit_dims {

@@ -21,7 +21,7 @@ class PevitDims(C.Structure):
                 ("num_classes", C.c_int32), ("weight_format", C.c_int32)]
 
 
-WEIGHT_FORMATS = {"bf16": 0, "fp8": 1}
+WEIGHT_FORMATS = {"bf16": 0, "fp8": 1, "f32-verify": 2}
 
 
 METHOD_IDS = {"kadaptation": 0, "lora": 1, "adapter": 2, "compacter": 3, "none": 4}

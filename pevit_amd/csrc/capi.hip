@@ -60,6 +60,8 @@ struct pevit_ctx {
     int E, L, H, N, P, R, D, C, G2, Kpatch;
     int NQ, NQpad;            // 3E+64 and its multiple-of-128 padding
     bool fp8 = false;         // frozen block weights as e4m3 codes + per-channel scales (fp8.hip)
+    bool f32 = false;         // f32-class verification mode: every bf16-declared buffer holds f32 (verify.hip)
+    size_t es = 2;            // bytes per element of those buffers
     float ascale;             // 160 (model.py:564) or alpha/r (lora_model.py:491)
     // arena
     BlockArena* blk = nullptr;
@@ -111,39 +113,39 @@ inline bool post_mlp(const pevit_ctx* c) { return c->d.method == PEVIT_ADAPTER |
 
 void layout_workspace(pevit_ctx* c, int B, LayerSaved* sav, size_t* total, pevit_ctx* fill) {
     Carver cv;
-    const size_t T = (size_t)B * c->N, E = c->E;
+    const size_t T = (size_t)B * c->N, E = c->E, es = c->es;
     for (int l = 0; l < c->L; ++l) {
         LayerSaved s;
         s.x_in = cv.take(T * E * 4);
         s.x_mid = cv.take(T * E * 4);
         s.mean1 = cv.take(T * 4); s.rstd1 = cv.take(T * 4);
         s.mean2 = cv.take(T * 4); s.rstd2 = cv.take(T * 4);
-        s.xn1 = cv.take(T * E * 2);
-        s.qkv = cv.take(3 * T * E * 2);
+        s.xn1 = cv.take(T * E * es);
+        s.qkv = cv.take(3 * T * E * es);
         s.t = cv.take(T * 64 * 4);
         s.lse = cv.take((size_t)B * c->H * c->N * 4);
-        s.attn_out = cv.take(T * E * 2);
-        s.h = cv.take(T * 4 * E * 2);
+        s.attn_out = cv.take(T * E * es);
+        s.h = cv.take(T * 4 * E * es);
         s.hf32 = s.mean_a = s.rstd_a = s.z = s.apre = s.act = 0;
         if (post_mlp(c)) {
             s.hf32 = cv.take(T * E * 4); s.mean_a = cv.take(T * 4); s.rstd_a = cv.take(T * 4);
-            s.z = cv.take(T * E * 2); s.apre = cv.take(T * 64 * 2); s.act = cv.take(T * 64 * 2);
+            s.z = cv.take(T * E * es); s.apre = cv.take(T * 64 * es); s.act = cv.take(T * 64 * es);
         }
         if (sav) sav[l] = s;
     }
     const int chunks = pevit_lowrank_chunks((int)T);
     size_t o;
     o = cv.take(T * E * 4);                 if (fill) fill->w_xfinal = o;
-    o = cv.take(T * E * 2);                 if (fill) fill->w_xn2 = o;
-    o = cv.take(T * 4 * E * 2);             if (fill) fill->w_g = o;
-    o = cv.take(T * (size_t)c->NQ * 2);     if (fill) fill->w_dqkv = o;
+    o = cv.take(T * E * es);                 if (fill) fill->w_xn2 = o;
+    o = cv.take(T * 4 * E * es);             if (fill) fill->w_g = o;
+    o = cv.take(T * (size_t)c->NQ * es);     if (fill) fill->w_dqkv = o;
     o = cv.take(T * 64 * 4);                if (fill) fill->w_u32 = o;
-    o = cv.take(T * E * 2);                 if (fill) fill->w_dO = o;
-    o = cv.take(T * 4 * E * 2);             if (fill) fill->w_dh = o;
+    o = cv.take(T * E * es);                 if (fill) fill->w_dO = o;
+    o = cv.take(T * 4 * E * es);             if (fill) fill->w_dh = o;
     o = cv.take(T * E * 4);                 if (fill) fill->w_dxn = o;
     o = cv.take(T * E * 4);                 if (fill) fill->w_dxa = o;
     o = cv.take(T * E * 4);                 if (fill) fill->w_dxb = o;
-    o = cv.take(T * E * 2);                 if (fill) fill->w_dyb = o;
+    o = cv.take(T * E * es);                 if (fill) fill->w_dyb = o;
     // adapter-gradient partials of every layer (reduced once per step, after the layer loop)
     const size_t part_layer = align_up((size_t)chunks * 4 * E * 32 * 4, 256), db_layer = align_up((size_t)chunks * 2 * E * 4, 256);
     o = cv.take(part_layer * c->L);                      if (fill) { fill->w_partial = o; fill->partial_layer = part_layer; }
@@ -154,9 +156,9 @@ void layout_workspace(pevit_ctx* c, int B, LayerSaved* sav, size_t* total, pevit
         const int tch = pevit_tn_chunks((int)T), lnb = pevit_lna_blocks((int)T);
         const size_t tn_layer = (size_t)tch * E * 64 * 4, csx_layer = (size_t)tch * E * 4, csy_layer = (size_t)tch * 64 * 4,
                      lnp_layer = (size_t)lnb * 3 * E * 4;
-        o = cv.take(T * 64 * 2);            if (fill) fill->w_dpre = o;
+        o = cv.take(T * 64 * es);            if (fill) fill->w_dpre = o;
         o = cv.take(T * E * 4);             if (fill) fill->w_dht = o;
-        o = cv.take(T * E * 2);             if (fill) fill->w_dhb = o;
+        o = cv.take(T * E * es);             if (fill) fill->w_dhb = o;
         o = cv.take(tn_layer * c->L);       if (fill) { fill->w_tnU = o; fill->tn_layer = tn_layer; }
         o = cv.take(tn_layer * c->L);       if (fill) fill->w_tnD = o;
         o = cv.take(csx_layer * c->L);      if (fill) { fill->w_csx = o; fill->csx_layer = csx_layer; }
@@ -166,8 +168,8 @@ void layout_workspace(pevit_ctx* c, int B, LayerSaved* sav, size_t* total, pevit
         o = cv.take((size_t)c->L * E * 64 * 4);  if (fill) fill->w_Gu = o;
     }
     const size_t Bz = (size_t)B, D = c->D, Cc = c->C;
-    o = cv.take(Bz * c->G2 * (size_t)c->Kpatch * 2);      if (fill) fill->w_patches = o;
-    o = cv.take(Bz * E * 2);      if (fill) fill->w_xpost = o;
+    o = cv.take(Bz * c->G2 * (size_t)c->Kpatch * es);      if (fill) fill->w_patches = o;
+    o = cv.take(Bz * E * es);      if (fill) fill->w_xpost = o;
     o = cv.take(Bz * D * 4);      if (fill) fill->w_feat = o;
     o = cv.take(Bz * 4);          if (fill) fill->w_pmean = o;
     o = cv.take(Bz * 4);          if (fill) fill->w_prstd = o;
@@ -177,13 +179,17 @@ void layout_workspace(pevit_ctx* c, int B, LayerSaved* sav, size_t* total, pevit
     o = cv.take(Bz * Cc * 4);     if (fill) fill->w_dlogits = o;
     o = cv.take(Bz * D * 4);      if (fill) fill->w_dybn = o;
     o = cv.take(Bz * D * 4);      if (fill) fill->w_dfeat = o;
-    o = cv.take(Bz * D * 2);      if (fill) fill->w_dfeatb = o;
+    o = cv.take(Bz * D * es);      if (fill) fill->w_dfeatb = o;
     o = cv.take(Bz * E * 4);      if (fill) fill->w_dxpost = o;
     *total = cv.off;
 }
 
 template <typename T>
 inline T* at(char* base, size_t off) { return reinterpret_cast<T*>(base + off); }
+// advance a bf16-declared pointer by `elems` elements of the context's storage type (bf16, or f32 in verification mode)
+inline bf16* eadv(const pevit_ctx* c, const bf16* p, size_t elems) {
+    return reinterpret_cast<bf16*>(const_cast<char*>(reinterpret_cast<const char*>(p)) + elems * c->es);
+}
 
 }  // namespace
 
@@ -201,11 +207,14 @@ extern "C" int pevit_ctx_create(const pevit_dims* dims, pevit_ctx** out) {
     if (d.method == PEVIT_LORA && (d.lora_rank < 1 || d.lora_rank > 32)) {
         pevit_set_error("ctx_create: LoRA rank %d outside [1,32]", d.lora_rank); return -1;
     }
-    if (d.weight_format != PEVIT_W_BF16 && d.weight_format != PEVIT_W_FP8_E4M3) {
+    if (d.weight_format != PEVIT_W_BF16 && d.weight_format != PEVIT_W_FP8_E4M3 && d.weight_format != PEVIT_W_F32_VERIFY) {
         pevit_set_error("ctx_create: unknown weight_format %d", d.weight_format); return -1;
     }
     if (d.weight_format == PEVIT_W_FP8_E4M3 && (d.method == PEVIT_ADAPTER || d.method == PEVIT_COMPACTER)) {
         pevit_set_error("ctx_create: fp8 weights are built for the attention-site methods (KAdaptation, LoRA) and the frozen tower"); return -1;
+    }
+    if (d.weight_format == PEVIT_W_F32_VERIFY && (d.method == PEVIT_ADAPTER || d.method == PEVIT_COMPACTER)) {
+        pevit_set_error("ctx_create: the f32 verification mode covers the attention-site methods (KAdaptation, LoRA) and the frozen tower"); return -1;
     }
     if (d.out_dim <= 0 || d.out_dim % 8 != 0 || d.num_classes <= 0) {
         pevit_set_error("ctx_create: bad out_dim/num_classes %d/%d", d.out_dim, d.num_classes); return -1;
@@ -220,6 +229,8 @@ extern "C" int pevit_ctx_create(const pevit_dims* dims, pevit_ctx** out) {
     c->NQ = 3 * c->E + 64; c->NQpad = (int)align_up((size_t)c->NQ, 128);
     c->ascale = d.method == PEVIT_LORA ? 128.0f / (float)d.lora_rank : 160.0f;
     c->fp8 = d.weight_format == PEVIT_W_FP8_E4M3;
+    c->f32 = d.weight_format == PEVIT_W_F32_VERIFY;
+    c->es = c->f32 ? 4 : 2;
     if (c->N > 288) { pevit_set_error("ctx_create: %d tokens per image exceeds 288", c->N); delete c; return -1; }
 
     // ---- weight arena -------------------------------------------------------------
@@ -242,24 +253,25 @@ extern "C" int pevit_ctx_create(const pevit_dims* dims, pevit_ctx** out) {
             b.wpr = cv.take(r1 * 4 * E);  b.wprT = cv.take(r4 * E);
             b.sqkv = cv.take(3 * E * 4); b.so = cv.take(E * 4); b.sfc = cv.take(4 * E * 4); b.spr = cv.take(E * 4);
         } else {
-            b.wqkv = cv.take((size_t)c->NQpad * E * 2);
-            b.wqkvT = cv.take(E * (size_t)c->NQ * 2);
-            b.wo = cv.take(E * E * 2);   b.woT = cv.take(E * E * 2);
-            b.wfc = cv.take(4 * E * E * 2); b.wfcT = cv.take(4 * E * E * 2);
-            b.wpr = cv.take(4 * E * E * 2); b.wprT = cv.take(4 * E * E * 2);
+            const size_t es = c->es;
+            b.wqkv = cv.take((size_t)c->NQpad * E * es);
+            b.wqkvT = cv.take(E * (size_t)c->NQ * es);
+            b.wo = cv.take(E * E * es);   b.woT = cv.take(E * E * es);
+            b.wfc = cv.take(4 * E * E * es); b.wfcT = cv.take(4 * E * E * es);
+            b.wpr = cv.take(4 * E * E * es); b.wprT = cv.take(4 * E * E * es);
         }
         b.bqkv = cv.take(3 * E * 4); b.bo = cv.take(E * 4); b.bfc = cv.take(4 * E * 4); b.bpr = cv.take(E * 4);
         b.ln1w = cv.take(E * 4); b.ln1b = cv.take(E * 4); b.ln2w = cv.take(E * 4); b.ln2b = cv.take(E * 4);
-        b.q32 = cv.take(E * 64 * 4); b.qT = cv.take(64 * E * 2);
-        b.wd = cv.take(64 * E * 2); b.wdT = cv.take(64 * E * 2); b.wu = cv.take(64 * E * 2); b.wuT = cv.take(64 * E * 2);
+        b.q32 = cv.take(E * 64 * 4); b.qT = cv.take(64 * E * c->es);
+        b.wd = cv.take(64 * E * c->es); b.wdT = cv.take(64 * E * c->es); b.wu = cv.take(64 * E * c->es); b.wuT = cv.take(64 * E * c->es);
     }
-    c->a_conv = cv.take(align_up(E, 128) * (size_t)c->Kpatch * 2);
+    c->a_conv = cv.take(align_up(E, 128) * (size_t)c->Kpatch * c->es);
     c->a_cls = cv.take(E * 4);
     c->a_pos = cv.take((size_t)c->N * E * 4);
     c->a_lnpre_w = cv.take(E * 4); c->a_lnpre_b = cv.take(E * 4);
     c->a_lnpost_w = cv.take(E * 4); c->a_lnpost_b = cv.take(E * 4);
-    c->a_proj = cv.take(align_up((size_t)c->D, 128) * E * 2);      // [D][E]  (proj^T)
-    c->a_projT = cv.take(E * (size_t)c->D * 2);                   // [E][D]
+    c->a_proj = cv.take(align_up((size_t)c->D, 128) * E * c->es);      // [D][E]  (proj^T)
+    c->a_projT = cv.take(E * (size_t)c->D * c->es);                   // [E][D]
     c->a_phm = cv.take(64 * 4);
     c->arena_bytes = cv.off;
 
@@ -385,17 +397,18 @@ extern "C" int pevit_load_block(pevit_ctx* c, void* stream, int l, const float* 
         CHECK(pevit_launch_dequant_rows_fp8(at<u8>(A, b.wqkv), e, at<float>(A, b.sqkv), 3 * e, e, tmp, s));
         CHECK(pevit_launch_transpose_bf16(tmp, 3 * e, e, at<bf16>(A, b.wqkvT), c->NQ, 0, 1.0f, s));
     } else {
-        HIP_OK(hipMemsetAsync(A + b.wqkv, 0, (size_t)c->NQpad * E * 2, s));
-        CHECK(pevit_launch_cast_bf16(in_w, at<bf16>(A, b.wqkv), E * E, 0.125f, s));
-        CHECK(pevit_launch_cast_bf16(in_w + E * E, at<bf16>(A, b.wqkv) + E * E, 2 * E * E, 1.0f, s));
-        HIP_OK(hipMemsetAsync(A + b.wqkvT, 0, E * (size_t)c->NQ * 2, s));
-        CHECK(pevit_launch_transpose_bf16(in_w, 3 * (int)E, (int)E, at<bf16>(A, b.wqkvT), c->NQ, (int)E, 0.125f, s));
-        CHECK(pevit_launch_cast_bf16(out_w, at<bf16>(A, b.wo), E * E, 1.0f, s));
-        CHECK(pevit_launch_transpose_bf16(out_w, (int)E, (int)E, at<bf16>(A, b.woT), (int)E, 0, 1.0f, s));
-        CHECK(pevit_launch_cast_bf16(fc_w, at<bf16>(A, b.wfc), 4 * E * E, 1.0f, s));
-        CHECK(pevit_launch_transpose_bf16(fc_w, 4 * (int)E, (int)E, at<bf16>(A, b.wfcT), 4 * (int)E, 0, 1.0f, s));
-        CHECK(pevit_launch_cast_bf16(pr_w, at<bf16>(A, b.wpr), 4 * E * E, 1.0f, s));
-        CHECK(pevit_launch_transpose_bf16(pr_w, (int)E, 4 * (int)E, at<bf16>(A, b.wprT), (int)E, 0, 1.0f, s));
+        const int f = c->f32;
+        HIP_OK(hipMemsetAsync(A + b.wqkv, 0, (size_t)c->NQpad * E * c->es, s));
+        CHECK(pevit_launch_cast_bf16(in_w, at<bf16>(A, b.wqkv), E * E, 0.125f, s, f));
+        CHECK(pevit_launch_cast_bf16(in_w + E * E, eadv(c, at<bf16>(A, b.wqkv), E * E), 2 * E * E, 1.0f, s, f));
+        HIP_OK(hipMemsetAsync(A + b.wqkvT, 0, E * (size_t)c->NQ * c->es, s));
+        CHECK(pevit_launch_transpose_bf16(in_w, 3 * (int)E, (int)E, at<bf16>(A, b.wqkvT), c->NQ, (int)E, 0.125f, s, f));
+        CHECK(pevit_launch_cast_bf16(out_w, at<bf16>(A, b.wo), E * E, 1.0f, s, f));
+        CHECK(pevit_launch_transpose_bf16(out_w, (int)E, (int)E, at<bf16>(A, b.woT), (int)E, 0, 1.0f, s, f));
+        CHECK(pevit_launch_cast_bf16(fc_w, at<bf16>(A, b.wfc), 4 * E * E, 1.0f, s, f));
+        CHECK(pevit_launch_transpose_bf16(fc_w, 4 * (int)E, (int)E, at<bf16>(A, b.wfcT), 4 * (int)E, 0, 1.0f, s, f));
+        CHECK(pevit_launch_cast_bf16(pr_w, at<bf16>(A, b.wpr), 4 * E * E, 1.0f, s, f));
+        CHECK(pevit_launch_transpose_bf16(pr_w, (int)E, 4 * (int)E, at<bf16>(A, b.wprT), (int)E, 0, 1.0f, s, f));
     }
     // biases and LN affines stay f32; the q third of in_proj_bias carries the same 1/8
     HIP_OK(hipMemcpyAsync(A + b.bqkv, in_b, 3 * E * 4, hipMemcpyDeviceToDevice, s));
@@ -408,7 +421,7 @@ extern "C" int pevit_load_block(pevit_ctx* c, void* stream, int l, const float* 
     HIP_OK(hipMemcpyAsync(A + b.ln2w, ln2w, E * 4, hipMemcpyDeviceToDevice, s));
     HIP_OK(hipMemcpyAsync(A + b.ln2b, ln2b, E * 4, hipMemcpyDeviceToDevice, s));
     HIP_OK(hipMemsetAsync(A + b.q32, 0, E * 64 * 4, s));
-    HIP_OK(hipMemsetAsync(A + b.qT, 0, 64 * E * 2, s));
+    HIP_OK(hipMemsetAsync(A + b.qT, 0, 64 * E * c->es, s));
     return 0;
 }
 
@@ -425,9 +438,9 @@ int check_ready(pevit_ctx* c, int B, const char* who) {
 AdapterPanels panels(pevit_ctx* c, int l) {
     const BlockArena& b = c->blk[l];
     AdapterPanels p;
-    p.w_aug_rows = c->fp8 ? at<bf16>(c->arena, b.wpan) : at<bf16>(c->arena, b.wqkv) + (size_t)3 * c->E * c->E;
+    p.w_aug_rows = c->fp8 ? at<bf16>(c->arena, b.wpan) : eadv(c, at<bf16>(c->arena, b.wqkv), (size_t)3 * c->E * c->E);
     p.ldw = c->E;
-    p.wT_aug_cols = at<bf16>(c->arena, b.wqkvT) + 3 * c->E;
+    p.wT_aug_cols = eadv(c, at<bf16>(c->arena, b.wqkvT), 3 * (size_t)c->E);
     p.ldwT = c->NQ;
     p.q32 = at<float>(c->arena, b.q32);
     p.qT = at<bf16>(c->arena, b.qT);
@@ -443,11 +456,11 @@ int prep_adapters(pevit_ctx* c, hipStream_t s) {
     const float* lp = c->params + c->p_layer0;
     if (c->d.method == PEVIT_KADAPTATION) {
         const float* r = c->params;
-        CHECK(pevit_launch_prep_kadapt(r, r + 1024, r + 2048, r + 3072, lp, lp + E, panels(c, 0), c->E, c->ascale, c->L, st, s));
+        CHECK(pevit_launch_prep_kadapt(r, r + 1024, r + 2048, r + 3072, lp, lp + E, panels(c, 0), c->E, c->ascale, c->L, st, s, c->f32));
     } else if (c->d.method == PEVIT_LORA) {
         const size_t rE = (size_t)c->d.lora_rank * E;
         CHECK(pevit_launch_prep_lora(lp, lp + rE, lp + 2 * rE, lp + 3 * rE, c->d.lora_rank, panels(c, 0), c->E, c->ascale,
-                                     c->L, st, s));
+                                     c->L, st, s, c->f32));
     } else if (post_mlp(c)) {
         const BlockArena& b0 = c->blk[0];
         BottleneckPanels bp{at<bf16>(c->arena, b0.wd), at<bf16>(c->arena, b0.wdT), at<bf16>(c->arena, b0.wu),
@@ -465,7 +478,7 @@ int prep_adapters(pevit_ctx* c, hipStream_t s) {
 int gemm(pevit_ctx* c, int epi, const GemmParams& p, hipStream_t s) {
     const bool rec = c->prof_on && c->prof_n < c->prof_cap;
     if (rec) (void)hipEventRecord(c->prof_ev[2 * c->prof_n], s);
-    const int rc = pevit_launch_gemm(epi, p, c->tune, s);
+    const int rc = c->f32 ? pevit_launch_gemm_f32(epi, p, s) : pevit_launch_gemm(epi, p, c->tune, s);
     if (rec) {
         (void)hipEventRecord(c->prof_ev[2 * c->prof_n + 1], s);
         c->prof_flops[c->prof_n] = 2.0 * (double)p.M * (double)p.N * (double)p.K;
@@ -518,7 +531,7 @@ int blocks_forward(pevit_ctx* c, hipStream_t s, int B, bool cls_only) {
         const size_t plane = (size_t)T * E;
         // x = x + attn(ln_1(x))                                         model.py:973
         CHECK(pevit_launch_ln_fwd(x_in, at<float>(A, b.ln1w), at<float>(A, b.ln1b), T, E, at<bf16>(W, v.xn1), nullptr,
-                                  at<float>(W, v.mean1), at<float>(W, v.rstd1), s));
+                                  at<float>(W, v.mean1), at<float>(W, v.rstd1), s, 0, c->f32));
         if (!c->fp8) {
             GemmParams p = gp(at<bf16>(W, v.xn1), E, at<bf16>(A, b.wqkv), E, c->NQpad, T, site ? c->NQ : 3 * E, E);
             p.bias = at<float>(A, b.bqkv); p.outb = qkv; p.head_stride = plane; p.outf = at<float>(W, v.t); p.ldo = 64;
@@ -538,11 +551,15 @@ int blocks_forward(pevit_ctx* c, hipStream_t s, int B, bool cls_only) {
         if (site) {
             const float* bias = nullptr;
             if (c->d.method == PEVIT_KADAPTATION) bias = c->params + c->p_layer0 + c->p_layer_stride * l + 4 * (size_t)E;
-            CHECK(pevit_launch_delta_add(qkv, qkv + 2 * plane, at<float>(W, v.t), at<float>(A, b.q32), bias, c->ascale, B, N,
-                                         E, s));
+            CHECK(pevit_launch_delta_add(qkv, eadv(c, qkv, 2 * plane), at<float>(W, v.t), at<float>(A, b.q32), bias, c->ascale, B, N,
+                                         E, s, c->f32));
         }
-        CHECK(pevit_launch_attn_fwd(qkv, qkv + plane, qkv + 2 * plane, at<bf16>(W, v.attn_out), E, at<float>(W, v.lse), B,
-                                    H, N, s));
+        if (c->f32)
+            CHECK(pevit_launch_attn_fwd_f32((const float*)qkv, (const float*)eadv(c, qkv, plane), (const float*)eadv(c, qkv, 2 * plane),
+                                            at<float>(W, v.attn_out), E, at<float>(W, v.lse), B, H, N, s));
+        else
+            CHECK(pevit_launch_attn_fwd(qkv, qkv + plane, qkv + 2 * plane, at<bf16>(W, v.attn_out), E, at<float>(W, v.lse), B,
+                                        H, N, s));
         // rows of the tail of this block: all T, or (last block, cls_only) the B class-token rows, which
         // sit N*E elements apart in every [T][E] buffer
         const bool cls = cls_only && l == c->L - 1;
@@ -555,7 +572,7 @@ int blocks_forward(pevit_ctx* c, hipStream_t s, int B, bool cls_only) {
         }
         // x = x + mlp(ln_2(x))                                          model.py:974
         CHECK(pevit_launch_ln_fwd(x_mid, at<float>(A, b.ln2w), at<float>(A, b.ln2b), R, E, at<bf16>(W, c->w_xn2), nullptr,
-                                  at<float>(W, v.mean2), at<float>(W, v.rstd2), s, (size_t)rs));
+                                  at<float>(W, v.mean2), at<float>(W, v.rstd2), s, (size_t)rs, c->f32));
         {
             GemmParams p = gpw(c, at<bf16>(W, c->w_xn2), E, b.wfc, E, 4 * E, R, 4 * E, E, b.sfc);
             p.bias = at<float>(A, b.bfc); p.outb = at<bf16>(W, v.h); p.ldob = 4 * E; p.outb2 = at<bf16>(W, c->w_g);
@@ -683,7 +700,7 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0, bool cls_
         // fp8: the bf16 copy feeds the out-projection backward, whose contraction runs over out_proj's output channels
         CHECK(pevit_launch_ln_bwd(dxn, at<float>(W, v.x_mid), at<float>(W, v.mean2), at<float>(W, v.rstd2),
                                   at<float>(A, b.ln2w), dxa, dxb, dyb, R, E, s, (size_t)rs,
-                                  c->fp8 ? at<float>(A, b.so) : nullptr));
+                                  c->fp8 ? at<float>(A, b.so) : nullptr, c->f32));
         // ---- attention branch
         {
             GemmParams p = gpw(c, dyb, rs, b.woT, E, E, R, E, E, 0);
@@ -692,10 +709,19 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0, bool cls_
         }
         // dqkv / u32 are about to be overwritten: the previous layer's gradient contraction must have read them
         if (side_pending) { HIP_OK(hipStreamWaitEvent(s, c->ev_join, 0)); side_pending = false; }
-        CHECK(pevit_launch_attn_bwd(qkv, qkv + plane, qkv + 2 * plane, at<bf16>(W, v.attn_out), E, at<bf16>(W, c->w_dO), E,
-                                    at<float>(W, v.lse), dqkv, c->NQ, B, H, N, s));
+        if (c->f32)
+            CHECK(pevit_launch_attn_bwd_f32((const float*)qkv, (const float*)eadv(c, qkv, plane), (const float*)eadv(c, qkv, 2 * plane),
+                                            at<float>(W, v.attn_out), E, at<float>(W, c->w_dO), E, at<float>(W, v.lse), (float*)dqkv,
+                                            c->NQ, B, H, N, s));
+        else
+            CHECK(pevit_launch_attn_bwd(qkv, qkv + plane, qkv + 2 * plane, at<bf16>(W, v.attn_out), E, at<bf16>(W, c->w_dO), E,
+                                        at<float>(W, v.lse), dqkv, c->NQ, B, H, N, s));
         if (site) {
-            CHECK(pevit_launch_lowrank_u(dqkv, c->NQ, at<bf16>(A, b.qT), at<float>(W, c->w_u32), dqkv + 3 * E, B, H, N, E, s));
+            if (c->f32)
+                CHECK(pevit_launch_lowrank_u_f32((const float*)dqkv, c->NQ, at<float>(A, b.q32), at<float>(W, c->w_u32),
+                                                 (float*)eadv(c, dqkv, 3 * (size_t)E), B, H, N, E, s));
+            else
+                CHECK(pevit_launch_lowrank_u(dqkv, c->NQ, at<bf16>(A, b.qT), at<float>(W, c->w_u32), dqkv + 3 * E, B, H, N, E, s));
             // the token-contracted adapter gradients feed nothing before the end of the step: run them beside
             // the QKV-backward GEMM / LayerNorm backward / next layer's MLP GEMMs on the second stream
             hipStream_t gs = s;
@@ -704,9 +730,14 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0, bool cls_
                 HIP_OK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
                 gs = c->side;
             }
-            CHECK(pevit_launch_lowrank_grad(at<bf16>(W, v.xn1), E, at<float>(W, c->w_u32), dqkv, c->NQ, at<float>(W, v.t),
-                                            at<float>(W, c->w_partial + (size_t)l * c->partial_layer),
-                                            at<float>(W, c->w_dbias + (size_t)l * c->dbias_layer), chunks, B, H, N, E, gs));
+            if (c->f32)
+                CHECK(pevit_launch_lowrank_grad_f32(at<float>(W, v.xn1), E, at<float>(W, c->w_u32), (const float*)dqkv, c->NQ,
+                                                    at<float>(W, v.t), at<float>(W, c->w_partial + (size_t)l * c->partial_layer),
+                                                    at<float>(W, c->w_dbias + (size_t)l * c->dbias_layer), chunks, B, H, N, E, gs));
+            else
+                CHECK(pevit_launch_lowrank_grad(at<bf16>(W, v.xn1), E, at<float>(W, c->w_u32), dqkv, c->NQ, at<float>(W, v.t),
+                                                at<float>(W, c->w_partial + (size_t)l * c->partial_layer),
+                                                at<float>(W, c->w_dbias + (size_t)l * c->dbias_layer), chunks, B, H, N, E, gs));
             if (use_side) { HIP_OK(hipEventRecord(c->ev_join, c->side)); side_pending = true; }
         }
         if (l > 0 || need_dx0) {
@@ -716,7 +747,7 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0, bool cls_
             // fp8: this bf16 copy is the upstream gradient of layer l-1's c_proj backward
             CHECK(pevit_launch_ln_bwd(dxn, at<float>(W, v.x_in), at<float>(W, v.mean1), at<float>(W, v.rstd1),
                                       at<float>(A, b.ln1w), dxb, dxa, dyb, T, E, s, 0,
-                                      (c->fp8 && l > 0) ? at<float>(A, c->blk[l - 1].spr) : nullptr));
+                                      (c->fp8 && l > 0) ? at<float>(A, c->blk[l - 1].spr) : nullptr, c->f32));
         }
     }
     if (side_pending) HIP_OK(hipStreamWaitEvent(s, c->ev_join, 0));
@@ -789,7 +820,7 @@ extern "C" int pevit_transformer_backward(pevit_ctx* c, void* stream, const floa
         CHECK(pevit_launch_cast_bf16_cols(at<float>(c->ws, c->w_dxa), at<bf16>(c->ws, c->w_dyb), (size_t)B * c->N, c->E,
                                           at<float>(c->arena, c->blk[c->L - 1].spr), s));
     else
-        CHECK(pevit_launch_cast_bf16(at<float>(c->ws, c->w_dxa), at<bf16>(c->ws, c->w_dyb), n, 1.0f, s));
+        CHECK(pevit_launch_cast_bf16(at<float>(c->ws, c->w_dxa), at<bf16>(c->ws, c->w_dyb), n, 1.0f, s, c->f32));
     CHECK(blocks_backward(c, s, B, dx_nbe != nullptr, false, c->L, 0));
     if (dx_nbe) CHECK(pevit_launch_permute_rows(at<float>(c->ws, c->w_dxa), dx_nbe, c->N, B, c->E, 0, s));
     return 0;
@@ -816,7 +847,7 @@ extern "C" int pevit_load_stem(pevit_ctx* c, void* stream, const float* conv_w, 
     hipStream_t s = (hipStream_t)stream;
     char* A = c->arena;
     const size_t E = c->E;
-    CHECK(pevit_launch_conv_weight(conv_w, at<bf16>(A, c->a_conv), c->E, 3 * c->P * c->P, c->Kpatch, s));
+    CHECK(pevit_launch_conv_weight(conv_w, at<bf16>(A, c->a_conv), c->E, 3 * c->P * c->P, c->Kpatch, s, c->f32));
     HIP_OK(hipMemcpyAsync(A + c->a_cls, cls, E * 4, hipMemcpyDeviceToDevice, s));
     HIP_OK(hipMemcpyAsync(A + c->a_pos, pos, (size_t)c->N * E * 4, hipMemcpyDeviceToDevice, s));
     HIP_OK(hipMemcpyAsync(A + c->a_lnpre_w, lnpre_w, E * 4, hipMemcpyDeviceToDevice, s));
@@ -824,8 +855,8 @@ extern "C" int pevit_load_stem(pevit_ctx* c, void* stream, const float* conv_w, 
     HIP_OK(hipMemcpyAsync(A + c->a_lnpost_w, lnpost_w, E * 4, hipMemcpyDeviceToDevice, s));
     HIP_OK(hipMemcpyAsync(A + c->a_lnpost_b, lnpost_b, E * 4, hipMemcpyDeviceToDevice, s));
     // proj is (E, D): feat = x @ proj  ->  B operand [D][E] = proj^T ; backward uses proj itself [E][D]
-    CHECK(pevit_launch_transpose_bf16(proj, c->E, c->D, at<bf16>(A, c->a_proj), c->E, 0, 1.0f, s));
-    CHECK(pevit_launch_cast_bf16(proj, at<bf16>(A, c->a_projT), E * (size_t)c->D, 1.0f, s));
+    CHECK(pevit_launch_transpose_bf16(proj, c->E, c->D, at<bf16>(A, c->a_proj), c->E, 0, 1.0f, s, c->f32));
+    CHECK(pevit_launch_cast_bf16(proj, at<bf16>(A, c->a_projT), E * (size_t)c->D, 1.0f, s, c->f32));
     return 0;
 }
 
@@ -844,7 +875,7 @@ extern "C" int pevit_visual_forward(pevit_ctx* c, void* stream, const float* ima
     char* W = c->ws; char* A = c->arena;
     const int E = c->E, N = c->N, T = B * N;
     float* xpre = at<float>(W, c->w_dxn);               // scratch, free during the forward pass
-    CHECK(pevit_launch_im2col(images, at<bf16>(W, c->w_patches), B, c->R, c->P, c->Kpatch, s));
+    CHECK(pevit_launch_im2col(images, at<bf16>(W, c->w_patches), B, c->R, c->P, c->Kpatch, s, c->f32));
     CHECK(pevit_launch_cls_row(at<float>(A, c->a_cls), at<float>(A, c->a_pos), xpre, B, N, E, s));
     {
         GemmParams p = gp(at<bf16>(W, c->w_patches), c->Kpatch, at<bf16>(A, c->a_conv), c->Kpatch, E, B * c->G2, E, c->Kpatch);
@@ -857,7 +888,7 @@ extern "C" int pevit_visual_forward(pevit_ctx* c, void* stream, const float* ima
     // ln_post on the class token of every image (row b*N), then @ proj
     CHECK(pevit_launch_ln_fwd(at<float>(W, c->w_xfinal), at<float>(A, c->a_lnpost_w), at<float>(A, c->a_lnpost_b), B, E,
                               at<bf16>(W, c->w_xpost), nullptr, at<float>(W, c->w_pmean), at<float>(W, c->w_prstd), s,
-                              (size_t)N * E));
+                              (size_t)N * E, c->f32));
     {
         GemmParams p = gp(at<bf16>(W, c->w_xpost), E, at<bf16>(A, c->a_proj), E, c->D, B, c->D, E);
         p.outf = feat ? feat : at<float>(W, c->w_feat); p.ldo = c->D;
@@ -885,7 +916,7 @@ extern "C" int pevit_visual_backward_part(pevit_ctx* c, void* stream, const floa
     const bool cls = !post_mlp(c);
     if (l_hi == c->L) {
         if (!dfeat) { pevit_set_error("visual_backward: dfeat is required for the part that starts at the last block"); return -1; }
-        CHECK(pevit_launch_cast_bf16(dfeat, at<bf16>(W, c->w_dfeatb), (size_t)B * c->D, 1.0f, s));
+        CHECK(pevit_launch_cast_bf16(dfeat, at<bf16>(W, c->w_dfeatb), (size_t)B * c->D, 1.0f, s, c->f32));
         {
             GemmParams p = gp(at<bf16>(W, c->w_dfeatb), c->D, at<bf16>(A, c->a_projT), c->D, E, B, E, c->D);
             p.outf = at<float>(W, c->w_dxpost); p.ldo = E;
@@ -896,15 +927,15 @@ extern "C" int pevit_visual_backward_part(pevit_ctx* c, void* stream, const floa
         // LN1 backward consume (dO, dxb) are zeroed instead.
         if (cls) {
             HIP_OK(hipMemsetAsync(W + c->w_dxb, 0, (size_t)T * E * 4, s));
-            HIP_OK(hipMemsetAsync(W + c->w_dO, 0, (size_t)T * E * 2, s));
+            HIP_OK(hipMemsetAsync(W + c->w_dO, 0, (size_t)T * E * c->es, s));
         } else {
             HIP_OK(hipMemsetAsync(W + c->w_dxa, 0, (size_t)T * E * 4, s));
-            HIP_OK(hipMemsetAsync(W + c->w_dyb, 0, (size_t)T * E * 2, s));
+            HIP_OK(hipMemsetAsync(W + c->w_dyb, 0, (size_t)T * E * c->es, s));
         }
         CHECK(pevit_launch_ln_bwd(at<float>(W, c->w_dxpost), at<float>(W, c->w_xfinal), at<float>(W, c->w_pmean),
                                   at<float>(W, c->w_prstd), at<float>(A, c->a_lnpost_w), nullptr, at<float>(W, c->w_dxa),
                                   at<bf16>(W, c->w_dyb), B, E, s, (size_t)N * E,
-                                  c->fp8 ? at<float>(A, c->blk[c->L - 1].spr) : nullptr));
+                                  c->fp8 ? at<float>(A, c->blk[c->L - 1].spr) : nullptr, c->f32));
     }
     CHECK(blocks_backward(c, s, B, false, cls, l_hi, l_lo));
     return 0;

@@ -53,6 +53,24 @@ __device__ __forceinline__ bf16x8 zero_bf16x8() {
     return z;
 }
 
+// Activation / weight storage is bf16 in production and f32 in the f32-class verification mode (weight_format
+// PEVIT_W_F32_VERIFY); such buffers are declared bf16* everywhere and accessed through these helpers in the kernels
+// that serve both modes (ST = bf16 or float, offsets in elements of ST).
+template <typename ST> __device__ __forceinline__ void st_store(bf16* base, size_t off, float v) {
+    if constexpr (sizeof(ST) == 2) base[off] = f2bf(v); else reinterpret_cast<float*>(base)[off] = v;
+}
+template <typename ST> __device__ __forceinline__ float st_load(const bf16* base, size_t off) {
+    if constexpr (sizeof(ST) == 2) return bf2f(base[off]); else return reinterpret_cast<const float*>(base)[off];
+}
+template <typename ST> __device__ __forceinline__ void st_store4(bf16* base, size_t off, float a, float b, float c, float d) {
+    if constexpr (sizeof(ST) == 2) {
+        bf16x4 o; o[0] = f2bf(a); o[1] = f2bf(b); o[2] = f2bf(c); o[3] = f2bf(d);
+        *reinterpret_cast<bf16x4*>(base + off) = o;
+    } else {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + off) = make_float4(a, b, c, d);
+    }
+}
+
 // Asynchronous global -> LDS copy, 16 bytes per lane.  The LDS destination is
 // wave-uniform: the hardware writes lane l's 16 bytes at lds_wave_base + 16*l.
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {

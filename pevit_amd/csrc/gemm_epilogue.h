@@ -1,0 +1,158 @@
+// Fused GEMM epilogues, shared by the MFMA kernel (gemm.hip, bf16 storage) and the f32-class verification GEMM
+// (verify.hip, f32 storage): identical arithmetic, the storage type of the bf16-declared buffers is the template
+// parameter ST.
+#pragma once
+#include "common.h"
+#include "kernels.h"
+
+// 1 / (1 + e^-x) with the hardware exp2 and reciprocal (1 ulp each; the results are rounded to bf16): the IEEE division
+// hipcc emits for 1.0f / x is ~10 VALU instructions and made the GELU epilogues VALU-bound (18 instructions per element)
+__device__ __forceinline__ float sigmoidf_fast(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+// transformers' "gelu_new" (compacter_model.py:8,172): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+__device__ __forceinline__ float gelu_new_f(float x) {
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    return 0.5f * x * (1.0f + tanhf(u));
+}
+__device__ __forceinline__ float gelu_new_grad_f(float x) {
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    const float th = tanhf(u);
+    return 0.5f * (1.0f + th) + 0.5f * x * (1.0f - th * th) * 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * x * x);
+}
+
+__device__ __forceinline__ void add8(float v[8], const float* src) {
+    const float4 b0 = *reinterpret_cast<const float4*>(src);
+    const float4 b1 = *reinterpret_cast<const float4*>(src + 4);
+    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+    v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+}
+__device__ __forceinline__ void mul8(float v[8], const float* src) {
+    const float4 b0 = *reinterpret_cast<const float4*>(src);
+    const float4 b1 = *reinterpret_cast<const float4*>(src + 4);
+    v[0] *= b0.x; v[1] *= b0.y; v[2] *= b0.z; v[3] *= b0.w;
+    v[4] *= b1.x; v[5] *= b1.y; v[6] *= b1.z; v[7] *= b1.w;
+}
+__device__ __forceinline__ void store8f(float* dst, const float v[8]) {
+    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+// activation storage: bf16 (production) or f32 (the f32-class verification mode, PEVIT_W_F32_VERIFY); pointers are
+// declared bf16* throughout and reinterpreted here, element offsets are in elements of ST
+template <typename ST> __device__ __forceinline__ void store8s(bf16* base, size_t off, const float v[8]) {
+    if constexpr (sizeof(ST) == 2) {
+        bf16x8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = f2bf(v[i]);
+        store_bf16x8(base + off, o);
+    } else {
+        store8f(reinterpret_cast<float*>(base) + off, v);
+    }
+}
+template <typename ST> __device__ __forceinline__ void load8s(const bf16* base, size_t off, float v[8]) {
+    if constexpr (sizeof(ST) == 2) {
+        const bf16x8 h = load_bf16x8(base + off);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = bf2f(h[i]);
+    } else {
+        const float* p = reinterpret_cast<const float*>(base) + off;
+        const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+}
+// the value a stored activation will be read back as (bf16 rounding in production, identity in f32 mode)
+template <typename ST> __device__ __forceinline__ float as_stored(float x) {
+    if constexpr (sizeof(ST) == 2) return bf2f(f2bf(x)); else return x;
+}
+
+template <int EPI, typename ST>
+__device__ __forceinline__ void epilogue_store(const GemmParams& p, int row, int col, float v[8]) {
+    // row < M and col < N (col multiple of 8) are guaranteed by the caller.
+    if constexpr (EPI == EPI_QKV_HEADS) {
+        const int E3 = 3 * p.E;
+        if (col < E3) {
+            add8(v, p.bias + col);
+            const int which = col / p.E, ce = col - which * p.E;
+            const int h = ce >> 6, d = ce & 63;
+            const int b = row / p.Ntok, n = row - b * p.Ntok;
+            store8s<ST>(p.outb, (size_t)which * p.head_stride + ((size_t)(b * p.H + h) * p.Ntok + n) * 64 + d, v);
+        } else {
+            store8f(p.outf + (size_t)row * p.ldo + (col - E3), v);
+        }
+    } else if constexpr (EPI == EPI_BIAS_RESID_F32) {
+        add8(v, p.bias + col);
+        add8(v, p.resid + (size_t)row * p.ldr + col);
+        store8f(p.outf + (size_t)row * p.ldo + col, v);
+    } else if constexpr (EPI == EPI_BIAS_GELU) {
+        add8(v, p.bias + col);
+        float g[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            // QuickGELU (model.py:163-165) evaluated on the pre-activation AS STORED (bf16-rounded in production), which
+            // is what the backward pass will see, so fwd and bwd agree on the same h.
+            v[i] = as_stored<ST>(v[i]);
+            g[i] = v[i] * sigmoidf_fast(1.702f * v[i]);
+        }
+        store8s<ST>(p.outb, (size_t)row * p.ldob + col, v);
+        store8s<ST>(p.outb2, (size_t)row * p.ldob2 + col, g);
+    } else if constexpr (EPI == EPI_DGELU_BF16) {
+        float h[8];
+        load8s<ST>(p.aux, (size_t)row * p.ldaux + col, h);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float hv = h[i];
+            const float s = sigmoidf_fast(1.702f * hv);
+            v[i] = v[i] * (s * (1.0f + 1.702f * hv * (1.0f - s)));
+        }
+        // fp8 weights: the consumer (c_fc backward) contracts over these columns, whose power-of-two
+        // channel scales are folded into its A operand here (exact)
+        if (p.oscale) mul8(v, p.oscale + col);
+        store8s<ST>(p.outb, (size_t)row * p.ldob + col, v);
+    } else if constexpr (EPI == EPI_F32) {
+        store8f(p.outf + (size_t)row * p.ldo + col, v);
+    } else if constexpr (EPI == EPI_BF16) {
+        store8s<ST>(p.outb, (size_t)row * p.ldob + col, v);
+    } else if constexpr (EPI == EPI_BIAS_BF16) {
+        add8(v, p.bias + col);
+        store8s<ST>(p.outb, (size_t)row * p.ldob + col, v);
+    } else if constexpr (EPI == EPI_PATCH_EMBED) {
+        // row = b*G2 + g (patch index), output row = b*Ntok + 1 + g ; + positional embedding
+        const int G2 = p.Ntok - 1;
+        const int b = row / G2, g = row - b * G2;
+        add8(v, p.resid + (size_t)(1 + g) * p.ldr + col);
+        store8f(p.outf + ((size_t)b * p.Ntok + 1 + g) * p.ldo + col, v);
+    } else if constexpr (EPI == EPI_BIAS_RESID_KEEP) {
+        add8(v, p.bias + col);
+        store8f(p.outf2 + (size_t)row * p.ldo2 + col, v);
+        add8(v, p.resid + (size_t)row * p.ldr + col);
+        store8f(p.outf + (size_t)row * p.ldo + col, v);
+    } else if constexpr (EPI == EPI_BIAS_GELUNEW) {
+        add8(v, p.bias + col);
+        float g[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            v[i] = as_stored<ST>(v[i]);
+            g[i] = gelu_new_f(v[i]);
+        }
+        store8s<ST>(p.outb, (size_t)row * p.ldob + col, v);
+        store8s<ST>(p.outb2, (size_t)row * p.ldob2 + col, g);
+    } else if constexpr (EPI == EPI_DRELU_BF16) {
+        float a[8];
+        load8s<ST>(p.aux, (size_t)row * p.ldaux + col, a);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = a[i] > 0.f ? v[i] : 0.f;
+        store8s<ST>(p.outb, (size_t)row * p.ldob + col, v);
+    } else if constexpr (EPI == EPI_DGELUNEW_BF16) {
+        float a[8];
+        load8s<ST>(p.aux, (size_t)row * p.ldaux + col, a);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = v[i] * gelu_new_grad_f(a[i]);
+        store8s<ST>(p.outb, (size_t)row * p.ldob + col, v);
+    } else if constexpr (EPI == EPI_BIAS_RELU_BF16) {
+        add8(v, p.bias + col);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.0f);
+        store8s<ST>(p.outb, (size_t)row * p.ldob + col, v);
+    }
+}
+

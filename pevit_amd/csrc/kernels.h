@@ -56,11 +56,11 @@ int pevit_launch_gemm(int epi, const GemmParams& p, const GemmTune& t, hipStream
 // y = LN(x) * gamma + beta over the last dim (eps 1e-5, f32 statistics: model.py:154-160)
 int pevit_launch_ln_fwd(const float* x, const float* gamma, const float* beta, int rows, int E,
                         bf16* y_bf16, float* y_f32, float* mean, float* rstd, hipStream_t s,
-                        size_t xstride = 0);
+                        size_t xstride = 0, int f32 = 0);
 // dx_out = dres + LN-backward(dy)   (gamma/beta frozen: no parameter grads)
 int pevit_launch_ln_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
                         const float* gamma, const float* dres, float* dx_out, bf16* dx_bf16, int rows, int E,
-                        hipStream_t s, size_t xstride = 0, const float* bf16_colscale = nullptr);
+                        hipStream_t s, size_t xstride = 0, const float* bf16_colscale = nullptr, int f32 = 0);
 
 // ---- attention.hip ---------------------------------------------------------------
 // q,k,v: (B*H, N, 64) bf16 (q pre-scaled by 1/8, deltas already added); out: rows (b*N+n), cols h*64+d
@@ -84,14 +84,14 @@ struct LayerStrides { size_t arena_bytes; size_t param_floats; };   // per-layer
 // KAdaptation: P[:,j] = s_j (x) l_j , Q[:,j] = t_j (x) r_j   (model.py:567-580); all layers
 int pevit_launch_prep_kadapt(const float* rule1_l, const float* rule1_r, const float* rule2_l,
                              const float* rule2_r, const float* q_left, const float* q_right,
-                             AdapterPanels pan, int E, float ascale, int layers, LayerStrides st, hipStream_t s);
+                             AdapterPanels pan, int E, float ascale, int layers, LayerStrides st, hipStream_t s, int f32 = 0);
 // LoRA: P_q = A1q^T, Q_q = A2q (rank r zero-padded to 32)   (lora_model.py:490-514); all layers
 int pevit_launch_prep_lora(const float* a1q, const float* a2q, const float* a1v, const float* a2v,
-                           int r, AdapterPanels pan, int E, float ascale, int layers, LayerStrides st, hipStream_t s);
+                           int r, AdapterPanels pan, int E, float ascale, int layers, LayerStrides st, hipStream_t s, int f32 = 0);
 // q_buf_flat[rr*E+e] += ascale * t[row(rr)][0:32] . Q_q[e] + bias[e]   (and v with cols 32:64)
 // rr is the reference's (n*B+b) row index of the raw reshape (model.py:796-799); row(rr)=b*N+n.
 int pevit_launch_delta_add(bf16* qbuf, bf16* vbuf, const float* t, const float* q32,
-                           const float* bias, float ascale, int B, int N, int E, hipStream_t s);
+                           const float* bias, float ascale, int B, int N, int E, hipStream_t s, int f32 = 0);
 // u[row(rr)][0:32] = dDelta_q[rr] . Q_q ; [32:64] = dDelta_v[rr] . Q_v ; written f32 (u32) and
 // bf16 into dqkv[:, 3E:3E+64]
 int pevit_launch_lowrank_u(const bf16* dqkv, int ld, const bf16* qT, float* u32, bf16* u_bf16_cols,
@@ -111,10 +111,10 @@ int pevit_launch_chain_lora(const float* partial, size_t partial_layer, int chun
                             float* G, float* grads, size_t p_layer0, size_t p_layer_stride, int E, hipStream_t s);
 
 // ---- misc.hip --------------------------------------------------------------------
-int pevit_launch_cast_bf16(const float* src, bf16* dst, size_t n, float scale, hipStream_t s);
+int pevit_launch_cast_bf16(const float* src, bf16* dst, size_t n, float scale, hipStream_t s, int f32 = 0);
 // dst[c][r] = scale(r) * src[r][c]  (bf16 out), used once at load for the backward weights
 int pevit_launch_transpose_bf16(const float* src, int rows, int cols, bf16* dst, int ldd,
-                                int scaled_rows, float scale, hipStream_t s);
+                                int scaled_rows, float scale, hipStream_t s, int f32 = 0);
 int pevit_launch_permute_rows(const float* src, float* dst, int N, int B, int E, int to_internal,
                               hipStream_t s);
 int pevit_launch_scale_f32(float* p, size_t n, float scale, hipStream_t s);
@@ -130,9 +130,20 @@ int pevit_launch_cast_bf16_cols(const float* src, bf16* dst, size_t rows, int co
 int pevit_launch_dequant_rows_fp8(const unsigned char* codes, int ldc, const float* scale, int rows, int cols, float* out,
                                   hipStream_t s);
 
+// ---- verify.hip (f32-class verification mode: plain f32 kernels for the matrix-core contractions) -----------------
+int pevit_launch_gemm_f32(int epi, const GemmParams& p, hipStream_t s);      // A, B and the bf16-declared buffers hold f32
+int pevit_launch_attn_fwd_f32(const float* q, const float* k, const float* v, float* out, int ldo, float* lse, int B, int H, int N,
+                              hipStream_t s);
+int pevit_launch_attn_bwd_f32(const float* q, const float* k, const float* v, const float* out, int ldo, const float* dout,
+                              int lddo, const float* lse, float* dqkv, int ld, int B, int H, int N, hipStream_t s);
+int pevit_launch_lowrank_u_f32(const float* dqkv, int ld, const float* q32, float* u32, float* ucols, int B, int H, int N, int E,
+                               hipStream_t s);
+int pevit_launch_lowrank_grad_f32(const float* xn, int ldx, const float* u32, const float* dqkv, int ld, const float* t,
+                                  float* partial, float* dbias_partial, int chunks, int B, int H, int N, int E, hipStream_t s);
+
 // ---- stem_head.hip -----------------------------------------------------------------
-int pevit_launch_im2col(const float* img, bf16* out, int B, int R, int P, int Kp, hipStream_t s);
-int pevit_launch_conv_weight(const float* w, bf16* out, int E, int K, int Kp, hipStream_t s);
+int pevit_launch_im2col(const float* img, bf16* out, int B, int R, int P, int Kp, hipStream_t s, int f32 = 0);
+int pevit_launch_conv_weight(const float* w, bf16* out, int E, int K, int Kp, hipStream_t s, int f32 = 0);
 int pevit_launch_cls_row(const float* cls, const float* pos, float* x, int B, int N, int E, hipStream_t s);
 int pevit_launch_head(const float* feat, const int64_t* labels, const float* W, const float* bias, float* gW, float* gb,
                       float* running_mean, float* running_var, int training, float* ybn, float* rstd, float* logits,

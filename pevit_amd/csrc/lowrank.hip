@@ -37,6 +37,7 @@ __device__ __forceinline__ AdapterPanels layer_panels(AdapterPanels pan, LayerSt
     return pan;
 }
 
+template <typename ST>
 __global__ void prep_kadapt_kernel(const float* __restrict__ rule1_l, const float* __restrict__ rule1_r,
                                    const float* __restrict__ rule2_l, const float* __restrict__ rule2_r,
                                    const float* __restrict__ q_left, const float* __restrict__ q_right,
@@ -50,16 +51,17 @@ __global__ void prep_kadapt_kernel(const float* __restrict__ rule1_l, const floa
     const float l = q_left[j * F + kk], r = q_right[j * F + kk];
     const float pq = rule1_l[j * 32 + a] * l, pv = rule2_l[j * 32 + a] * l;
     const float qq = rule1_r[j * 32 + a] * r, qv = rule2_r[j * 32 + a] * r;
-    pan.w_aug_rows[(size_t)j * pan.ldw + e] = f2bf(pq);
-    pan.w_aug_rows[(size_t)(32 + j) * pan.ldw + e] = f2bf(pv);
-    pan.wT_aug_cols[(size_t)e * pan.ldwT + j] = f2bf(ascale * pq);
-    pan.wT_aug_cols[(size_t)e * pan.ldwT + 32 + j] = f2bf(ascale * pv);
+    st_store<ST>(pan.w_aug_rows, (size_t)j * pan.ldw + e, pq);
+    st_store<ST>(pan.w_aug_rows, (size_t)(32 + j) * pan.ldw + e, pv);
+    st_store<ST>(pan.wT_aug_cols, (size_t)e * pan.ldwT + j, ascale * pq);
+    st_store<ST>(pan.wT_aug_cols, (size_t)e * pan.ldwT + 32 + j, ascale * pv);
     pan.q32[(size_t)e * 64 + j] = qq;
     pan.q32[(size_t)e * 64 + 32 + j] = qv;
-    pan.qT[(size_t)j * E + e] = f2bf(qq);
-    pan.qT[(size_t)(32 + j) * E + e] = f2bf(qv);
+    st_store<ST>(pan.qT, (size_t)j * E + e, qq);
+    st_store<ST>(pan.qT, (size_t)(32 + j) * E + e, qv);
 }
 
+template <typename ST>
 __global__ void prep_lora_kernel(const float* __restrict__ a1q, const float* __restrict__ a2q,
                                  const float* __restrict__ a1v, const float* __restrict__ a2v, int r,
                                  AdapterPanels pan, int E, float ascale, LayerStrides st) {
@@ -70,14 +72,14 @@ __global__ void prep_lora_kernel(const float* __restrict__ a1q, const float* __r
     const int j = idx / E, e = idx - j * E;
     const float pq = j < r ? a1q[(size_t)j * E + e] : 0.f, pv = j < r ? a1v[(size_t)j * E + e] : 0.f;
     const float qq = j < r ? a2q[(size_t)e * r + j] : 0.f, qv = j < r ? a2v[(size_t)e * r + j] : 0.f;
-    pan.w_aug_rows[(size_t)j * pan.ldw + e] = f2bf(pq);
-    pan.w_aug_rows[(size_t)(32 + j) * pan.ldw + e] = f2bf(pv);
-    pan.wT_aug_cols[(size_t)e * pan.ldwT + j] = f2bf(ascale * pq);
-    pan.wT_aug_cols[(size_t)e * pan.ldwT + 32 + j] = f2bf(ascale * pv);
+    st_store<ST>(pan.w_aug_rows, (size_t)j * pan.ldw + e, pq);
+    st_store<ST>(pan.w_aug_rows, (size_t)(32 + j) * pan.ldw + e, pv);
+    st_store<ST>(pan.wT_aug_cols, (size_t)e * pan.ldwT + j, ascale * pq);
+    st_store<ST>(pan.wT_aug_cols, (size_t)e * pan.ldwT + 32 + j, ascale * pv);
     pan.q32[(size_t)e * 64 + j] = qq;
     pan.q32[(size_t)e * 64 + 32 + j] = qv;
-    pan.qT[(size_t)j * E + e] = f2bf(qq);
-    pan.qT[(size_t)(32 + j) * E + e] = f2bf(qv);
+    st_store<ST>(pan.qT, (size_t)j * E + e, qq);
+    st_store<ST>(pan.qT, (size_t)(32 + j) * E + e, qv);
 }
 
 // ---------------------------------------------------------------------------------
@@ -100,6 +102,7 @@ __device__ __forceinline__ void split_bf16(const float* src, bf16x8& hi, bf16x8&
 // one row -> one 16-byte read-modify-write); the split Q fragments of a step are loaded once and reused for all
 // DA_RG row groups (they were 2/3 of this kernel's L2 traffic when every 16-row group re-read them).
 constexpr int DA_RG = 4, DA_COLS = 64;
+template <typename ST>
 __global__ __launch_bounds__(256) void delta_add_kernel(bf16* qbuf, bf16* vbuf, const float* __restrict__ t,
                                                         const float* __restrict__ q32, const float* __restrict__ bias,
                                                         float ascale, int B, int N, int E) {
@@ -112,7 +115,8 @@ __global__ __launch_bounds__(256) void delta_add_kernel(bf16* qbuf, bf16* vbuf, 
     const int rr0 = grp * 16 * DA_RG;
     if (rr0 >= T) return;                          // whole wave exits together
     bf16x8 th[DA_RG], tl[DA_RG];
-    bf16* buf[DA_RG];
+    size_t boff[DA_RG];                            // element offset of this lane's row in the q / v buffer
+    bf16* const base = which ? vbuf : qbuf;
     bool rok[DA_RG];
 #pragma unroll
     for (int k = 0; k < DA_RG; ++k) {
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(256) void delta_add_kernel(bf16* qbuf, bf16* vbuf, 
         rok[k] = rr < T;
         rr = rok[k] ? rr : T - 1;
         split_bf16(t + (size_t)row_of_ref(rr, B, N) * 64 + which * 32 + 8 * g, th[k], tl[k]);
-        buf[k] = (which ? vbuf : qbuf) + (size_t)rr * E;
+        boff[k] = (size_t)rr * E;
     }
     const int m = c16;
 #pragma unroll
@@ -139,9 +143,18 @@ __global__ __launch_bounds__(256) void delta_add_kernel(bf16* qbuf, bf16* vbuf, 
 #pragma unroll
             for (int i = 0; i < 8; ++i) bb[i] = 0.f;
         }
-        bf16x8 cur[DA_RG];
+        float cur[DA_RG][8];
 #pragma unroll
-        for (int k = 0; k < DA_RG; ++k) cur[k] = load_bf16x8(buf[k] + eb + 8 * g);
+        for (int k = 0; k < DA_RG; ++k) {
+            if constexpr (sizeof(ST) == 2) {
+                const bf16x8 c8 = load_bf16x8(base + boff[k] + eb + 8 * g);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) cur[k][i] = bf2f(c8[i]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) cur[k][i] = reinterpret_cast<const float*>(base)[boff[k] + eb + 8 * g + i];
+            }
+        }
 #pragma unroll
         for (int k = 0; k < DA_RG; ++k) {
             f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
@@ -152,13 +165,16 @@ __global__ __launch_bounds__(256) void delta_add_kernel(bf16* qbuf, bf16* vbuf, 
             a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1h, tl[k], a1, 0, 0, 0);
             a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1h, th[k], a1, 0, 0, 0);
             // lane: column rr, rows 4g+r of each tile -> e = eb + 8g + r (tile 0), eb + 8g + 4 + r (tile 1)
-            bf16x8 o;
+            float o[8];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                o[r] = f2bf(bf2f(cur[k][r]) + ascale * a0[r] + bb[r]);
-                o[4 + r] = f2bf(bf2f(cur[k][4 + r]) + ascale * a1[r] + bb[4 + r]);
+                o[r] = cur[k][r] + ascale * a0[r] + bb[r];
+                o[4 + r] = cur[k][4 + r] + ascale * a1[r] + bb[4 + r];
             }
-            if (rok[k]) store_bf16x8(buf[k] + eb + 8 * g, o);
+            if (rok[k]) {
+                st_store4<ST>(base, boff[k] + eb + 8 * g, o[0], o[1], o[2], o[3]);
+                st_store4<ST>(base, boff[k] + eb + 8 * g + 4, o[4], o[5], o[6], o[7]);
+            }
         }
     }
 }
@@ -455,30 +471,36 @@ __global__ void chain_lora_kernel(const float* __restrict__ G, float ascale, int
 
 int pevit_launch_prep_kadapt(const float* rule1_l, const float* rule1_r, const float* rule2_l, const float* rule2_r,
                              const float* q_left, const float* q_right, AdapterPanels pan, int E, float ascale,
-                             int layers, LayerStrides st, hipStream_t s) {
+                             int layers, LayerStrides st, hipStream_t s, int f32) {
     if (E % 32) { pevit_set_error("prep_kadapt: width %d not divisible by phm_dim 32", E); return -1; }
-    hipLaunchKernelGGL(prep_kadapt_kernel, dim3(ceil_div(E * 32, 256), layers), dim3(256), 0, s, rule1_l, rule1_r,
-                       rule2_l, rule2_r, q_left, q_right, pan, E, ascale, st);
+    if (f32) hipLaunchKernelGGL(prep_kadapt_kernel<float>, dim3(ceil_div(E * 32, 256), layers), dim3(256), 0, s, rule1_l, rule1_r,
+                                rule2_l, rule2_r, q_left, q_right, pan, E, ascale, st);
+    else hipLaunchKernelGGL(prep_kadapt_kernel<bf16>, dim3(ceil_div(E * 32, 256), layers), dim3(256), 0, s, rule1_l, rule1_r,
+                            rule2_l, rule2_r, q_left, q_right, pan, E, ascale, st);
     LAUNCH_OK("prep_kadapt_kernel");
     return 0;
 }
 
 int pevit_launch_prep_lora(const float* a1q, const float* a2q, const float* a1v, const float* a2v, int r,
-                           AdapterPanels pan, int E, float ascale, int layers, LayerStrides st, hipStream_t s) {
+                           AdapterPanels pan, int E, float ascale, int layers, LayerStrides st, hipStream_t s, int f32) {
     if (r < 1 || r > 32) { pevit_set_error("prep_lora: rank %d outside [1,32]", r); return -1; }
-    hipLaunchKernelGGL(prep_lora_kernel, dim3(ceil_div(E * 32, 256), layers), dim3(256), 0, s, a1q, a2q, a1v, a2v, r,
-                       pan, E, ascale, st);
+    if (f32) hipLaunchKernelGGL(prep_lora_kernel<float>, dim3(ceil_div(E * 32, 256), layers), dim3(256), 0, s, a1q, a2q, a1v, a2v, r,
+                                pan, E, ascale, st);
+    else hipLaunchKernelGGL(prep_lora_kernel<bf16>, dim3(ceil_div(E * 32, 256), layers), dim3(256), 0, s, a1q, a2q, a1v, a2v, r,
+                            pan, E, ascale, st);
     LAUNCH_OK("prep_lora_kernel");
     return 0;
 }
 
 int pevit_launch_delta_add(bf16* qbuf, bf16* vbuf, const float* t, const float* q32, const float* bias, float ascale,
-                           int B, int N, int E, hipStream_t s) {
+                           int B, int N, int E, hipStream_t s, int f32) {
     if (E % DA_COLS) { pevit_set_error("delta_add: width %d must be a multiple of %d", E, DA_COLS); return -1; }
     const int T = B * N;
     const int waves = ceil_div(T, 16 * DA_RG) * (E / DA_COLS);
-    hipLaunchKernelGGL(delta_add_kernel, dim3(ceil_div(waves, 4), 2), dim3(256), 0, s, qbuf, vbuf, t, q32, bias, ascale,
-                       B, N, E);
+    if (f32) hipLaunchKernelGGL(delta_add_kernel<float>, dim3(ceil_div(waves, 4), 2), dim3(256), 0, s, qbuf, vbuf, t, q32, bias, ascale,
+                                B, N, E);
+    else hipLaunchKernelGGL(delta_add_kernel<bf16>, dim3(ceil_div(waves, 4), 2), dim3(256), 0, s, qbuf, vbuf, t, q32, bias, ascale,
+                            B, N, E);
     LAUNCH_OK("delta_add_kernel");
     return 0;
 }

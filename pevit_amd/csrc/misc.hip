@@ -6,20 +6,20 @@
 
 namespace {
 
+template <typename ST>
 __global__ void cast_bf16_kernel(const float* __restrict__ src, bf16* __restrict__ dst, size_t n, float scale) {
     size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
     for (; i + 3 < n; i += stride) {
         const float4 v = *reinterpret_cast<const float4*>(src + i);
-        bf16x4 o;
-        o[0] = f2bf(v.x * scale); o[1] = f2bf(v.y * scale); o[2] = f2bf(v.z * scale); o[3] = f2bf(v.w * scale);
-        *reinterpret_cast<bf16x4*>(dst + i) = o;
+        st_store4<ST>(dst, i, v.x * scale, v.y * scale, v.z * scale, v.w * scale);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0)
-        for (size_t j = n & ~(size_t)3; j < n; ++j) dst[j] = f2bf(src[j] * scale);
+        for (size_t j = n & ~(size_t)3; j < n; ++j) st_store<ST>(dst, j, src[j] * scale);
 }
 
 // dst[c*ldd + r] = src[r*cols + c] * (r < scaled_rows ? scale : 1)
+template <typename ST>
 __global__ void transpose_bf16_kernel(const float* __restrict__ src, int rows, int cols, bf16* __restrict__ dst,
                                       int ldd, int scaled_rows, float scale) {
     __shared__ float tile[32][33];
@@ -32,7 +32,7 @@ __global__ void transpose_bf16_kernel(const float* __restrict__ src, int rows, i
     __syncthreads();
     for (int i = ty; i < 32; i += 8) {
         const int c = c0 + i, r = r0 + tx;
-        if (c < cols && r < rows) dst[(size_t)c * ldd + r] = f2bf(tile[tx][i]);
+        if (c < cols && r < rows) st_store<ST>(dst, (size_t)c * ldd + r, tile[tx][i]);
     }
 }
 
@@ -68,19 +68,21 @@ __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, f
 
 }  // namespace
 
-int pevit_launch_cast_bf16(const float* src, bf16* dst, size_t n, float scale, hipStream_t s) {
+int pevit_launch_cast_bf16(const float* src, bf16* dst, size_t n, float scale, hipStream_t s, int f32) {
     if (n == 0) return 0;
     const int blocks = (int)((n / 4 + 255) / 256);
-    hipLaunchKernelGGL(cast_bf16_kernel, dim3(blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks)), dim3(256), 0, s, src,
-                       dst, n, scale);
+    const dim3 grid(blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks));
+    if (f32) hipLaunchKernelGGL(cast_bf16_kernel<float>, grid, dim3(256), 0, s, src, dst, n, scale);
+    else hipLaunchKernelGGL(cast_bf16_kernel<bf16>, grid, dim3(256), 0, s, src, dst, n, scale);
     LAUNCH_OK("cast_bf16_kernel");
     return 0;
 }
 
 int pevit_launch_transpose_bf16(const float* src, int rows, int cols, bf16* dst, int ldd, int scaled_rows, float scale,
-                                hipStream_t s) {
-    hipLaunchKernelGGL(transpose_bf16_kernel, dim3(ceil_div(cols, 32), ceil_div(rows, 32)), dim3(256), 0, s, src, rows,
-                       cols, dst, ldd, scaled_rows, scale);
+                                hipStream_t s, int f32) {
+    const dim3 grid(ceil_div(cols, 32), ceil_div(rows, 32));
+    if (f32) hipLaunchKernelGGL(transpose_bf16_kernel<float>, grid, dim3(256), 0, s, src, rows, cols, dst, ldd, scaled_rows, scale);
+    else hipLaunchKernelGGL(transpose_bf16_kernel<bf16>, grid, dim3(256), 0, s, src, rows, cols, dst, ldd, scaled_rows, scale);
     LAUNCH_OK("transpose_bf16_kernel");
     return 0;
 }

@@ -10,6 +10,7 @@ namespace {
 
 constexpr int MAXV = 4;   // float4 per lane -> E <= 1024
 
+template <typename ST>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, int rows, int E, size_t xstride,
                                                      bf16* __restrict__ yb, float* __restrict__ yf,
@@ -54,17 +55,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
             o.y = (v[i].y - mean) * rstd * g.y + b.y;
             o.z = (v[i].z - mean) * rstd * g.z + b.z;
             o.w = (v[i].w - mean) * rstd * g.w + b.w;
-            if (yb) {
-                bf16x4 ob;
-                ob[0] = f2bf(o.x); ob[1] = f2bf(o.y); ob[2] = f2bf(o.z); ob[3] = f2bf(o.w);
-                *reinterpret_cast<bf16x4*>(yb + (size_t)row * E + c) = ob;
-            }
+            if (yb) st_store4<ST>(yb, (size_t)row * E + c, o.x, o.y, o.z, o.w);
             if (yf) *reinterpret_cast<float4*>(yf + (size_t)row * E + c) = o;
         }
     }
 }
 
 // dx = dres + rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat))
+template <typename ST>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                      const float* __restrict__ gamma, const float* dres,
@@ -114,9 +112,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                     const float4 sc = *reinterpret_cast<const float4*>(bscale + c);
                     o.x *= sc.x; o.y *= sc.y; o.z *= sc.z; o.w *= sc.w;
                 }
-                bf16x4 ob;
-                ob[0] = f2bf(o.x); ob[1] = f2bf(o.y); ob[2] = f2bf(o.z); ob[3] = f2bf(o.w);
-                *reinterpret_cast<bf16x4*>(dx_bf16 + xb + c) = ob;
+                st_store4<ST>(dx_bf16, xb + c, o.x, o.y, o.z, o.w);
             }
         }
     }
@@ -125,24 +121,28 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 }  // namespace
 
 int pevit_launch_ln_fwd(const float* x, const float* gamma, const float* beta, int rows, int E, bf16* y_bf16,
-                        float* y_f32, float* mean, float* rstd, hipStream_t s, size_t xstride) {
+                        float* y_f32, float* mean, float* rstd, hipStream_t s, size_t xstride, int f32) {
     if (xstride == 0) xstride = (size_t)E;
     if (E % 4 != 0 || E > 256 * MAXV) { pevit_set_error("ln_fwd: unsupported width %d", E); return -1; }
     if (rows <= 0) return 0;
-    hipLaunchKernelGGL(ln_fwd_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, s, x, gamma, beta, rows, E, xstride,
-                       y_bf16, y_f32, mean, rstd);
+    if (f32) hipLaunchKernelGGL(ln_fwd_kernel<float>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, x, gamma, beta, rows, E, xstride,
+                                y_bf16, y_f32, mean, rstd);
+    else hipLaunchKernelGGL(ln_fwd_kernel<bf16>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, x, gamma, beta, rows, E, xstride,
+                            y_bf16, y_f32, mean, rstd);
     LAUNCH_OK("ln_fwd_kernel");
     return 0;
 }
 
 int pevit_launch_ln_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                         const float* dres, float* dx_out, bf16* dx_bf16, int rows, int E, hipStream_t s,
-                        size_t xstride, const float* bf16_colscale) {
+                        size_t xstride, const float* bf16_colscale, int f32) {
     if (xstride == 0) xstride = (size_t)E;
     if (E % 4 != 0 || E > 256 * MAXV) { pevit_set_error("ln_bwd: unsupported width %d", E); return -1; }
     if (rows <= 0) return 0;
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, s, dy, x, mean, rstd, gamma, dres,
-                       dx_out, dx_bf16, rows, E, xstride, bf16_colscale);
+    if (f32) hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, dy, x, mean, rstd, gamma, dres,
+                                dx_out, dx_bf16, rows, E, xstride, bf16_colscale);
+    else hipLaunchKernelGGL(ln_bwd_kernel<bf16>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, dy, x, mean, rstd, gamma, dres,
+                            dx_out, dx_bf16, rows, E, xstride, bf16_colscale);
     LAUNCH_OK("ln_bwd_kernel");
     return 0;
 }

@@ -13,6 +13,7 @@
 namespace {
 
 // patches[(b*G2 + gy*G + gx)][c*P*P + i*P + j] = img[b][c][gy*P+i][gx*P+j]   (bf16, zero padded to Kp)
+template <typename ST>
 __global__ void im2col_kernel(const float* __restrict__ img, bf16* __restrict__ out, int B, int R, int P, int Kp) {
     const int G = R / P, G2 = G * G, K = 3 * P * P;
     const size_t total = (size_t)B * G2 * (Kp / 2);
@@ -21,7 +22,6 @@ __global__ void im2col_kernel(const float* __restrict__ img, bf16* __restrict__ 
         const size_t row = idx / (Kp / 2);
         const int b = (int)(row / G2), gidx = (int)(row - (size_t)b * G2);
         const int gy = gidx / G, gx = gidx - gy * G;
-        bf16x2 o;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int k = 2 * k2 + u;
@@ -31,18 +31,18 @@ __global__ void im2col_kernel(const float* __restrict__ img, bf16* __restrict__ 
                 const int i = rem / P, j = rem - i * P;
                 v = img[(((size_t)b * 3 + c) * R + gy * P + i) * R + gx * P + j];
             }
-            o[u] = f2bf(v);
+            st_store<ST>(out, row * Kp + 2 * k2 + u, v);
         }
-        *reinterpret_cast<bf16x2*>(out + row * Kp + 2 * k2) = o;
     }
 }
 
 // conv1.weight (E, 3, P, P) f32 -> [E][Kp] bf16 zero padded
+template <typename ST>
 __global__ void conv_weight_kernel(const float* __restrict__ w, bf16* __restrict__ out, int E, int K, int Kp) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)E * Kp) return;
     const int e = (int)(idx / Kp), k = (int)(idx - (size_t)e * Kp);
-    out[idx] = f2bf(k < K ? w[(size_t)e * K + k] : 0.f);
+    st_store<ST>(out, idx, k < K ? w[(size_t)e * K + k] : 0.f);
 }
 
 // x[b*N + 0][:] = class_embedding + positional_embedding[0]
@@ -230,15 +230,18 @@ __global__ void loss_mean_kernel(const float* __restrict__ rowloss, const int64_
 
 }  // namespace
 
-int pevit_launch_im2col(const float* img, bf16* out, int B, int R, int P, int Kp, hipStream_t s) {
+int pevit_launch_im2col(const float* img, bf16* out, int B, int R, int P, int Kp, hipStream_t s, int f32) {
     const size_t total = (size_t)B * (R / P) * (R / P) * (Kp / 2);
     const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
-    hipLaunchKernelGGL(im2col_kernel, dim3(blocks), dim3(256), 0, s, img, out, B, R, P, Kp);
+    if (f32) hipLaunchKernelGGL(im2col_kernel<float>, dim3(blocks), dim3(256), 0, s, img, out, B, R, P, Kp);
+    else hipLaunchKernelGGL(im2col_kernel<bf16>, dim3(blocks), dim3(256), 0, s, img, out, B, R, P, Kp);
     LAUNCH_OK("im2col_kernel");
     return 0;
 }
-int pevit_launch_conv_weight(const float* w, bf16* out, int E, int K, int Kp, hipStream_t s) {
-    hipLaunchKernelGGL(conv_weight_kernel, dim3((unsigned)(((size_t)E * Kp + 255) / 256)), dim3(256), 0, s, w, out, E, K, Kp);
+int pevit_launch_conv_weight(const float* w, bf16* out, int E, int K, int Kp, hipStream_t s, int f32) {
+    const dim3 grid((unsigned)(((size_t)E * Kp + 255) / 256));
+    if (f32) hipLaunchKernelGGL(conv_weight_kernel<float>, grid, dim3(256), 0, s, w, out, E, K, Kp);
+    else hipLaunchKernelGGL(conv_weight_kernel<bf16>, grid, dim3(256), 0, s, w, out, E, K, Kp);
     LAUNCH_OK("conv_weight_kernel");
     return 0;
 }
