@@ -60,7 +60,7 @@ enum pevit_weight_format {
                              f32, the matrix-core contractions run as plain f32 kernels (csrc/verify.hip) inside the same
                              launch sequences, layouts and index arithmetic.  Used by the parity tests to assert the stated
                              gates against the reference's fixtures without bf16 operand rounding; ~20x slower; workspace
-                             and arena are twice the size.  KAdaptation, LoRA and the frozen tower.                     */
+                             and arena are twice the size.  All methods.                                                */
 };
 
 typedef struct pevit_dims {

@@ -26,6 +26,7 @@ __device__ __forceinline__ int tg_col(int row_e, int y) { return y ^ (((row_e >>
 // ---------------------------------------------------------------------------------------------
 // panels: wd [64][E] (B operand of the down GEMM), wdT [E][64] (d z GEMM), wu [E][64] (up GEMM),
 // wuT [64][E] (d act GEMM).  blockIdx.y = layer.
+template <typename ST>
 __global__ void prep_adapter_kernel(const float* __restrict__ w_down, const float* __restrict__ w_up, BottleneckPanels pan,
                                     int E, LayerStrides st) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -40,15 +41,16 @@ __global__ void prep_adapter_kernel(const float* __restrict__ w_down, const floa
     const int j = idx / E, e = idx - j * E;
     const float d = w_down[(size_t)j * E + e];        // (64, E)
     const float u = w_up[(size_t)e * 64 + j];         // (E, 64)
-    wd[(size_t)j * E + e] = f2bf(d);
-    wdT[(size_t)e * 64 + j] = f2bf(d);
-    wu[(size_t)e * 64 + j] = f2bf(u);
-    wuT[(size_t)j * E + e] = f2bf(u);
+    st_store<ST>(wd, (size_t)j * E + e, d);
+    st_store<ST>(wdT, (size_t)e * 64 + j, d);
+    st_store<ST>(wu, (size_t)e * 64 + j, u);
+    st_store<ST>(wuT, (size_t)j * E + e, u);
 }
 
 // Compacter: H_down[a*Fi+k][c*16+p] = sum_i rule[i][a][c] Wl[i][k] Wr[i][p]   (Fi = E/4)
 //            H_up  [a*16+k][c*Fi+p] = sum_i rule[i][a][c] Ul[i][k] Ur[i][p]
 // effective dense weights: w_down[j][e] = H_down[e][j], w_up[e][j] = H_up[j][e].
+template <typename ST>
 __global__ void prep_compacter_kernel(const float* __restrict__ rule, const float* __restrict__ dWl,
                                       const float* __restrict__ dWr, const float* __restrict__ uWl,
                                       const float* __restrict__ uWr, BottleneckPanels pan, int E, LayerStrides st) {
@@ -68,16 +70,16 @@ __global__ void prep_compacter_kernel(const float* __restrict__ rule, const floa
         float h = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) h += rule[i * 16 + a * 4 + c] * dWl[i * Fi + k] * dWr[i * 16 + p];
-        wd[(size_t)j * E + e] = f2bf(h);
-        wdT[(size_t)e * 64 + j] = f2bf(h);
+        st_store<ST>(wd, (size_t)j * E + e, h);
+        st_store<ST>(wdT, (size_t)e * 64 + j, h);
     }
     {   // up: j = a*16 + k, e = c*Fi + p
         const int a = j >> 4, k = j & 15, c = e / Fi, p = e - c * Fi;
         float h = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) h += rule[i * 16 + a * 4 + c] * uWl[i * 16 + k] * uWr[i * Fi + p];
-        wu[(size_t)e * 64 + j] = f2bf(h);
-        wuT[(size_t)j * E + e] = f2bf(h);
+        st_store<ST>(wu, (size_t)e * 64 + j, h);
+        st_store<ST>(wuT, (size_t)j * E + e, h);
     }
 }
 
@@ -163,6 +165,7 @@ __global__ __launch_bounds__(256) void tn_gemm64_kernel(const bf16* __restrict__
 constexpr int LNA_ROWS = 32;
 constexpr int LNA_WAVES = 8;
 constexpr int LNA_MAXV = 4;
+template <typename ST>
 __global__ __launch_bounds__(64 * LNA_WAVES) void ln_bwd_affine_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                             const float* __restrict__ gamma, const float* dres, float* dx,
@@ -211,11 +214,7 @@ __global__ __launch_bounds__(64 * LNA_WAVES) void ln_bwd_affine_kernel(const flo
                     ar[i].x += r.x; ar[i].y += r.y; ar[i].z += r.z; ar[i].w += r.w;
                 }
                 *reinterpret_cast<float4*>(dx + base + c) = o;
-                if (dx_bf16) {
-                    bf16x4 ob;
-                    ob[0] = f2bf(o.x); ob[1] = f2bf(o.y); ob[2] = f2bf(o.z); ob[3] = f2bf(o.w);
-                    *reinterpret_cast<bf16x4*>(dx_bf16 + base + c) = ob;
-                }
+                if (dx_bf16) st_store4<ST>(dx_bf16, base + c, o.x, o.y, o.z, o.w);
             }
         }
     }
@@ -374,16 +373,19 @@ int pevit_tn_chunks(int T) { return ceil_div(T, TG_ROWS); }
 int pevit_lna_blocks(int rows) { return ceil_div(rows, LNA_ROWS); }
 
 int pevit_launch_prep_adapter(const float* w_down, const float* w_up, BottleneckPanels pan, int E, int layers, LayerStrides st,
-                              hipStream_t s) {
-    hipLaunchKernelGGL(prep_adapter_kernel, dim3(ceil_div(64 * E, 256), layers), dim3(256), 0, s, w_down, w_up, pan, E, st);
+                              hipStream_t s, int f32) {
+    if (f32) hipLaunchKernelGGL(prep_adapter_kernel<float>, dim3(ceil_div(64 * E, 256), layers), dim3(256), 0, s, w_down, w_up, pan, E, st);
+    else hipLaunchKernelGGL(prep_adapter_kernel<bf16>, dim3(ceil_div(64 * E, 256), layers), dim3(256), 0, s, w_down, w_up, pan, E, st);
     LAUNCH_OK("prep_adapter_kernel");
     return 0;
 }
 int pevit_launch_prep_compacter(const float* rule, const float* dWl, const float* dWr, const float* uWl, const float* uWr,
-                                BottleneckPanels pan, int E, int layers, LayerStrides st, hipStream_t s) {
+                                BottleneckPanels pan, int E, int layers, LayerStrides st, hipStream_t s, int f32) {
     if (E % 4) { pevit_set_error("prep_compacter: width %d not divisible by 4", E); return -1; }
-    hipLaunchKernelGGL(prep_compacter_kernel, dim3(ceil_div(64 * E, 256), layers), dim3(256), 0, s, rule, dWl, dWr, uWl, uWr,
-                       pan, E, st);
+    if (f32) hipLaunchKernelGGL(prep_compacter_kernel<float>, dim3(ceil_div(64 * E, 256), layers), dim3(256), 0, s, rule, dWl, dWr, uWl, uWr,
+                                pan, E, st);
+    else hipLaunchKernelGGL(prep_compacter_kernel<bf16>, dim3(ceil_div(64 * E, 256), layers), dim3(256), 0, s, rule, dWl, dWr, uWl, uWr,
+                            pan, E, st);
     LAUNCH_OK("prep_compacter_kernel");
     return 0;
 }
@@ -396,17 +398,20 @@ int pevit_launch_tn_gemm64(const bf16* X, int ldx, const bf16* Y, int ldy, float
     return 0;
 }
 int pevit_launch_ln_bwd_affine(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
-                               const float* dres, float* dx, bf16* dx_bf16, float* partial, int rows, int E, hipStream_t s) {
+                               const float* dres, float* dx, bf16* dx_bf16, float* partial, int rows, int E, hipStream_t s, int f32) {
     if (E % 4 || E > 256 * LNA_MAXV) { pevit_set_error("ln_bwd_affine: unsupported width %d", E); return -1; }
     const size_t lds = (size_t)(LNA_WAVES - 1) * 3 * E * sizeof(float);      // 64.5 KiB at E = 768
     static bool attr_set = false;
     if (!attr_set) {
-        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(ln_bwd_affine_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (LNA_WAVES - 1) * 3 * 256 * LNA_MAXV * (int)sizeof(float)));
+        const int maxlds = (LNA_WAVES - 1) * 3 * 256 * LNA_MAXV * (int)sizeof(float);
+        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(ln_bwd_affine_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds));
+        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(ln_bwd_affine_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds));
         attr_set = true;
     }
-    hipLaunchKernelGGL(ln_bwd_affine_kernel, dim3(ceil_div(rows, LNA_ROWS)), dim3(64 * LNA_WAVES), lds, s, dy, x, mean, rstd, gamma,
-                       dres, dx, dx_bf16, partial, rows, E);
+    if (f32) hipLaunchKernelGGL(ln_bwd_affine_kernel<float>, dim3(ceil_div(rows, LNA_ROWS)), dim3(64 * LNA_WAVES), lds, s, dy, x, mean, rstd,
+                                gamma, dres, dx, dx_bf16, partial, rows, E);
+    else hipLaunchKernelGGL(ln_bwd_affine_kernel<bf16>, dim3(ceil_div(rows, LNA_ROWS)), dim3(64 * LNA_WAVES), lds, s, dy, x, mean, rstd,
+                            gamma, dres, dx, dx_bf16, partial, rows, E);
     LAUNCH_OK("ln_bwd_affine_kernel");
     return 0;
 }

@@ -213,9 +213,6 @@ extern "C" int pevit_ctx_create(const pevit_dims* dims, pevit_ctx** out) {
     if (d.weight_format == PEVIT_W_FP8_E4M3 && (d.method == PEVIT_ADAPTER || d.method == PEVIT_COMPACTER)) {
         pevit_set_error("ctx_create: fp8 weights are built for the attention-site methods (KAdaptation, LoRA) and the frozen tower"); return -1;
     }
-    if (d.weight_format == PEVIT_W_F32_VERIFY && (d.method == PEVIT_ADAPTER || d.method == PEVIT_COMPACTER)) {
-        pevit_set_error("ctx_create: the f32 verification mode covers the attention-site methods (KAdaptation, LoRA) and the frozen tower"); return -1;
-    }
     if (d.out_dim <= 0 || d.out_dim % 8 != 0 || d.num_classes <= 0) {
         pevit_set_error("ctx_create: bad out_dim/num_classes %d/%d", d.out_dim, d.num_classes); return -1;
     }
@@ -466,10 +463,10 @@ int prep_adapters(pevit_ctx* c, hipStream_t s) {
         BottleneckPanels bp{at<bf16>(c->arena, b0.wd), at<bf16>(c->arena, b0.wdT), at<bf16>(c->arena, b0.wu),
                             at<bf16>(c->arena, b0.wuT)};
         if (c->d.method == PEVIT_ADAPTER)
-            CHECK(pevit_launch_prep_adapter(lp + c->o_dw, lp + c->o_uw, bp, c->E, c->L, st, s));
+            CHECK(pevit_launch_prep_adapter(lp + c->o_dw, lp + c->o_uw, bp, c->E, c->L, st, s, c->f32));
         else
             CHECK(pevit_launch_prep_compacter(at<float>(c->arena, c->a_phm), lp + c->o_dWl, lp + c->o_dWr, lp + c->o_uWl,
-                                              lp + c->o_uWr, bp, c->E, c->L, st, s));
+                                              lp + c->o_uWr, bp, c->E, c->L, st, s, c->f32));
     }
     return 0;
 }
@@ -600,7 +597,7 @@ int blocks_forward(pevit_ctx* c, hipStream_t s, int B, bool cls_only) {
                 CHECK(gemm(c, EPI_BIAS_RESID_KEEP, p, s));
             }
             CHECK(pevit_launch_ln_fwd(at<float>(W, v.hf32), lp + c->o_nw, lp + c->o_nb, T, E, at<bf16>(W, v.z), nullptr,
-                                      at<float>(W, v.mean_a), at<float>(W, v.rstd_a), s));
+                                      at<float>(W, v.mean_a), at<float>(W, v.rstd_a), s, 0, c->f32));
             {
                 GemmParams p = gp(at<bf16>(W, v.z), E, at<bf16>(A, b.wd), E, 64, T, 64, E);
                 p.bias = lp + c->o_db;
@@ -658,8 +655,12 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0, bool cls_
             const float* lp = c->params + c->p_layer0 + c->p_layer_stride * l;
             bf16* dpre = at<bf16>(W, c->w_dpre);
             // d W_up[e][j] = sum_r dx_out[r][e] act[r][j] ; d b_up = colsum(dx_out)
-            CHECK(pevit_launch_tn_gemm64(dyb, E, at<bf16>(W, v.act), 64, at<float>(W, c->w_tnU + (size_t)l * c->tn_layer),
-                                         nullptr, nullptr, T, E, s));
+            if (c->f32)
+                CHECK(pevit_launch_tn_gemm64_f32((const float*)dyb, E, at<float>(W, v.act), 64, at<float>(W, c->w_tnU + (size_t)l * c->tn_layer),
+                                                 nullptr, nullptr, T, E, s));
+            else
+                CHECK(pevit_launch_tn_gemm64(dyb, E, at<bf16>(W, v.act), 64, at<float>(W, c->w_tnU + (size_t)l * c->tn_layer),
+                                             nullptr, nullptr, T, E, s));
             {   // d act = dx_out W_up ; d pre = d act * act'(pre)
                 GemmParams p = gp(dyb, E, at<bf16>(A, b.wuT), E, 64, T, 64, E);
                 p.outb = dpre; p.ldob = 64; p.ldaux = 64;
@@ -667,8 +668,12 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0, bool cls_
                 else { p.aux = at<bf16>(W, v.apre); CHECK(gemm(c, EPI_DGELUNEW_BF16, p, s)); }
             }
             // d W_down[j][e] = sum_r d pre[r][j] z[r][e] ; d b_down = colsum(d pre)
-            CHECK(pevit_launch_tn_gemm64(at<bf16>(W, v.z), E, dpre, 64, at<float>(W, c->w_tnD + (size_t)l * c->tn_layer), nullptr,
-                                         at<float>(W, c->w_csy + (size_t)l * c->csy_layer), T, E, s));
+            if (c->f32)
+                CHECK(pevit_launch_tn_gemm64_f32(at<float>(W, v.z), E, (const float*)dpre, 64, at<float>(W, c->w_tnD + (size_t)l * c->tn_layer),
+                                                 nullptr, at<float>(W, c->w_csy + (size_t)l * c->csy_layer), T, E, s));
+            else
+                CHECK(pevit_launch_tn_gemm64(at<bf16>(W, v.z), E, dpre, 64, at<float>(W, c->w_tnD + (size_t)l * c->tn_layer), nullptr,
+                                             at<float>(W, c->w_csy + (size_t)l * c->csy_layer), T, E, s));
             {   // d z = d pre W_down
                 GemmParams p = gp(dpre, 64, at<bf16>(A, b.wdT), 64, E, T, E, 64);
                 p.outf = dxn; p.ldo = E;
@@ -677,7 +682,7 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0, bool cls_
             // d h = dx_out + LN_a-backward(d z) ; partial sums for d gamma_a, d beta_a
             CHECK(pevit_launch_ln_bwd_affine(dxn, at<float>(W, v.hf32), at<float>(W, v.mean_a), at<float>(W, v.rstd_a), lp + c->o_nw,
                                              dxa, at<float>(W, c->w_dht), at<bf16>(W, c->w_dhb),
-                                             at<float>(W, c->w_lnp + (size_t)l * c->lnp_layer), T, E, s));
+                                             at<float>(W, c->w_lnp + (size_t)l * c->lnp_layer), T, E, s, c->f32));
             mlp_dy = at<bf16>(W, c->w_dhb);
             if (l == 0 && !need_dx0) break;     // nothing trainable below the first block's adapter
         }

@@ -138,6 +138,9 @@ int pevit_launch_attn_bwd_f32(const float* q, const float* k, const float* v, co
                               int lddo, const float* lse, float* dqkv, int ld, int B, int H, int N, hipStream_t s);
 int pevit_launch_lowrank_u_f32(const float* dqkv, int ld, const float* q32, float* u32, float* ucols, int B, int H, int N, int E,
                                hipStream_t s);
+// G[e][j] = sum_r X[r][e] Y[r][j], partial / column-sum layout of tn_gemm64 (adapter.hip)
+int pevit_launch_tn_gemm64_f32(const float* X, int ldx, const float* Y, int ldy, float* partial, float* csx, float* csy, int T, int E,
+                               hipStream_t s);
 int pevit_launch_lowrank_grad_f32(const float* xn, int ldx, const float* u32, const float* dqkv, int ld, const float* t,
                                   float* partial, float* dbias_partial, int chunks, int B, int H, int N, int E, hipStream_t s);
 
@@ -154,14 +157,14 @@ struct BottleneckPanels { bf16* wd; bf16* wdT; bf16* wu; bf16* wuT; };   // [64]
 int pevit_tn_chunks(int T);
 int pevit_lna_blocks(int rows);
 int pevit_launch_prep_adapter(const float* w_down, const float* w_up, BottleneckPanels pan, int E, int layers, LayerStrides st,
-                              hipStream_t s);
+                              hipStream_t s, int f32 = 0);
 int pevit_launch_prep_compacter(const float* rule, const float* dWl, const float* dWr, const float* uWl, const float* uWr,
-                                BottleneckPanels pan, int E, int layers, LayerStrides st, hipStream_t s);
+                                BottleneckPanels pan, int E, int layers, LayerStrides st, hipStream_t s, int f32 = 0);
 // G[e][j] = sum_r X[r][e] Y[r][j] (per-chunk partials [chunk][E][64]); optional column sums of X / Y
 int pevit_launch_tn_gemm64(const bf16* X, int ldx, const bf16* Y, int ldy, float* partial, float* csx, float* csy, int T, int E,
                            hipStream_t s);
 int pevit_launch_ln_bwd_affine(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
-                               const float* dres, float* dx, bf16* dx_bf16, float* partial, int rows, int E, hipStream_t s);
+                               const float* dres, float* dx, bf16* dx_bf16, float* partial, int rows, int E, hipStream_t s, int f32 = 0);
 int pevit_launch_colsum_reduce(const float* partial, int chunks, int n, float* out, int layers, size_t partial_layer,
                                size_t out_layer, hipStream_t s);
 int pevit_launch_colsum_reduce3(const float* partial, int chunks, int n, float* o0, float* o1, float* o2, int layers,

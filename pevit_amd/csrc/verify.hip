@@ -237,7 +237,35 @@ __global__ __launch_bounds__(256) void lowrank_grad_f32_kernel(const float* __re
     }
 }
 
+// post-MLP adapters: partial[chunk][E][64], csx[chunk][E], csy[chunk][64] exactly as tn_gemm64_kernel writes them
+constexpr int VT_ROWS = 256;       // == TG_ROWS of adapter.hip (pevit_tn_chunks)
+__global__ __launch_bounds__(256) void tn_gemm64_f32_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ Y, int ldy,
+                                                            float* __restrict__ partial, float* __restrict__ csx,
+                                                            float* __restrict__ csy, int T, int E) {
+    const int eslabs = E / 64;
+    const int chunk = blockIdx.x / eslabs, e0 = (blockIdx.x - chunk * eslabs) * 64;
+    const int r0 = chunk * VT_ROWS, r1 = min(T, r0 + VT_ROWS), tid = threadIdx.x;
+    for (int o = tid; o < 64 * 64; o += 256) {
+        const int e = e0 + (o >> 6), j = o & 63;
+        float s = 0.f;
+        for (int r = r0; r < r1; ++r) s = fmaf(X[(size_t)r * ldx + e], Y[(size_t)r * ldy + j], s);
+        partial[(size_t)chunk * E * 64 + (size_t)e * 64 + j] = s;
+    }
+    if (tid < 64) {
+        if (csx) { float s = 0.f; for (int r = r0; r < r1; ++r) s += X[(size_t)r * ldx + e0 + tid]; csx[(size_t)chunk * E + e0 + tid] = s; }
+        if (csy && e0 == 0) { float s = 0.f; for (int r = r0; r < r1; ++r) s += Y[(size_t)r * ldy + tid]; csy[(size_t)chunk * 64 + tid] = s; }
+    }
+}
+
 }  // namespace
+
+int pevit_launch_tn_gemm64_f32(const float* X, int ldx, const float* Y, int ldy, float* partial, float* csx, float* csy, int T, int E,
+                               hipStream_t s) {
+    if (E % 64) { pevit_set_error("tn_gemm64 (f32 verification): bad width %d", E); return -1; }
+    hipLaunchKernelGGL(tn_gemm64_f32_kernel, dim3(ceil_div(T, VT_ROWS) * (E / 64)), dim3(256), 0, s, X, ldx, Y, ldy, partial, csx, csy, T, E);
+    LAUNCH_OK("tn_gemm64_f32_kernel");
+    return 0;
+}
 
 int pevit_launch_gemm_f32(int epi, const GemmParams& p, hipStream_t s) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.K % 32 || p.N % 8) {

@@ -43,7 +43,7 @@ def _engine(meta, sd, t=None, batch=None, head=None):
     return eng
 
 
-@pytest.mark.parametrize("case", ["tiny_kadaptation", "tiny_lora", "tiny_lora_r8"])
+@pytest.mark.parametrize("case", ["tiny_kadaptation", "tiny_lora", "tiny_lora_r8", "tiny_adapter", "tiny_compacter"])
 def test_stated_gates_on_tiny_fixtures_full_tensors(case):
     meta, t = load_golden(case)
     eng = _engine(meta, golden_param_dict(meta, t), t)
@@ -84,6 +84,9 @@ def _full_case(meta, t):
     ordered = [(n, torch.zeros(spec[n])) for n in meta["trainable_names"]]
     randomize_adapters(ordered, seed=3)
     sd.update(dict(ordered))
+    for k, v in t.items():                       # tensors the reference adds but never trains (Compacter's phm_rule)
+        if k.startswith("adapter/"):
+            sd[k[len("adapter/"):]] = v.float()
     g = torch.Generator().manual_seed(5)
     bound = 1.0 / math.sqrt(arch.embed_dim)
     hw = (torch.rand((meta["classes"], arch.embed_dim), generator=g) * 2 - 1) * bound
@@ -91,7 +94,8 @@ def _full_case(meta, t):
     return arch, sd, hw, hb
 
 
-@pytest.mark.parametrize("case", ["full_b32_kadaptation", "full_b32_lora", "full_b32_lora_r8", "full_l14_kadaptation"])
+@pytest.mark.parametrize("case", ["full_b32_kadaptation", "full_b32_lora", "full_b32_lora_r8", "full_b32_adapter",
+                                  "full_b32_compacter", "full_b16_compacter", "full_l14_kadaptation"])
 def test_stated_gates_on_full_size_fixtures(case):
     """ViT-B/32 (12 layers) and ViT-L/14 (24 layers, N = 257) at full width, bs = 8, as recorded from the reference: logits,
     loss and the norm of every gradient tensor."""
@@ -114,6 +118,7 @@ def test_stated_gates_on_full_size_fixtures(case):
 
 
 @pytest.mark.parametrize("arch_name,method,lora_r,B", [("ViT-B/32", "kadaptation", 4, 8), ("ViT-B/32", "lora", 8, 8),
+                                                        ("ViT-B/32", "adapter", 4, 8), ("ViT-B/32", "compacter", 4, 8),
                                                         ("ViT-B/32-2L", "kadaptation", 4, 128)])
 def test_stated_gates_full_tensors_vs_live_oracle(arch_name, method, lora_r, B):
     """Every gradient TENSOR (not its norm) of the headline architecture, and the whole step at the headline batch of 128
