@@ -100,6 +100,7 @@ struct pevit_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // A/B-measurement knobs (pevit_tune): per context, so that contexts stay independent of each other
     GemmTune tune;
+    int dx_stored = 1;        // dX GEMMs hand the LN-input gradient to LayerNorm backward in the activation storage type (bf16)
     int side_stream = 0;      // adapter-gradient contractions on a second stream: +0.5 % step throughput, but it slows the GEMMs
                               // it overlaps by 4 %, which blurs the per-kernel roofline measurement: off by default
 };
@@ -698,14 +699,16 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0, bool cls_
             CHECK(gemm(c, EPI_DGELU_BF16, p, s));
         }
         {
+            // the LN-input gradient leaves the GEMM in the activation storage type (bf16): LayerNorm backward is
+            // HBM-bound, and this halves the bytes on both sides of the hand-over
             GemmParams p = gpw(c, at<bf16>(W, c->w_dh), 4 * E, b.wfcT, 4 * E, E, R, E, 4 * E, 0);
-            p.outf = dxn; p.ldo = E;
-            CHECK(gemm(c, EPI_F32, p, s));
+            if (c->dx_stored) { p.outb = reinterpret_cast<bf16*>(dxn); p.ldob = E; CHECK(gemm(c, EPI_BF16, p, s)); }
+            else { p.outf = dxn; p.ldo = E; CHECK(gemm(c, EPI_F32, p, s)); }
         }
         // fp8: the bf16 copy feeds the out-projection backward, whose contraction runs over out_proj's output channels
         CHECK(pevit_launch_ln_bwd(dxn, at<float>(W, v.x_mid), at<float>(W, v.mean2), at<float>(W, v.rstd2),
                                   at<float>(A, b.ln2w), dxa, dxb, dyb, R, E, s, (size_t)rs,
-                                  c->fp8 ? at<float>(A, b.so) : nullptr, c->f32));
+                                  c->fp8 ? at<float>(A, b.so) : nullptr, c->f32, c->dx_stored));
         // ---- attention branch
         {
             GemmParams p = gpw(c, dyb, rs, b.woT, E, E, R, E, E, 0);
@@ -747,12 +750,12 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0, bool cls_
         }
         if (l > 0 || need_dx0) {
             GemmParams p = gp(dqkv, c->NQ, at<bf16>(A, b.wqkvT), c->NQ, E, T, E, site ? c->NQ : 3 * E);
-            p.outf = dxn; p.ldo = E;
-            CHECK(gemm(c, EPI_F32, p, s));
+            if (c->dx_stored) { p.outb = reinterpret_cast<bf16*>(dxn); p.ldob = E; CHECK(gemm(c, EPI_BF16, p, s)); }
+            else { p.outf = dxn; p.ldo = E; CHECK(gemm(c, EPI_F32, p, s)); }
             // fp8: this bf16 copy is the upstream gradient of layer l-1's c_proj backward
             CHECK(pevit_launch_ln_bwd(dxn, at<float>(W, v.x_in), at<float>(W, v.mean1), at<float>(W, v.rstd1),
                                       at<float>(A, b.ln1w), dxb, dxa, dyb, T, E, s, 0,
-                                      (c->fp8 && l > 0) ? at<float>(A, c->blk[l - 1].spr) : nullptr, c->f32));
+                                      (c->fp8 && l > 0) ? at<float>(A, c->blk[l - 1].spr) : nullptr, c->f32, c->dx_stored));
         }
     }
     if (side_pending) HIP_OK(hipStreamWaitEvent(s, c->ev_join, 0));
@@ -1147,6 +1150,7 @@ extern "C" int pevit_tune(pevit_ctx* c, const char* key, int value) {
     if (key && !strcmp(key, "gemm_cfg_shortk")) { t.cfg_shortk = value; return 0; }
     if (key && !strcmp(key, "gemm_big_bias")) { t.big_bias = value; return 0; }
     if (key && c && !strcmp(key, "side_stream")) { c->side_stream = value; return 0; }
+    if (key && c && !strcmp(key, "dx_stored")) { c->dx_stored = value; return 0; }
     pevit_set_error("tune: unknown key %s", key ? key : "(null)");
     return -1;
 }

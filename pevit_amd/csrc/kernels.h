@@ -57,10 +57,11 @@ int pevit_launch_gemm(int epi, const GemmParams& p, const GemmTune& t, hipStream
 int pevit_launch_ln_fwd(const float* x, const float* gamma, const float* beta, int rows, int E,
                         bf16* y_bf16, float* y_f32, float* mean, float* rstd, hipStream_t s,
                         size_t xstride = 0, int f32 = 0);
-// dx_out = dres + LN-backward(dy)   (gamma/beta frozen: no parameter grads)
-int pevit_launch_ln_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
+// dx_out = dres + LN-backward(dy)   (gamma/beta frozen: no parameter grads).  dy is f32, or (dy_stored) in the activation
+// storage type -- bf16 in production -- when it is the output of a dX GEMM
+int pevit_launch_ln_bwd(const void* dy, const float* x, const float* mean, const float* rstd,
                         const float* gamma, const float* dres, float* dx_out, bf16* dx_bf16, int rows, int E,
-                        hipStream_t s, size_t xstride = 0, const float* bf16_colscale = nullptr, int f32 = 0);
+                        hipStream_t s, size_t xstride = 0, const float* bf16_colscale = nullptr, int f32 = 0, int dy_stored = 0);
 
 // ---- attention.hip ---------------------------------------------------------------
 // q,k,v: (B*H, N, 64) bf16 (q pre-scaled by 1/8, deltas already added); out: rows (b*N+n), cols h*64+d

@@ -62,8 +62,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 }
 
 // dx = dres + rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat))
-template <typename ST>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+// DYT: storage of the upstream gradient dy -- f32, or the activation storage type ST when it comes straight out of a
+// dX GEMM (bf16 in production: one rounding, half the bytes on both sides of this HBM-bound kernel)
+template <typename ST, typename DYT>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy_, const float* __restrict__ x,
                                                      const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                      const float* __restrict__ gamma, const float* dres,
                                                      float* dx, bf16* __restrict__ dx_bf16, int rows, int E, size_t xstride,
@@ -80,7 +82,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     for (int i = 0; i < MAXV; ++i) {
         const int c = lane * 4 + i * 256;
         if (c < E) {
-            const float4 d = *reinterpret_cast<const float4*>(dy + base + c);
+            float4 d;
+            if constexpr (sizeof(DYT) == 2) {
+                const bf16x4 d4 = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(dy_) + base + c);
+                d = make_float4(bf2f(d4[0]), bf2f(d4[1]), bf2f(d4[2]), bf2f(d4[3]));
+            } else {
+                d = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(dy_) + base + c);
+            }
             const float4 xv = *reinterpret_cast<const float4*>(x + xb + c);
             const float4 g = *reinterpret_cast<const float4*>(gamma + c);
             gd[i] = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
@@ -133,15 +141,18 @@ int pevit_launch_ln_fwd(const float* x, const float* gamma, const float* beta, i
     return 0;
 }
 
-int pevit_launch_ln_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+int pevit_launch_ln_bwd(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                         const float* dres, float* dx_out, bf16* dx_bf16, int rows, int E, hipStream_t s,
-                        size_t xstride, const float* bf16_colscale, int f32) {
+                        size_t xstride, const float* bf16_colscale, int f32, int dy_stored) {
     if (xstride == 0) xstride = (size_t)E;
     if (E % 4 != 0 || E > 256 * MAXV) { pevit_set_error("ln_bwd: unsupported width %d", E); return -1; }
     if (rows <= 0) return 0;
-    if (f32) hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, dy, x, mean, rstd, gamma, dres,
+    const dim3 grid(ceil_div(rows, 4));
+    if (f32) hipLaunchKernelGGL((ln_bwd_kernel<float, float>), grid, dim3(256), 0, s, dy, x, mean, rstd, gamma, dres,
                                 dx_out, dx_bf16, rows, E, xstride, bf16_colscale);
-    else hipLaunchKernelGGL(ln_bwd_kernel<bf16>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, dy, x, mean, rstd, gamma, dres,
+    else if (dy_stored) hipLaunchKernelGGL((ln_bwd_kernel<bf16, bf16>), grid, dim3(256), 0, s, dy, x, mean, rstd, gamma, dres,
+                                           dx_out, dx_bf16, rows, E, xstride, bf16_colscale);
+    else hipLaunchKernelGGL((ln_bwd_kernel<bf16, float>), grid, dim3(256), 0, s, dy, x, mean, rstd, gamma, dres,
                             dx_out, dx_bf16, rows, E, xstride, bf16_colscale);
     LAUNCH_OK("ln_bwd_kernel");
     return 0;

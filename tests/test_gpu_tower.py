@@ -66,12 +66,19 @@ def bf16_noise(sd, method, classes, images, labels, head_w, head_b):
 
 
 def tol(base, emulated, worst=0.0):
-    """Gate = the stated tolerance, widened only where bf16 operand rounding alone already exceeds it:
-    cancellation-heavy sums (bias gradients over a 4-image batch) and everything behind the bottleneck
-    Adapter's ReLU, whose mask flips under operand rounding -- there the f32 oracle with bf16-rounded
-    operands moves individual tensors by 5-70 % and WHICH tensor moves most is chaotic
-    (scripts/debug_adapter.py), so the bound also admits 1.25x the worst tensor of the emulation."""
+    """Gate of the bf16 production path = the calibrated tolerance, widened per tensor only where bf16 operand rounding
+    ALONE (the f32 oracle with its contraction operands rounded to bf16, same inputs) already exceeds it.  The STATED gates
+    of BASELINE.md (2e-2 / 5e-2) are asserted without any widening in the f32-class verification mode
+    (tests/test_gpu_verify.py).  `worst` (see relu_worst) is non-zero only for the bottleneck Adapter."""
     return max(base, 2.5 * emulated + 1e-2, 1.25 * worst)
+
+
+def relu_worst(method, noise):
+    """The bottleneck Adapter alone has a hard non-linearity on the trainable path (ReLU, adapter_model.py:271): under
+    operand rounding its mask flips for pre-activations near zero, and WHICH gradient tensor absorbs the flips is chaotic
+    (the f32 oracle with bf16-rounded operands moves single tensors by 5-70 % there, scripts/debug_adapter.py), so for
+    that method the per-tensor bound also admits 1.25x the worst tensor of the emulation.  Every other method: 0."""
+    return max(noise.values()) if method == "adapter" else 0.0
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -101,7 +108,7 @@ def test_train_step_matches_reference_fixture(case):
             assert float(g.abs().max()) == 0.0, name              # reference .grad is None
             continue
         err = rel_err(g.cpu(), t[key])
-        assert err < tol(GRAD_TOL, noise[name], max(noise.values())), (name, err, noise[name])
+        assert err < tol(GRAD_TOL, noise[name], relu_worst(meta["method"], noise)), (name, err, noise[name])
 
 
 @pytest.mark.parametrize("case", ["tiny_kadaptation", "tiny_lora", "tiny_adapter", "tiny_compacter"])
@@ -335,7 +342,7 @@ def test_long_sequences_full_step_vs_oracle(method, arch_name, B):
             assert float(gv[k].abs().max()) == 0.0
         else:
             err = rel_err(gv[k].cpu(), tr.p[k].grad)
-            assert err < tol(GRAD_TOL, noise[k], max(noise.values())), (k, err, noise[k])
+            assert err < tol(GRAD_TOL, noise[k], relu_worst(method, noise)), (k, err, noise[k])
 
 
 # ---- the architectures of BASELINE configs 3-5 at full width/depth ---------------------------------------
@@ -386,7 +393,7 @@ def test_baseline_config_architectures_vs_oracle(arch_name, method, lora_r):
     # logits moved (24 random-weight layers move them by ~10 % under bf16 operand rounding alone)
     assert abs(float(loss) - float(ref_loss)) <= max(5e-2, 2.0 * float((logits.cpu() - ref_logits).abs().max()))
     gv = eng.grad_views()
-    worst = max(noise.values())
+    worst = relu_worst(method, noise)
     for k in tr.names:
         if tr.p[k].grad is None:
             assert float(gv[k].abs().max()) == 0.0
