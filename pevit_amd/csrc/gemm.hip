@@ -54,6 +54,11 @@ int num_cus() {
     return n;
 }
 
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 // tile coordinates of this workgroup.  Order: XCD-contiguous (xcd_remap), and inside that a band
 // of TILE_BAND m-tiles is walked n-major, so the tiles an XCD has in flight share TILE_BAND
 // A-panels and only a few B-panels (a 128x768 bf16 panel is 192 KiB; the XCD's L2 is 4 MiB).
@@ -90,7 +95,7 @@ typedef __attribute__((ext_vector_type(4))) int i32x4;
 // WGM x WGN waves, each owning WM x WN fragments of 32x32.  MINW = waves per SIMD the register
 // allocation must allow (= workgroups per CU x waves per workgroup / 4).
 // LDS: [A stage 0][B stage 0][A stage 1][B stage 1], rows of 128 bytes (64 bf16 / 128 fp8).
-template <int EPI, int WGM, int WGN, int WM, int WN, int MINW, bool HOIST, bool BF8, bool SPREAD>
+template <int EPI, int WGM, int WGN, int WM, int WN, int MINW, bool HOIST, bool BF8, bool SPREAD, bool PIPE>
 __global__ __launch_bounds__(WGM * WGN * 64, MINW) void gemm_kernel(GemmParams p, int ntiles) {
     constexpr int NW = WGM * WGN;
     constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32, BK = 64;
@@ -245,8 +250,63 @@ __global__ __launch_bounds__(WGM * WGN * 64, MINW) void gemm_kernel(GemmParams p
                 }
             }
         };
-        for (int kt = 0; kt + 1 < nk; ++kt) k_tile(kt, std::true_type{});
-        if (nk > 0) k_tile(nk - 1, std::false_type{});
+        if constexpr (PIPE) {
+            // Software-pipelined k-loop (bf16 B, hoisted fragments): the fragments of k-tile t+1 are read from LDS into a
+            // SECOND register set while the MFMAs of k-tile t run from the first, so neither the ds_read latency nor the
+            // LDS bandwidth of a k-tile sits in front of its MFMAs any more -- measured "compute only" the plain loop
+            // reaches 39 % of the MFMA peak on the step's shapes, its waves alternate between a read phase and an MFMA
+            // phase in lock step with the workgroup barrier.  Because a k-tile's LDS stage is free as soon as its
+            // fragments are in registers, the LDS-DMA of k-tile t+2 is requested at the top of iteration t: two k-tiles
+            // of operand stream in flight with two stages.
+            //   top of iteration t:  DMA(t+1) landed (vmcnt), own reads(t) landed (lgkmcnt) -> barrier
+            //                        -> request DMA(t+2) into stage t&1 -> reads(t+1) -> MFMA(t)
+            static_assert(HOIST && !BF8, "the pipelined loop is built for hoisted bf16 fragments");
+            constexpr int G = PA + PB;
+            bf16x8 afA[KS][WM], bfA[KS][WN], afB[KS][WM], bfB[KS][WN];
+            auto read_frags = [&](int kt, bf16x8 (&af)[KS][WM], bf16x8 (&bf)[KS][WN]) {
+                const char* st = smem + (kt & 1) * STAGE_BYTES;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int coff = (((ks * 2 + fhalf) ^ fswz) << 4);
+#pragma unroll
+                    for (int i = 0; i < WM; ++i) af[ks][i] = *reinterpret_cast<const bf16x8*>(st + a_off[i] + coff);
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) bf[ks][j] = *reinterpret_cast<const bf16x8*>(st + b_off[j] + coff);
+                }
+            };
+            auto mfma_all = [&](bf16x8 (&af)[KS][WM], bf16x8 (&bf)[KS][WN]) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int i = 0; i < WM; ++i)
+#pragma unroll
+                        for (int j = 0; j < WN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bf[ks][j], acc[i][j], 0, 0, 0);
+            };
+            auto step = [&](int t, bf16x8 (&caf)[KS][WM], bf16x8 (&cbf)[KS][WN], bf16x8 (&naf)[KS][WM], bf16x8 (&nbf)[KS][WN]) {
+                // DMA(t+1) and this wave's reads(t) have landed.  The builtin (not inline asm) so that the compiler's own
+                // wait-count bookkeeping knows it: otherwise it protects the MFMAs of k-tile t with an lgkmcnt(0) placed
+                // AFTER the reads of k-tile t+1 were issued, which serialises them again
+                __builtin_amdgcn_s_waitcnt(0x0070);                              // vmcnt(0) expcnt(7) lgkmcnt(0)
+                __builtin_amdgcn_s_barrier();                                    // ... for every wave: stage t&1 is free
+                if (t + 2 < nk) issue_tile(t + 2);
+                if (t + 1 < nk) read_frags(t + 1, naf, nbf);
+                mfma_all(caf, cbf);
+            };
+            if (nk > 0) {
+                __syncthreads();                                // the previous epilogue no longer uses stage 1 as scratch
+                if (nk > 1) { issue_tile(1); wait_vmcnt<G>(); } else wait_vmcnt<0>();    // k-tile 0 landed; k-tile 1 may fly
+                __builtin_amdgcn_s_barrier();
+                read_frags(0, afA, bfA);
+                for (int kt = 0; kt < nk; kt += 2) {
+                    step(kt, afA, bfA, afB, bfB);
+                    if (kt + 1 < nk) step(kt + 1, afB, bfB, afA, bfA);
+                }
+            }
+        } else {
+            for (int kt = 0; kt + 1 < nk; ++kt) k_tile(kt, std::true_type{});
+            if (nk > 0) k_tile(nk - 1, std::false_type{});
+        }
         // both stages are idle after this barrier: stage 0 receives the next tile's first k-tile while
         // the epilogue transposes through (this wave's 4 KiB of) stage 1
         __syncthreads();
@@ -292,18 +352,24 @@ __global__ __launch_bounds__(WGM * WGN * 64, MINW) void gemm_kernel(GemmParams p
 }
 
 // wgm x wgn waves of wm x wn fragments; wgs = workgroups per CU the LDS and registers are sized for
-struct TileConfig { int wgm, wgn, wm, wn, wgs; bool hoist, spread; };
+struct TileConfig { int wgm, wgn, wm, wn, wgs; bool hoist, spread, pipe; };
 constexpr TileConfig kConfigs[] = {
     // 4-wave tiles request the next k-tile in one burst: with 2-4 workgroups per CU another workgroup computes while
-    // this one sits in its issue slots, and in the step the burst measured 3 % faster than the spread order
-    // (5.59 vs 5.75 ms per step, profiles/r02_step_ab.md); the 8-wave tiles (one workgroup per CU) spread it.
-    {2, 2, 2, 2, 2, true, false},   // 0: 128x128, 4 waves, 64 KiB, 2 workgroups / CU
-    {2, 2, 1, 2, 3, true, false},   // 1:  64x128, 4 waves, 48 KiB, 3 workgroups / CU
-    {2, 2, 1, 1, 4, false, false},  // 2:  64x64,  4 waves, 32 KiB, 4 workgroups / CU (bottleneck products, N <= 64)
-    {4, 2, 2, 2, 1, true, true},    // 3: 256x128, 8 waves, 96 KiB, 1 workgroup / CU
-    {2, 4, 4, 2, 1, false, true},   // 4: 256x256, 8 waves, 128 KiB
-    {2, 4, 5, 2, 1, false, true},   // 5: 320x256, 8 waves, 144 KiB
-    {2, 2, 2, 1, 3, true, false},   // 6: 128x64,  4 waves, 48 KiB, 3 workgroups / CU
+    // this one sits in its issue slots (in the step: burst 5.59 ms, spread 5.75 ms).  The 8-wave tiles (one workgroup per
+    // CU) spread the requests between their MFMAs.
+    {2, 2, 2, 2, 2, true, false, false},   // 0: 128x128, 4 waves, 64 KiB, 2 workgroups / CU
+    {2, 2, 1, 2, 3, true, false, false},   // 1:  64x128, 4 waves, 48 KiB, 3 workgroups / CU
+    {2, 2, 1, 1, 4, false, false, false},  // 2:  64x64,  4 waves, 32 KiB, 4 workgroups / CU (bottleneck products, N <= 64)
+    {4, 2, 2, 2, 1, true, true, false},    // 3: 256x128, 8 waves, 96 KiB, 1 workgroup / CU
+    {2, 4, 4, 2, 1, false, true, false},   // 4: 256x256, 8 waves, 128 KiB
+    {2, 4, 5, 2, 1, false, true, false},   // 5: 320x256, 8 waves, 144 KiB
+    {2, 2, 2, 1, 3, true, false, false},   // 6: 128x64,  4 waves, 48 KiB, 3 workgroups / CU
+    // software-pipelined twins of 0 and 1 (register double buffer, two k-tiles of LDS-DMA in flight): bit-identical
+    // results, measured SLOWER on every shape of the step (c_proj 62.8 vs 54.9 us, 5.48 vs 5.45 ms per step) -- the
+    // k-loop is bound by the operand stream, not by the ds_read -> MFMA latency the pipelining removes
+    // (profiles/r02_gemm_pipelined.md).  Opt-in through gemm_config / gemm_cfg_longk for measurements only.
+    {2, 2, 2, 2, 2, true, false, true},    // 7
+    {2, 2, 1, 2, 2, true, false, true},    // 8
 };
 constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 constexpr int cfg_bm(int c) { return kConfigs[c].wgm * kConfigs[c].wm * 32; }
@@ -315,7 +381,7 @@ int launch_cfg(const GemmParams& p, const GemmTune& t, hipStream_t stream) {
     constexpr int nw = c.wgm * c.wgn, bm = cfg_bm(CFG), bn = cfg_bn(CFG);
     constexpr int lds = 2 * (bm + bn) * 128;
     constexpr int minw = c.wgs * nw / 4;
-    auto kern = gemm_kernel<EPI, c.wgm, c.wgn, c.wm, c.wn, minw, c.hoist, BF8, c.spread>;
+    auto kern = gemm_kernel<EPI, c.wgm, c.wgn, c.wm, c.wn, minw, c.hoist, BF8, c.spread, c.pipe && !BF8>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
@@ -380,6 +446,8 @@ int launch_epi(const GemmParams& p, const GemmTune& t, hipStream_t stream) {
         case 3: return launch_cfg<EPI, 3, BF8>(p, t, stream);
         case 4: return launch_cfg<EPI, 4, BF8>(p, t, stream);
         case 6: return launch_cfg<EPI, 6, BF8>(p, t, stream);
+        case 7: return launch_cfg<EPI, 7, BF8>(p, t, stream);
+        case 8: return launch_cfg<EPI, 8, BF8>(p, t, stream);
         default: return launch_cfg<EPI, 5, BF8>(p, t, stream);
     }
 }

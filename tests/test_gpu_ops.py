@@ -66,10 +66,10 @@ def test_gemm_f32_and_bf16(lib, M, N, K):
     assert max_rel(outb.float().cpu(), ref.cpu()) < 1e-2
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("M,N,K", [(6400, 768, 768), (700, 2368, 256), (257, 136, 64), (1300, 640, 1024)])
 def test_gemm_every_tile_config_is_bit_identical(lib, cfg, M, N, K):
-    """The seven tile configurations (4-wave 128x128 / 64x128 / 64x64 / 128x64, 8-wave 256x128 / 256x256 / 320x256) walk K in the
+    """The tile configurations (4-wave 128x128 / 64x128 / 64x64 / 128x64, 8-wave 256x128 / 256x256 / 320x256, and the plain-loop twins of the software-pipelined 4-wave kernels) walk K in the
     same order, so forcing any of them must reproduce the heuristic's result bit for bit -- partial tiles in M and N,
     several tiles per persistent workgroup (M=6400 at 64x64) and the fused epilogues included."""
     A = rnd(M, K, seed=1, dtype=torch.bfloat16)
