@@ -174,7 +174,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, MINW) void gemm_kernel(GemmParams p
         // per group of WN MFMAs): a wave issues in order, and a CU accepts only ~64 outstanding 128-byte requests, so
         // a burst of PA+PB requests at the top of the iteration parks every wave in its issue slot until the burst has
         // drained -- the k-loop then runs load + compute instead of max(load, compute) (measured: 320x256 tile,
-        // 5200 clk per k-tile against 2560 of MFMA and ~3100 of stream; profiles/r02_gemm_shapes.md).
+        // 5200 clk per k-tile against 2560 of MFMA and ~3100 of stream; profiles/r02_gemm_experiments.md).
         auto k_tile = [&](int kt, auto issue_next) {
             constexpr bool ISSUE = decltype(issue_next)::value;
             constexpr int NG = KS * WM, NP = PA + PB;       // MFMA groups per k-tile, pieces per wave
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, MINW) void gemm_kernel(GemmParams p
 struct TileConfig { int wgm, wgn, wm, wn, wgs; bool hoist, spread, pipe; };
 constexpr TileConfig kConfigs[] = {
     // 4-wave tiles request the next k-tile in one burst: with 2-4 workgroups per CU another workgroup computes while
-    // this one sits in its issue slots (in the step: burst 5.59 ms, spread 5.75 ms).  The 8-wave tiles (one workgroup per
+    // this one sits in its issue slots (in the step: burst 5.59 ms, spread 5.75 ms; profiles/r02_gemm_experiments.md section 2).  The 8-wave tiles (one workgroup per
     // CU) spread the requests between their MFMAs.
     {2, 2, 2, 2, 2, true, false, false},   // 0: 128x128, 4 waves, 64 KiB, 2 workgroups / CU
     {2, 2, 1, 2, 3, true, false, false},   // 1:  64x128, 4 waves, 48 KiB, 3 workgroups / CU
@@ -367,7 +367,7 @@ constexpr TileConfig kConfigs[] = {
     // software-pipelined twins of 0 and 1 (register double buffer, two k-tiles of LDS-DMA in flight): bit-identical
     // results, measured SLOWER on every shape of the step (c_proj 62.8 vs 54.9 us, 5.48 vs 5.45 ms per step) -- the
     // k-loop is bound by the operand stream, not by the ds_read -> MFMA latency the pipelining removes
-    // (profiles/r02_gemm_pipelined.md).  Opt-in through gemm_config / gemm_cfg_longk for measurements only.
+    // (profiles/r02_gemm_experiments.md section 3).  Opt-in through gemm_config / gemm_cfg_longk for measurements only.
     {2, 2, 2, 2, 2, true, false, true},    // 7
     {2, 2, 1, 2, 2, true, false, true},    // 8
 };
@@ -404,7 +404,7 @@ int launch_cfg(const GemmParams& p, const GemmTune& t, hipStream_t stream) {
     return 0;
 }
 
-// Tile shape per problem.  Measured on MI355X (scripts/bench_gemm.py, profiles/r02_gemm_shapes.md).
+// Tile shape per problem.  Measured on MI355X (scripts/bench_gemm.py, profiles/r02_gemm_experiments.md).
 // The 8-wave tiles win when their tiling still gives (almost) every CU one tile per round;
 // the N = 768 products of the ViT-B step (75 tiles of 256x256) stay on the 4-wave tiles.
 int pick_config(const GemmParams& p, const GemmTune& t) {
