@@ -434,7 +434,10 @@ int pick_config(const GemmParams& p, const GemmTune& t) {
     }
     const long t128 = (long)ceil_div(p.M, 128) * ceil_div(p.N, 128);
     if (t128 >= 700) return 0;
-    return p.K >= t.kswitch ? t.cfg_longk : t.cfg_shortk;
+    // few-tile problems (the N = E products): 128x128 only when K is long AND its tiles fit the 2 x CUs residency slots in
+    // one round -- 300 tiles at ViT-B/32 B=128; at 520 (ViT-L/14, B=32) or 594 (ViT-B/16, B=64) tiles the handful of
+    // second-round tiles doubles the kernel time and 64x128 is 1.3-2.7 % faster per step (profiles/r02_gemm_experiments.md 9)
+    return (p.K >= t.kswitch && t128 <= 2L * cus) ? t.cfg_longk : t.cfg_shortk;
 }
 
 template <int EPI, bool BF8>
