@@ -143,6 +143,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=INT",
                     help="library tuning knob for A/B runs, e.g. gemm_big=0 (see pevit_tune)")
+    ap.add_argument("--dist-backend", default="nccl", help="(tests only) process-group backend; RCCL refuses two ranks on one device, "
+                                                            "gloo carries device tensors")
+    ap.add_argument("--share-device", action="store_true", help="(tests only) every rank uses cuda:0")
     ap.add_argument("--pmc-calib", action="store_true",
                     help="(profiling runs only) first move a known byte count through HBM so that the FETCH_SIZE / "
                          "WRITE_SIZE counters of the same rocprofv3 pass can be calibrated (scripts/pmc_traffic.py)")
@@ -154,11 +157,16 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == "nccl":
+            torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            torch.distributed.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
     from pevit_amd.engine import HipEngine
     from pevit_amd.synth import ARCHS, reference_init_, synth_batch, synth_state_dict
