@@ -94,6 +94,7 @@ def default_config() -> CfgNode:
         NAME="", OUTPUT_DIR="", GPUS=(0,), RANK=0, VERBOSE=True, WORKERS=4, PIN_MEMORY=True,
         CUDNN=dict(BENCHMARK=True, DETERMINISTIC=False, ENABLED=True),
         MODEL=dict(NAME="ViT-B/32", NUM_PARAMS_IN_M=0.0, AUTHOR="", PRETRAINED_DATA="", CREATION_TIME="", CLIP_FP32=False,
+                   WEIGHT_FORMAT="bf16",     # engine storage of the frozen block weights: "bf16" | "fp8" (not a reference key)
                    SPEC=dict(EMBED_DIM=512, TEXT=dict(TOKENIZER="clip", CONTEXT_LENGTH=77))),
         DATASET=dict(DATASET="cifar100", ROOT="", NUM_CLASSES=100, NUM_SAMPLES_PER_CLASS=-1, RANDOM_SEED_SAMPLING=0,
                      MERGE_TRAIN_VAL_FINAL_RUN=True, CENTER_CROP=True, IMAGE_SIZE=(224,)),

@@ -195,6 +195,9 @@ class ClassifierBase(nn.Module):
             self.channel_bn = nn.Identity()
 
         visual = self.backbone.visual
+        wf = str(config.MODEL.get("WEIGHT_FORMAT", "bf16")) if hasattr(config.MODEL, "get") else "bf16"
+        if wf != "bf16":
+            visual.weight_format = wf
         visual._num_classes = output_dim
         visual._max_batch = max(int(config.TRAIN.BATCH_SIZE_PER_GPU), int(config.TEST.BATCH_SIZE_PER_GPU))
         if visual._engine is not None and visual._engine.num_classes != output_dim:

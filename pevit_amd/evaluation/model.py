@@ -16,6 +16,7 @@ PyTorch, as SURVEY 8f-4 prescribes; it is not on the accelerated path.
 from __future__ import annotations
 
 import math
+import os
 import weakref
 from collections import OrderedDict
 
@@ -110,7 +111,7 @@ class _EngineCache:
     @staticmethod
     def _key(visual, device, num_classes):
         fp = getattr(visual, "_frozen_fingerprint", None)
-        return None if fp is None else (fp, visual.method, visual.lora_rank, num_classes, str(device))
+        return None if fp is None else (fp, visual.method, visual.lora_rank, num_classes, str(device), visual.weight_format)
 
     def acquire(self, visual, device, num_classes, max_batch):
         key = self._key(visual, device, num_classes)
@@ -213,6 +214,10 @@ class VisionTransformer(nn.Module):
         super().__init__()
         self.input_resolution, self.output_dim = arch.resolution, arch.embed_dim
         self.arch, self.method, self.lora_rank = arch, method, lora_rank
+        # storage of the frozen block weights in the engine: "bf16", or "fp8" (e4m3 codes + per-channel scales, BASELINE
+        # config 5; KAdaptation / LoRA).  Set before the model moves to the GPU (config key MODEL.WEIGHT_FORMAT, or the
+        # PEVIT_WEIGHT_FORMAT environment variable for scripts that cannot pass config keys)
+        self.weight_format = os.environ.get("PEVIT_WEIGHT_FORMAT", "bf16")
         self._engine: HipEngine | None = None
         self._train_params = None
         E, L = arch.width, arch.layers
@@ -288,7 +293,8 @@ class VisionTransformer(nn.Module):
         sd = {"visual." + k: v for k, v in self.state_dict().items()}
         eng = _ENGINES.acquire(self, torch.device(device), num_classes, max_batch)
         if eng is None:
-            eng = HipEngine(self.arch, self.method, num_classes, max_batch, lora_rank=self.lora_rank, device=device)
+            eng = HipEngine(self.arch, self.method, num_classes, max_batch, lora_rank=self.lora_rank, device=device,
+                            weight_format=self.weight_format)
             eng.load_state_dict(sd)                    # frozen weights + overlay of the adapter values in sd
             _ENGINES.register(self, eng)
         else:

@@ -304,3 +304,37 @@ def test_engine_rejects_inputs_it_would_misread(ckpt):
     assert abs(float(loss) - float(ref)) < 1e-5
     _, loss = eng.forward_backward(img, torch.tensor([1, 10, 3, 2]).cuda())
     assert not torch.isfinite(loss).all()
+
+
+def test_fp8_weight_format_through_the_reference_api(ckpt):
+    """MODEL.WEIGHT_FORMAT = 'fp8' (BASELINE config 5) reaches the engine through Classifier / train_one, and the step is
+    bit-identical to the same Classifier on the de-quantised checkpoint with bf16 weights."""
+    import os
+    from pevit_amd import fp8
+    from pevit_amd.evaluation import _harness
+    meta, t = load_golden("tiny_kadaptation")
+    losses = {}
+    for fmt in ("fp8", "bf16"):
+        _harness._BACKBONES.clear()
+        path = ckpt
+        if fmt == "bf16":                                      # the weights an fp8 engine computes with, as a checkpoint
+            sd = dict(load_tiny_sd())
+            path = os.path.join(os.path.dirname(str(ckpt)), "tiny_dequantised.pt")
+            torch.save(fp8.dequantized_state_dict(sd), path)
+        mod = importlib.import_module("pevit_amd.evaluation.kadaptation_clip")
+        cfg = tiny_config(path, classes=meta["classes"])
+        cfg.TRAIN.LR, cfg.TRAIN.WD, cfg.TRAIN.MOMENTUM = meta["lr"], meta["wd"], 0.9
+        cfg.MODEL.WEIGHT_FORMAT = fmt
+        clf = mod.Classifier(cfg, 0).cuda(0)
+        named = dict(clf.backbone.named_parameters())
+        with torch.no_grad():
+            for k, v in t.items():
+                if k.startswith("adapter/"):
+                    named[k[len("adapter/"):]].copy_(v)
+            clf.layers[0].weight.copy_(t["head_w"]); clf.layers[0].bias.copy_(t["head_b"])
+        assert clf.backbone.visual.engine().weight_format == fmt
+        opt = mod.build_optimizer(cfg, clf)
+        crit = torch.nn.CrossEntropyLoss().cuda(0)
+        mod.train_one(OneBatch(t["images"], t["labels"], 2), clf, crit, opt, 0, cfg)
+        losses[fmt] = torch.cat([p.detach().flatten().cpu() for n, p in clf.named_parameters() if p.requires_grad and n != "logit_scale"])
+    assert torch.equal(losses["fp8"], losses["bf16"])
