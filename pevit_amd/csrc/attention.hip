@@ -66,6 +66,23 @@ __device__ __forceinline__ bf16x8 tfrag(const bf16* Tt, int LDT, int dt, int s, 
     return o;
 }
 
+// The same fragment straight from a ROW-major tile Ys[y][LDR] (LDS) with gfx950's transposing read: in each 16-lane
+// group, lane 4j+q passes the address of 4 consecutive d of token-row j, and lane i receives, as element j, element i&3
+// of the piece addressed by lane 4j + (i>>2) (measured: scripts/probe_tr_b16.hip).  Lane 4j+q therefore points at
+// Ys[32s + 4g + j][16q + 4dt ..+3], and lane m ends up with d = 16*(m>>2) + 4*dt + (m&3) for the tokens 32s+4g+0..3
+// (second read: +16 tokens) -- tfrag()'s layout without a transposed copy and its scattered 2-byte writes.
+__device__ __forceinline__ bf16x8 tfrag_tr(const bf16* Ys, int LDR, int dt, int s, int lane) {
+    typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+    const int m = lane & 15, g = lane >> 4;
+    const bf16* src = Ys + (32 * s + 4 * g + (m >> 2)) * LDR + 16 * (m & 3) + 4 * dt;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(src));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(src + 16 * LDR));
+    bf16x8 o;
+    o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
+    o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
+    return o;
+}
+
 // Tt[d][y] = src[y][d] for y < N, 0 for N <= y < NPAD.  src rows are `stride` elements apart.
 __device__ __forceinline__ void stage_transposed(bf16* Tt, int LDT, const bf16* src, size_t stride, int N,
                                                  int NPAD) {
@@ -96,22 +113,25 @@ template <int KT32>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
                                                        const bf16* __restrict__ v, bf16* __restrict__ out, int ldo,
                                                        float* __restrict__ lse, int H, int N) {
-    constexpr int NPAD = 32 * KT32, LDT = NPAD + att_tpad(KT32), LDK = ATT_LDR;
+    constexpr int NPAD = 32 * KT32, LDK = ATT_LDR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* Ks = reinterpret_cast<bf16*>(smem);                 // [NPAD][LDK] row-major, padded rows
-    bf16* Vt = Ks + NPAD * LDK;                               // [64][LDT]   transposed
+    bf16* Vs = Ks + NPAD * LDK;                               // [NPAD][LDK] row-major, padded rows zero
     const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
     const bf16* qh = q + (size_t)bh * N * 64;
     const bf16* kh = k + (size_t)bh * N * 64;
     const bf16* vh = v + (size_t)bh * N * 64;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, g = lane >> 4, c16 = lane & 15;
 
+    // K and V both stay row-major (16-byte LDS writes); V^T fragments come from the transposing read (tfrag_tr)
     for (int idx = threadIdx.x; idx < NPAD * 8; idx += 256) {
         const int y = idx >> 3, c = idx & 7;
         const int ys = y < N ? y : N - 1;
-        *reinterpret_cast<bf16x8*>(Ks + y * LDK + 8 * c) = load_bf16x8(kh + (size_t)ys * 64 + 8 * c);
+        const bf16x8 kk = load_bf16x8(kh + (size_t)ys * 64 + 8 * c);
+        const bf16x8 vv = y < N ? load_bf16x8(vh + (size_t)y * 64 + 8 * c) : zero_bf16x8();
+        *reinterpret_cast<bf16x8*>(Ks + y * LDK + 8 * c) = kk;
+        *reinterpret_cast<bf16x8*>(Vs + y * LDK + 8 * c) = vv;
     }
-    stage_transposed(Vt, LDT, vh, 64, N, NPAD);
     __syncthreads();
 
     const int nxt = (N + 15) >> 4;
@@ -159,7 +179,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
         for (int dt = 0; dt < 4; ++dt) {
             o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int s = 0; s < KT32; ++s) o[dt] = mfma16(tfrag(Vt, LDT, dt, s, lane), pf[s], o[dt]);
+            for (int s = 0; s < KT32; ++s) o[dt] = mfma16(tfrag_tr(Vs, LDK, dt, s, lane), pf[s], o[dt]);
         }
         if (xq < N) {
             store16(out + ((size_t)b * N + xq) * ldo + h * 64 + 16 * g, o, 1.0f / l);
@@ -176,12 +196,19 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
                                                        const float* __restrict__ lse, bf16* __restrict__ dqkv, int ld,
                                                        int H, int N, int phase) {
     constexpr int NPAD = 32 * KT32, LDT = NPAD + att_tpad(KT32);
+    constexpr bool ROWLDS = ROWLDS_T;
+    constexpr int LDR = ATT_LDR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // small-N variant (N <= 64): [lse][delta][Qs][Ks][Vs][dOs], row-major tiles only; otherwise [Kt][Qt][dOt][lse][delta]
+    float* lse_s = reinterpret_cast<float*>(smem + (ROWLDS ? 0 : 3 * 64 * LDT * 2));
+    float* del_s = lse_s + NPAD;
     bf16* Kt = reinterpret_cast<bf16*>(smem);
     bf16* Qt = Kt + 64 * LDT;
     bf16* dOt = Qt + 64 * LDT;
-    float* lse_s = reinterpret_cast<float*>(dOt + 64 * LDT);
-    float* del_s = lse_s + NPAD;
+    bf16* Qs = reinterpret_cast<bf16*>(del_s + NPAD);
+    bf16* Ks = Qs + NPAD * LDR;
+    bf16* Vs = Ks + NPAD * LDR;
+    bf16* dOs = Vs + NPAD * LDR;
     const int bh = blockIdx.x, b = bh / H, h = bh - b * H, E = H * 64;
     const bf16* qh = q + (size_t)bh * N * 64;
     const bf16* kh = k + (size_t)bh * N * 64;
@@ -190,57 +217,65 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
     const bf16* doh = dout + (size_t)b * N * lddo + h * 64;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, g = lane >> 4, c16 = lane & 15;
 
-    // Small-N variant (N <= 64): the row-major operands are staged in LDS as well, so that every
-    // MFMA fragment of the two passes is an LDS read (the pass loops are otherwise chains of
-    // dependent global-load latencies).  Padded rows are zero.
-    constexpr bool ROWLDS = ROWLDS_T;
-    constexpr int LDR = ATT_LDR;
-    bf16* Qs = reinterpret_cast<bf16*>(del_s + NPAD);
-    bf16* Ks = Qs + NPAD * LDR;
-    bf16* Vs = Ks + NPAD * LDR;
-    bf16* dOs = Vs + NPAD * LDR;
     if constexpr (ROWLDS) {
-        for (int idx = threadIdx.x; idx < NPAD * 8; idx += 256) {
-            const int y = idx >> 3, c = idx & 7;
-            bf16x8 vq = zero_bf16x8(), vk = zero_bf16x8(), vv = zero_bf16x8(), vd = zero_bf16x8();
-            if (y < N) {
-                vq = load_bf16x8(qh + (size_t)y * 64 + 8 * c);
-                vk = load_bf16x8(kh + (size_t)y * 64 + 8 * c);
-                vv = load_bf16x8(vh + (size_t)y * 64 + 8 * c);
-                vd = load_bf16x8(doh + (size_t)y * lddo + 8 * c);
-            }
-            *reinterpret_cast<bf16x8*>(Qs + y * LDR + 8 * c) = vq;
-            *reinterpret_cast<bf16x8*>(Ks + y * LDR + 8 * c) = vk;
-            *reinterpret_cast<bf16x8*>(Vs + y * LDR + 8 * c) = vv;
-            *reinterpret_cast<bf16x8*>(dOs + y * LDR + 8 * c) = vd;
+        // Small-N variant: every operand is staged ROW-major in LDS (16-byte writes), so that each MFMA fragment of the
+        // two passes is an LDS read -- the row fragments plain ds_read_b128, the transposed ones ds_read_b64_tr_b16
+        // (tfrag_tr).  One round trip to HBM: all five tensors of both loop iterations are requested before the first
+        // LDS write; delta[y] = sum_d dO[y][d] * O[y][d] (== sum_keys P*dP) comes out of the same registers.
+        // Padded rows are zero.
+        constexpr int IT = NPAD * 8 / 256;
+        bf16x8 vq[IT], vk[IT], vv[IT], vd[IT], vo[IT];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                Kt[(8 * c + i) * LDT + (y ^ (c << 2))] = vk[i];
-                Qt[(8 * c + i) * LDT + (y ^ (c << 2))] = vq[i];
-                dOt[(8 * c + i) * LDT + (y ^ (c << 2))] = vd[i];
+        for (int it = 0; it < IT; ++it) {
+            const int idx = threadIdx.x + 256 * it, y = idx >> 3, c = idx & 7;
+            vq[it] = zero_bf16x8(); vk[it] = zero_bf16x8(); vv[it] = zero_bf16x8(); vd[it] = zero_bf16x8(); vo[it] = zero_bf16x8();
+            if (y < N) {
+                vq[it] = load_bf16x8(qh + (size_t)y * 64 + 8 * c);
+                vk[it] = load_bf16x8(kh + (size_t)y * 64 + 8 * c);
+                vv[it] = load_bf16x8(vh + (size_t)y * 64 + 8 * c);
+                vd[it] = load_bf16x8(doh + (size_t)y * lddo + 8 * c);
+                vo[it] = load_bf16x8(oh + (size_t)y * ldo + 8 * c);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int idx = threadIdx.x + 256 * it, y = idx >> 3, c = idx & 7;
+            *reinterpret_cast<bf16x8*>(Qs + y * LDR + 8 * c) = vq[it];
+            *reinterpret_cast<bf16x8*>(Ks + y * LDR + 8 * c) = vk[it];
+            *reinterpret_cast<bf16x8*>(Vs + y * LDR + 8 * c) = vv[it];
+            *reinterpret_cast<bf16x8*>(dOs + y * LDR + 8 * c) = vd[it];
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc += bf2f(vd[it][i]) * bf2f(vo[it][i]);
+            acc += __shfl_xor(acc, 1, 64);
+            acc += __shfl_xor(acc, 2, 64);
+            acc += __shfl_xor(acc, 4, 64);
+            if (c == 0) {
+                del_s[y] = acc;
+                lse_s[y] = y < N ? lse[(size_t)bh * N + y] : 0.f;
             }
         }
     } else {
         stage_transposed(Kt, LDT, kh, 64, N, NPAD);
         stage_transposed(Qt, LDT, qh, 64, N, NPAD);
         stage_transposed(dOt, LDT, doh, (size_t)lddo, N, NPAD);
-    }
-    // delta[y] = sum_d dO[y][d] * O[y][d]   (== sum_keys P*dP), 8 lanes per row
-    for (int idx = threadIdx.x; idx < NPAD * 8; idx += 256) {
-        const int y = idx >> 3, c = idx & 7;
-        float acc = 0.f;
-        if (y < N) {
-            const bf16x8 a = load_bf16x8(doh + (size_t)y * lddo + 8 * c);
-            const bf16x8 o = load_bf16x8(oh + (size_t)y * ldo + 8 * c);
+        // delta[y] = sum_d dO[y][d] * O[y][d]   (== sum_keys P*dP), 8 lanes per row
+        for (int idx = threadIdx.x; idx < NPAD * 8; idx += 256) {
+            const int y = idx >> 3, c = idx & 7;
+            float acc = 0.f;
+            if (y < N) {
+                const bf16x8 a = load_bf16x8(doh + (size_t)y * lddo + 8 * c);
+                const bf16x8 o = load_bf16x8(oh + (size_t)y * ldo + 8 * c);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc += bf2f(a[i]) * bf2f(o[i]);
-        }
-        acc += __shfl_xor(acc, 1, 64);
-        acc += __shfl_xor(acc, 2, 64);
-        acc += __shfl_xor(acc, 4, 64);
-        if (c == 0) {
-            del_s[y] = acc;
-            lse_s[y] = y < N ? lse[(size_t)bh * N + y] : 0.f;
+                for (int i = 0; i < 8; ++i) acc += bf2f(a[i]) * bf2f(o[i]);
+            }
+            acc += __shfl_xor(acc, 1, 64);
+            acc += __shfl_xor(acc, 2, 64);
+            acc += __shfl_xor(acc, 4, 64);
+            if (c == 0) {
+                del_s[y] = acc;
+                lse_s[y] = y < N ? lse[(size_t)bh * N + y] : 0.f;
+            }
         }
     }
     __syncthreads();
@@ -283,7 +318,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
                 }
             }
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16(tfrag(Kt, LDT, dt, s, lane), dsb, o[dt]);
+            for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16(ROWLDS ? tfrag_tr(Ks, LDR, dt, s, lane) : tfrag(Kt, LDT, dt, s, lane), dsb, o[dt]);
         }
         if (xq < N) store16(dqkv + ((size_t)b * N + xq) * ld + h * 64 + 16 * g, o, 1.0f);
     }
@@ -322,8 +357,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
             }
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                ok[dt] = mfma16(tfrag(Qt, LDT, dt, s, lane), dsb, ok[dt]);
-                ov[dt] = mfma16(tfrag(dOt, LDT, dt, s, lane), pb, ov[dt]);
+                ok[dt] = mfma16(ROWLDS ? tfrag_tr(Qs, LDR, dt, s, lane) : tfrag(Qt, LDT, dt, s, lane), dsb, ok[dt]);
+                ov[dt] = mfma16(ROWLDS ? tfrag_tr(dOs, LDR, dt, s, lane) : tfrag(dOt, LDT, dt, s, lane), pb, ov[dt]);
             }
         }
         if (xk < N) {
@@ -338,7 +373,7 @@ template <int KT32>
 int launch_fwd(const bf16* q, const bf16* k, const bf16* v, bf16* out, int ldo, float* lse, int B, int H, int N,
                hipStream_t s) {
     constexpr int NPAD = 32 * KT32;
-    const int bytes = (NPAD * ATT_LDR + 64 * (NPAD + att_tpad(KT32))) * 2;
+    const int bytes = 2 * NPAD * ATT_LDR * 2;
     static bool attr = false;
     if (!attr && bytes > 48 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<KT32>),
@@ -356,7 +391,7 @@ template <int KT32, bool ROWLDS>
 int launch_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* out, int ldo, const bf16* dout, int lddo,
                const float* lse, bf16* dqkv, int ld, int B, int H, int N, hipStream_t s) {
     constexpr int NPAD = 32 * KT32;
-    const int bytes = 3 * 64 * (NPAD + att_tpad(KT32)) * 2 + 2 * NPAD * 4 + (ROWLDS ? 4 * NPAD * ATT_LDR * 2 : 0);
+    const int bytes = 2 * NPAD * 4 + (ROWLDS ? 4 * NPAD * ATT_LDR * 2 : 3 * 64 * (NPAD + att_tpad(KT32)) * 2);
     static bool attr = false;
     if (!attr && bytes > 48 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<KT32, ROWLDS>),

@@ -114,21 +114,34 @@ __global__ __launch_bounds__(256) void delta_add_kernel(bf16* qbuf, bf16* vbuf, 
     const int grp = wg / parts, part = wg - grp * parts;
     const int rr0 = grp * 16 * DA_RG;
     if (rr0 >= T) return;                          // whole wave exits together
-    bf16x8 th[DA_RG], tl[DA_RG];
     size_t boff[DA_RG];                            // element offset of this lane's row in the q / v buffer
     bf16* const base = which ? vbuf : qbuf;
     bool rok[DA_RG];
+    int rrk[DA_RG];
 #pragma unroll
     for (int k = 0; k < DA_RG; ++k) {
-        int rr = rr0 + 16 * k + c16;
+        const int rr = rr0 + 16 * k + c16;
         rok[k] = rr < T;
-        rr = rok[k] ? rr : T - 1;
-        split_bf16(t + (size_t)row_of_ref(rr, B, N) * 64 + which * 32 + 8 * g, th[k], tl[k]);
-        boff[k] = (size_t)rr * E;
+        rrk[k] = rok[k] ? rr : T - 1;
+        boff[k] = (size_t)rrk[k] * E;
     }
+    // the read-modify-write operands come from HBM: request all of them before anything else (the t / Q fragments
+    // below are L2 hits and their bf16 split is ALU work that runs under this latency)
+    constexpr int NST = DA_COLS / 32;
+    typedef typename std::conditional<sizeof(ST) == 2, bf16x8, f32x8>::type raw8;
+    raw8 cur[NST][DA_RG];                          // kept raw: converting here would wait for the loads here
+#pragma unroll
+    for (int st = 0; st < NST; ++st)
+#pragma unroll
+        for (int k = 0; k < DA_RG; ++k)
+            cur[st][k] = *reinterpret_cast<const raw8*>(reinterpret_cast<const ST*>(base) + boff[k] + part * DA_COLS + st * 32 + 8 * g);
+    bf16x8 th[DA_RG], tl[DA_RG];
+#pragma unroll
+    for (int k = 0; k < DA_RG; ++k)
+        split_bf16(t + (size_t)row_of_ref(rrk[k], B, N) * 64 + which * 32 + 8 * g, th[k], tl[k]);
     const int m = c16;
 #pragma unroll
-    for (int st = 0; st < DA_COLS / 32; ++st) {
+    for (int st = 0; st < NST; ++st) {
         const int eb = part * DA_COLS + st * 32;
         const int e_t0 = eb + 8 * (m >> 2) + (m & 3);
         bf16x8 q0h, q0l, q1h, q1l;
@@ -143,18 +156,6 @@ __global__ __launch_bounds__(256) void delta_add_kernel(bf16* qbuf, bf16* vbuf, 
 #pragma unroll
             for (int i = 0; i < 8; ++i) bb[i] = 0.f;
         }
-        float cur[DA_RG][8];
-#pragma unroll
-        for (int k = 0; k < DA_RG; ++k) {
-            if constexpr (sizeof(ST) == 2) {
-                const bf16x8 c8 = load_bf16x8(base + boff[k] + eb + 8 * g);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) cur[k][i] = bf2f(c8[i]);
-            } else {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) cur[k][i] = reinterpret_cast<const float*>(base)[boff[k] + eb + 8 * g + i];
-            }
-        }
 #pragma unroll
         for (int k = 0; k < DA_RG; ++k) {
             f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
@@ -168,8 +169,8 @@ __global__ __launch_bounds__(256) void delta_add_kernel(bf16* qbuf, bf16* vbuf, 
             float o[8];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                o[r] = cur[k][r] + ascale * a0[r] + bb[r];
-                o[4 + r] = cur[k][4 + r] + ascale * a1[r] + bb[4 + r];
+                o[r] = (float)cur[st][k][r] + ascale * a0[r] + bb[r];
+                o[4 + r] = (float)cur[st][k][4 + r] + ascale * a1[r] + bb[4 + r];
             }
             if (rok[k]) {
                 st_store4<ST>(base, boff[k] + eb + 8 * g, o[0], o[1], o[2], o[3]);
@@ -201,18 +202,32 @@ __global__ __launch_bounds__(256) void lowrank_u_kernel(const bf16* __restrict__
     f32x4 acc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // a wave's k-steps are s = wid, wid + 4, ...; the dDelta fragments (HBM) of LU_UNROLL steps are requested together,
+    // the Q fragments (L2 hits) follow -- one round trip per LU_UNROLL steps instead of one per step
+    constexpr int LU_UNROLL = 6;
     const int steps = E / 32;
-    for (int s = wid; s < steps; s += 4) {
-        const int e0 = (s >> 1) * 64, doff = (s & 1) * 32 + 8 * g;
-        const bf16x8 aq = load_bf16x8(ddelta_slab(dqkv, ld, 0, rr, e0, E, H, N) + doff);
-        const bf16x8 av = load_bf16x8(ddelta_slab(dqkv, ld, 2 * E, rr, e0, E, H, N) + doff);
-        const int ke = 32 * s + 8 * g;
+    for (int sb = wid; sb < steps; sb += 4 * LU_UNROLL) {
+        bf16x8 aq[LU_UNROLL], av[LU_UNROLL];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const bf16x8 bq = load_bf16x8(qT + (size_t)(16 * nt + c16) * E + ke);
-            const bf16x8 bv = load_bf16x8(qT + (size_t)(32 + 16 * nt + c16) * E + ke);
-            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq, bq, acc[nt], 0, 0, 0);
-            acc[2 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[2 + nt], 0, 0, 0);
+        for (int i = 0; i < LU_UNROLL; ++i) {
+            const int s = min(sb + 4 * i, steps - 1);
+            const int e0 = (s >> 1) * 64, doff = (s & 1) * 32 + 8 * g;
+            aq[i] = load_bf16x8(ddelta_slab(dqkv, ld, 0, rr, e0, E, H, N) + doff);
+            av[i] = load_bf16x8(ddelta_slab(dqkv, ld, 2 * E, rr, e0, E, H, N) + doff);
+        }
+#pragma unroll
+        for (int i = 0; i < LU_UNROLL; ++i) {
+            const int s = sb + 4 * i;
+            if (s < steps) {
+                const int ke = 32 * s + 8 * g;
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const bf16x8 bq = load_bf16x8(qT + (size_t)(16 * nt + c16) * E + ke);
+                    const bf16x8 bv = load_bf16x8(qT + (size_t)(32 + 16 * nt + c16) * E + ke);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[i], bq, acc[nt], 0, 0, 0);
+                    acc[2 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[i], bv, acc[2 + nt], 0, 0, 0);
+                }
+            }
         }
     }
 #pragma unroll
@@ -243,76 +258,115 @@ __global__ __launch_bounds__(256) void lowrank_u_kernel(const bf16* __restrict__
 //   kind 1: X = dDelta_q (flat view), Y = t_q  -> G2 = dQ_q  (+ column sums -> d bias)
 //   kind 2: X = dDelta_v,             Y = t_v  -> G3 = dQ_v  (+ column sums)
 // The MFMA wants the contraction index contiguous per lane, but both operands are stored
-// token-major.  One workgroup = (chunk of LG_ROWS tokens, 64 columns e, kind): it reads its
-// X / Y panels with 16-byte coalesced loads, writes them TRANSPOSED into LDS (Xt[e][token],
-// Yt[j][token], bf16, 8-token groups XOR-swizzled by e>>3 so that the scattered 2-byte writes
-// spread over all banks), and then runs 16x16x32 bf16 MFMAs whose fragments are plain
-// ds_read_b128.  One deterministic partial per chunk goes to HBM.
+// token-major.  One workgroup = (chunk of LG_ROWS tokens, kind, LG_ES slabs of 64 columns e).  Both panels go to LDS
+// ROW-major (X: 16-byte writes as loaded; Y: f32 -> bf16, 8-byte writes) and every MFMA fragment is a pair of
+// ds_read_b64_tr_b16 (the gfx950 transposing read: in a 16-lane group lane 4j+q passes the address of 4 consecutive
+// columns of token-row j and lane i receives column i of that 4 x 16 block; scripts/probe_tr_b16.hip), k-slot idx of
+// lane group g = token 32ks + 4g + idx (idx < 4) and 32ks + 16 + 4g + idx - 4.  The Y fragments are the same for every
+// slab: they are read once into registers, and the X panel of the next slab is in flight (registers) while the current
+// one is multiplied.  One deterministic partial per chunk goes to HBM.
 constexpr int LG_ROWS = 256;
-constexpr int LG_LDT = LG_ROWS + 8;
-__device__ __forceinline__ int lg_col(int row_e, int y) { return y ^ (((row_e >> 3) & 7) << 3); }
+constexpr int LG_LD = 72;          // row stride (elements) of the LDS tiles: 36 dwords, 8 consecutive rows cover all banks
+constexpr int LG_ES = 2;           // 64-column slabs per workgroup
 
-__global__ __launch_bounds__(256) void lowrank_grad_kernel(const bf16* __restrict__ xn, int ldx,
-                                                           const float* __restrict__ u32,
-                                                           const bf16* __restrict__ dqkv, int ld,
-                                                           const float* __restrict__ t, float* __restrict__ partial,
-                                                           float* __restrict__ dbias_partial, int B, int H, int N,
-                                                           int E) {
-    __shared__ __attribute__((aligned(16))) bf16 Xt[64 * LG_LDT];
-    __shared__ __attribute__((aligned(16))) bf16 Yt[64 * LG_LDT];
+__device__ __forceinline__ bf16x8 lg_trfrag(const bf16* tile, int ks, int col0, int lane) {
+    typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+    const int m = lane & 15, g = lane >> 4;
+    const bf16* src = tile + (32 * ks + 4 * g + (m >> 2)) * LG_LD + col0 + 4 * (m & 3);
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(src));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(src + 16 * LG_LD));
+    bf16x8 o;
+    o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
+    o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
+    return o;
+}
+
+__global__ __launch_bounds__(256, 2) void lowrank_grad_kernel(const bf16* __restrict__ xn, int ldx,
+                                                              const float* __restrict__ u32,
+                                                              const bf16* __restrict__ dqkv, int ld,
+                                                              const float* __restrict__ t, float* __restrict__ partial,
+                                                              float* __restrict__ dbias_partial, int B, int H, int N,
+                                                              int E) {
+    __shared__ __attribute__((aligned(16))) bf16 Xs[LG_ROWS * LG_LD];
+    __shared__ __attribute__((aligned(16))) bf16 Ys[LG_ROWS * LG_LD];
     __shared__ float cs[4][64];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, c16 = lane & 15;
-    const int epairs = E / 64;
-    const int per_chunk = epairs * 3;
+    const int groups = E / 64 / LG_ES;
+    const int per_chunk = groups * 3;
     const int chunk = blockIdx.x / per_chunk, rem = blockIdx.x - chunk * per_chunk;
-    const int kind = rem / epairs, ep = rem - kind * epairs;
-    const int T = B * N, e0 = ep * 64;
+    const int kind = rem / groups, eg = rem - kind * groups;
+    const int T = B * N;
     const int r0 = chunk * LG_ROWS;
     const int col0 = (kind == 1) ? 0 : 2 * E;
     const int toff = (kind == 1) ? 0 : 32;
-
-    // ---- issue every global load of the two panels first (the kernel is latency-bound) ------
     const int c = tid & 7;
+
     bf16x8 xv[LG_ROWS / 32];
+    auto load_x = [&](int e0) {
 #pragma unroll
-    for (int it = 0; it < LG_ROWS / 32; ++it) {
-        const int r = r0 + (tid >> 3) + 32 * it;
-        xv[it] = zero_bf16x8();
-        if (r < T) {
-            const bf16* src = (kind == 0) ? xn + (size_t)r * ldx + e0 : ddelta_slab(dqkv, ld, col0, r, e0, E, H, N);
-            xv[it] = load_bf16x8(src + 8 * c);
+        for (int it = 0; it < LG_ROWS / 32; ++it) {
+            const int r = r0 + (tid >> 3) + 32 * it;
+            xv[it] = zero_bf16x8();
+            if (r < T) {
+                const bf16* src = (kind == 0) ? xn + (size_t)r * ldx + e0 : ddelta_slab(dqkv, ld, col0, r, e0, E, H, N);
+                xv[it] = load_bf16x8(src + 8 * c);
+            }
         }
-    }
+    };
+    load_x(eg * LG_ES * 64);
     // Y (f32): kind 0 -> 64 columns of u (16 float4 per row); else 32 columns of t (8 float4 per row)
     const int sh = (kind == 0) ? 4 : 3;                     // log2(float4 groups per row)
     const int nY = (kind == 0) ? 16 : 8;                    // loads per thread
-    float4 yv[16];
+    {
+        float4 yv[16];
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
-        yv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (it < nY) {
-            const int idx = tid + 256 * it;
-            const int y = idx >> sh, c4 = idx & ((1 << sh) - 1);
-            const int r = r0 + y;
-            if (r < T) {
-                const float* src = (kind == 0) ? u32 + (size_t)r * 64 : t + (size_t)row_of_ref(r, B, N) * 64 + toff;
-                yv[it] = *reinterpret_cast<const float4*>(src + 4 * c4);
+        for (int it = 0; it < 16; ++it) {
+            yv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (it < nY) {
+                const int idx = tid + 256 * it;
+                const int y = idx >> sh, c4 = idx & ((1 << sh) - 1);
+                const int r = r0 + y;
+                if (r < T) {
+                    const float* src = (kind == 0) ? u32 + (size_t)r * 64 : t + (size_t)row_of_ref(r, B, N) * 64 + toff;
+                    yv[it] = *reinterpret_cast<const float4*>(src + 4 * c4);
+                }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            if (it < nY) {
+                const int idx = tid + 256 * it;
+                const int y = idx >> sh, j = 4 * (idx & ((1 << sh) - 1));
+                bf16x4 o;
+                o[0] = f2bf(yv[it].x); o[1] = f2bf(yv[it].y); o[2] = f2bf(yv[it].z); o[3] = f2bf(yv[it].w);
+                *reinterpret_cast<bf16x4*>(Ys + y * LG_LD + j) = o;
             }
         }
     }
-    // ---- transposed LDS writes ---------------------------------------------------------------
-    {
+    __syncthreads();
+    // Y fragments: col j = 16nt + c16, the same for every slab
+    const int NT = (kind == 0) ? 4 : 2;
+    bf16x8 bfr[LG_ROWS / 32][4];
+#pragma unroll
+    for (int ks = 0; ks < LG_ROWS / 32; ++ks)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+            bfr[ks][nt] = (nt < NT) ? lg_trfrag(Ys, ks, 16 * nt, lane) : zero_bf16x8();
+
+    const size_t plane = (size_t)E * 32;
+    float* base = partial + ((size_t)chunk * 4 + (kind == 0 ? 0 : kind + 1)) * plane;
+    for (int sl = 0; sl < LG_ES; ++sl) {
+        const int e0 = (eg * LG_ES + sl) * 64;
+        // ---- this slab's X panel: registers -> LDS (row-major), column sums on the way ----
         float colsum[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) colsum[i] = 0.f;
 #pragma unroll
         for (int it = 0; it < LG_ROWS / 32; ++it) {
             const int y = (tid >> 3) + 32 * it;
+            *reinterpret_cast<bf16x8*>(Xs + y * LG_LD + 8 * c) = xv[it];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                Xt[(8 * c + i) * LG_LDT + lg_col(8 * c + i, y)] = xv[it][i];
-                colsum[i] += bf2f(xv[it][i]);
-            }
+            for (int i = 0; i < 8; ++i) colsum[i] += bf2f(xv[it][i]);
         }
         if (kind != 0) {     // column sums: reduce over the 8 row-lanes of this wave, then over waves
 #pragma unroll
@@ -322,53 +376,33 @@ __global__ __launch_bounds__(256) void lowrank_grad_kernel(const bf16* __restric
                 if ((lane >> 3) == 0) cs[wid][8 * c + i] = a;
             }
         }
-    }
+        __syncthreads();
+        if (sl + 1 < LG_ES) load_x(e0 + 64);               // in flight during the MFMAs below
+        // ---- MFMA: wave w owns rows e = 16w..16w+15 of the 64 x (64|32) tile ----
+        f32x4 acc[4];
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
-        if (it < nY) {
-            const int idx = tid + 256 * it;
-            const int y = idx >> sh, j = 4 * (idx & ((1 << sh) - 1));
-            Yt[(j + 0) * LG_LDT + lg_col(j + 0, y)] = f2bf(yv[it].x);
-            Yt[(j + 1) * LG_LDT + lg_col(j + 1, y)] = f2bf(yv[it].y);
-            Yt[(j + 2) * LG_LDT + lg_col(j + 2, y)] = f2bf(yv[it].z);
-            Yt[(j + 3) * LG_LDT + lg_col(j + 3, y)] = f2bf(yv[it].w);
+        for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < LG_ROWS / 32; ++ks) {
+            const bf16x8 a = lg_trfrag(Xs, ks, 16 * wid, lane);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                if (nt < NT) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfr[ks][nt], acc[nt], 0, 0, 0);
         }
-    }
-    __syncthreads();
-
-    // ---- MFMA: wave w owns rows e = 16w..16w+15 of the 64 x (64|32) tile
-    const int NT = (kind == 0) ? 4 : 2;
-    f32x4 acc[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int ea = 16 * wid + c16;
-#pragma unroll
-    for (int ks = 0; ks < LG_ROWS / 32; ++ks) {
-        const int y0 = 32 * ks + 8 * g;
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(Xt + ea * LG_LDT + lg_col(ea, y0));
+        // C layout: col j = 16nt + c16, rows e = 16w + 4g + reg
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             if (nt < NT) {
-                const int jb = 16 * nt + c16;
-                const bf16x8 b = *reinterpret_cast<const bf16x8*>(Yt + jb * LG_LDT + lg_col(jb, y0));
-                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[nt], 0, 0, 0);
+                float* out = base + (nt >> 1) * plane;           // kind 0: j-tiles 2,3 are the u_v plane
+                const int j = 16 * (nt & 1) + c16;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[(size_t)(e0 + 16 * wid + 4 * g + r) * 32 + j] = acc[nt][r];
             }
         }
+        if (kind != 0 && tid < 64)
+            dbias_partial[((size_t)chunk * 2 + (kind - 1)) * E + e0 + tid] = cs[0][tid] + cs[1][tid] + cs[2][tid] + cs[3][tid];
+        __syncthreads();                                   // Xs and cs are rewritten by the next slab
     }
-    // C layout: col j = 16nt + c16, rows e = 16w + 4g + reg
-    const size_t plane = (size_t)E * 32;
-    float* base = partial + ((size_t)chunk * 4 + (kind == 0 ? 0 : kind + 1)) * plane;
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        if (nt < NT) {
-            float* out = base + (nt >> 1) * plane;           // kind 0: j-tiles 2,3 are the u_v plane
-            const int j = 16 * (nt & 1) + c16;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) out[(size_t)(e0 + 16 * wid + 4 * g + r) * 32 + j] = acc[nt][r];
-        }
-    }
-    if (kind != 0 && tid < 64)
-        dbias_partial[((size_t)chunk * 2 + (kind - 1)) * E + e0 + tid] = cs[0][tid] + cs[1][tid] + cs[2][tid] + cs[3][tid];
 }
 
 // sum the per-chunk partials of every layer (blockIdx.y): G[l][4][E][32], and the bias gradient
@@ -521,8 +555,8 @@ int pevit_launch_lowrank_grad(const bf16* xn, int ldx, const float* u32, const b
                               hipStream_t s) {
     const int T = B * N;
     if (chunks != ceil_div(T, LG_ROWS)) { pevit_set_error("lowrank_grad: chunks mismatch"); return -1; }
-    if (E % 64) { pevit_set_error("lowrank_grad: width %d must be a multiple of 64", E); return -1; }
-    hipLaunchKernelGGL(lowrank_grad_kernel, dim3(chunks * (E / 64) * 3), dim3(256), 0, s, xn, ldx, u32, dqkv, ld, t,
+    if (E % (64 * LG_ES)) { pevit_set_error("lowrank_grad: width %d must be a multiple of %d", E, 64 * LG_ES); return -1; }
+    hipLaunchKernelGGL(lowrank_grad_kernel, dim3(chunks * (E / 64 / LG_ES) * 3), dim3(256), 0, s, xn, ldx, u32, dqkv, ld, t,
                        partial, dbias_partial, B, H, N, E);
     LAUNCH_OK("lowrank_grad_kernel");
     return 0;
