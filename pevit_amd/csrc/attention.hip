@@ -25,11 +25,8 @@
 #include "common.h"
 #include "kernels.h"
 
-// LDS paddings (elements): transposed tiles have rows of NPAD + att_tpad(KT32) tokens, row-major copies rows of
-// ATT_LDR.  With the tswz() swizzle below, a transposed-row length of 96 mod 128 elements makes both the scattered
-// 2-byte writes and the 8-byte fragment reads bank-conflict free (bank model + search: scripts/lds_bank_model.py);
-// that costs 32 pad columns at N <= 64, none at N <= 224, and is not affordable at N <= 288 (pad 4 there).
-constexpr int att_tpad(int kt32) { return kt32 == 2 ? 32 : (kt32 == 7 ? 0 : 4); }
+// LDS tiles are row-major [tokens][ATT_LDR] (16-byte writes as loaded); rows of 80 elements = 40 dwords keep both the
+// ds_read_b128 row fragments and the ds_read_b64_tr_b16 transposed fragments spread over the banks (72 measured equal).
 #ifndef ATT_LDR
 #define ATT_LDR 80
 #endif
@@ -45,32 +42,12 @@ __device__ __forceinline__ bf16x8 rowfrag(const bf16* base, size_t stride, int r
     return load_bf16x8(base + (size_t)row * stride + 32 * s + 8 * g);
 }
 
-// Transposed tiles Tt[64][LDT] keep token y of row d at column y ^ tswz(d): the scattered 2-byte writes of one
-// wave instruction go to rows 8c+i, c = 0..7, whose 136-byte stride maps them onto only two LDS banks (4-way
-// conflicts, 62 % of this kernel's LDS cycles by SQ_LDS_BANK_CONFLICT); XOR-ing bits 2..4 of the token index with
-// the row group spreads them over disjoint dwords and leaves every aligned group of 4 tokens contiguous, which is
-// all the fragment reads need.
-__device__ __forceinline__ int tswz(int d) { return ((d >> 3) & 7) << 2; }
-
-// fragment of a transposed tile Tt[64][LDT] (LDS): output row m -> d = 16*(m>>2) + 4*dt + (m&3)
-__device__ __forceinline__ bf16x8 tfrag(const bf16* Tt, int LDT, int dt, int s, int lane) {
-    const int m = lane & 15, g = lane >> 4;
-    const int d = 16 * (m >> 2) + 4 * dt + (m & 3);
-    const bf16* row = Tt + d * LDT;
-    const int sw = tswz(d);
-    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(row + ((32 * s + 4 * g) ^ sw));
-    const bf16x4 hi = *reinterpret_cast<const bf16x4*>(row + ((32 * s + 16 + 4 * g) ^ sw));
-    bf16x8 o;
-    o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
-    o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
-    return o;
-}
-
-// The same fragment straight from a ROW-major tile Ys[y][LDR] (LDS) with gfx950's transposing read: in each 16-lane
+// Fragment of the TRANSPOSE of a row-major tile Ys[y][LDR] (LDS), output row m -> d = 16*(m>>2) + 4*dt + (m&3), with gfx950's
+// transposing read: in each 16-lane
 // group, lane 4j+q passes the address of 4 consecutive d of token-row j, and lane i receives, as element j, element i&3
 // of the piece addressed by lane 4j + (i>>2) (measured: scripts/probe_tr_b16.hip).  Lane 4j+q therefore points at
 // Ys[32s + 4g + j][16q + 4dt ..+3], and lane m ends up with d = 16*(m>>2) + 4*dt + (m&3) for the tokens 32s+4g+0..3
-// (second read: +16 tokens) -- tfrag()'s layout without a transposed copy and its scattered 2-byte writes.
+// (second read: +16 tokens) -- no transposed copy in LDS, no scattered 2-byte writes.
 __device__ __forceinline__ bf16x8 tfrag_tr(const bf16* Ys, int LDR, int dt, int s, int lane) {
     typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
     const int m = lane & 15, g = lane >> 4;
@@ -81,18 +58,6 @@ __device__ __forceinline__ bf16x8 tfrag_tr(const bf16* Ys, int LDR, int dt, int 
     o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
     o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
     return o;
-}
-
-// Tt[d][y] = src[y][d] for y < N, 0 for N <= y < NPAD.  src rows are `stride` elements apart.
-__device__ __forceinline__ void stage_transposed(bf16* Tt, int LDT, const bf16* src, size_t stride, int N,
-                                                 int NPAD) {
-    for (int idx = threadIdx.x; idx < NPAD * 8; idx += blockDim.x) {
-        const int y = idx >> 3, c = idx & 7;
-        bf16x8 v = zero_bf16x8();
-        if (y < N) v = load_bf16x8(src + (size_t)y * stride + 8 * c);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) Tt[(8 * c + i) * LDT + (y ^ (c << 2))] = v[i];      // tswz(8c+i) = c << 2
-    }
 }
 
 __device__ __forceinline__ void store16(bf16* dst, const f32x4 o[4], float scale) {
@@ -109,8 +74,8 @@ __device__ __forceinline__ void store16(bf16* dst, const f32x4 o[4], float scale
 }
 
 // ------------------------------------------------------------------------------------
-template <int KT32>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
+template <int KT32, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
                                                        const bf16* __restrict__ v, bf16* __restrict__ out, int ldo,
                                                        float* __restrict__ lse, int H, int N) {
     constexpr int NPAD = 32 * KT32, LDK = ATT_LDR;
@@ -124,7 +89,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, g = lane >> 4, c16 = lane & 15;
 
     // K and V both stay row-major (16-byte LDS writes); V^T fragments come from the transposing read (tfrag_tr)
-    for (int idx = threadIdx.x; idx < NPAD * 8; idx += 256) {
+    for (int idx = threadIdx.x; idx < NPAD * 8; idx += 64 * NW) {
         const int y = idx >> 3, c = idx & 7;
         const int ys = y < N ? y : N - 1;
         const bf16x8 kk = load_bf16x8(kh + (size_t)ys * 64 + 8 * c);
@@ -135,7 +100,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
     __syncthreads();
 
     const int nxt = (N + 15) >> 4;
-    for (int xt = wid; xt < nxt; xt += 4) {
+    for (int xt = wid; xt < nxt; xt += NW) {
         const int xq = 16 * xt + c16;                 // this lane's query (column)
         const int xs = xq < N ? xq : N - 1;
         bf16x8 qf[2];
@@ -189,26 +154,39 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------
-template <int KT32, bool ROWLDS_T>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
-                                                       const bf16* __restrict__ v, const bf16* __restrict__ out,
-                                                       int ldo, const bf16* __restrict__ dout, int lddo,
-                                                       const float* __restrict__ lse, bf16* __restrict__ dqkv, int ld,
-                                                       int H, int N, int phase) {
-    constexpr int NPAD = 32 * KT32, LDT = NPAD + att_tpad(KT32);
-    constexpr bool ROWLDS = ROWLDS_T;
+// rows [0, NPAD) of a row-major LDS tile <- src rows (stride elements apart), zero beyond N; 16-byte loads and writes
+__device__ __forceinline__ void stage_rows(bf16* dst, int LDR, const bf16* src, size_t stride, int N, int NPAD) {
+    for (int idx = threadIdx.x; idx < NPAD * 8; idx += blockDim.x) {
+        const int y = idx >> 3, c = idx & 7;
+        bf16x8 v = zero_bf16x8();
+        if (y < N) v = load_bf16x8(src + (size_t)y * stride + 8 * c);
+        *reinterpret_cast<bf16x8*>(dst + y * LDR + 8 * c) = v;
+    }
+}
+
+// ALL4 (N <= 64): Q, K, V, dO of the head are LDS-resident for both passes.  Otherwise the tiles of the loop side only:
+// K, V during pass A, then Q, dO in the same LDS during pass B; the 16-row x-side fragments come from global memory once
+// per tile.  Either way every fragment inside the pass loops is an LDS read: row fragments ds_read_b128, transposed
+// ones ds_read_b64_tr_b16 (tfrag_tr) -- no transposed copies, no dependent global loads in the loops.
+template <int KT32, bool ALL4, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
+                                                          const bf16* __restrict__ v, const bf16* __restrict__ out,
+                                                          int ldo, const bf16* __restrict__ dout, int lddo,
+                                                          const float* __restrict__ lse, bf16* __restrict__ dqkv, int ld,
+                                                          int H, int N) {
+    constexpr int NPAD = 32 * KT32;
     constexpr int LDR = ATT_LDR;
+    constexpr int NT = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // small-N variant (N <= 64): [lse][delta][Qs][Ks][Vs][dOs], row-major tiles only; otherwise [Kt][Qt][dOt][lse][delta]
-    float* lse_s = reinterpret_cast<float*>(smem + (ROWLDS ? 0 : 3 * 64 * LDT * 2));
+    // [lse][delta][tile 0][tile 1]([tile 2][tile 3])
+    float* lse_s = reinterpret_cast<float*>(smem);
     float* del_s = lse_s + NPAD;
-    bf16* Kt = reinterpret_cast<bf16*>(smem);
-    bf16* Qt = Kt + 64 * LDT;
-    bf16* dOt = Qt + 64 * LDT;
-    bf16* Qs = reinterpret_cast<bf16*>(del_s + NPAD);
-    bf16* Ks = Qs + NPAD * LDR;
-    bf16* Vs = Ks + NPAD * LDR;
-    bf16* dOs = Vs + NPAD * LDR;
+    bf16* T0 = reinterpret_cast<bf16*>(del_s + NPAD);
+    bf16* T1 = T0 + NPAD * LDR;
+    bf16* Qs = ALL4 ? T0 : T0;                 // pass B (and, with ALL4, pass A's x side)
+    bf16* Ks = ALL4 ? T1 : T0;                 // pass A
+    bf16* Vs = ALL4 ? T1 + NPAD * LDR : T1;    // pass A
+    bf16* dOs = ALL4 ? T1 + 2 * NPAD * LDR : T1;   // pass B
     const int bh = blockIdx.x, b = bh / H, h = bh - b * H, E = H * 64;
     const bf16* qh = q + (size_t)bh * N * 64;
     const bf16* kh = k + (size_t)bh * N * 64;
@@ -217,17 +195,14 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
     const bf16* doh = dout + (size_t)b * N * lddo + h * 64;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, g = lane >> 4, c16 = lane & 15;
 
-    if constexpr (ROWLDS) {
-        // Small-N variant: every operand is staged ROW-major in LDS (16-byte writes), so that each MFMA fragment of the
-        // two passes is an LDS read -- the row fragments plain ds_read_b128, the transposed ones ds_read_b64_tr_b16
-        // (tfrag_tr).  One round trip to HBM: all five tensors of both loop iterations are requested before the first
-        // LDS write; delta[y] = sum_d dO[y][d] * O[y][d] (== sum_keys P*dP) comes out of the same registers.
-        // Padded rows are zero.
-        constexpr int IT = NPAD * 8 / 256;
+    if constexpr (ALL4) {
+        // One round trip to HBM: all five tensors of both loop iterations are requested before the first LDS write;
+        // delta[y] = sum_d dO[y][d] * O[y][d] (== sum_keys P*dP) comes out of the same registers.  Padded rows are zero.
+        constexpr int IT = NPAD * 8 / NT;
         bf16x8 vq[IT], vk[IT], vv[IT], vd[IT], vo[IT];
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
-            const int idx = threadIdx.x + 256 * it, y = idx >> 3, c = idx & 7;
+            const int idx = threadIdx.x + NT * it, y = idx >> 3, c = idx & 7;
             vq[it] = zero_bf16x8(); vk[it] = zero_bf16x8(); vv[it] = zero_bf16x8(); vd[it] = zero_bf16x8(); vo[it] = zero_bf16x8();
             if (y < N) {
                 vq[it] = load_bf16x8(qh + (size_t)y * 64 + 8 * c);
@@ -239,7 +214,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
         }
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
-            const int idx = threadIdx.x + 256 * it, y = idx >> 3, c = idx & 7;
+            const int idx = threadIdx.x + NT * it, y = idx >> 3, c = idx & 7;
             *reinterpret_cast<bf16x8*>(Qs + y * LDR + 8 * c) = vq[it];
             *reinterpret_cast<bf16x8*>(Ks + y * LDR + 8 * c) = vk[it];
             *reinterpret_cast<bf16x8*>(Vs + y * LDR + 8 * c) = vv[it];
@@ -256,11 +231,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
             }
         }
     } else {
-        stage_transposed(Kt, LDT, kh, 64, N, NPAD);
-        stage_transposed(Qt, LDT, qh, 64, N, NPAD);
-        stage_transposed(dOt, LDT, doh, (size_t)lddo, N, NPAD);
+        stage_rows(Ks, LDR, kh, 64, N, NPAD);
+        stage_rows(Vs, LDR, vh, 64, N, NPAD);
         // delta[y] = sum_d dO[y][d] * O[y][d]   (== sum_keys P*dP), 8 lanes per row
-        for (int idx = threadIdx.x; idx < NPAD * 8; idx += 256) {
+        for (int idx = threadIdx.x; idx < NPAD * 8; idx += NT) {
             const int y = idx >> 3, c = idx & 7;
             float acc = 0.f;
             if (y < N) {
@@ -280,149 +254,170 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
     }
     __syncthreads();
 
-    if (phase < 2) return;
     const int ntile = (N + 15) >> 4;
-    // operand sources for the MFMA row fragments
-    const bf16* Qr = ROWLDS ? Qs : qh;   const size_t qst = ROWLDS ? LDR : 64;
-    const bf16* Kr = ROWLDS ? Ks : kh;   const size_t kst = ROWLDS ? LDR : 64;
-    const bf16* Vr = ROWLDS ? Vs : vh;   const size_t vst = ROWLDS ? LDR : 64;
-    const bf16* Dr = ROWLDS ? dOs : doh; const size_t dst_ = ROWLDS ? LDR : (size_t)lddo;
     // ---------------- pass A: x = queries, y = keys -> dQ -----------------------------
-    for (int xt = wid; xt < ntile; xt += 4) {
-        const int xq = 16 * xt + c16;
-        const int xs = xq < N ? xq : N - 1;
-        bf16x8 x1[2], x2[2];
-        x1[0] = rowfrag(Qr, qst, xs, 0, g);  x1[1] = rowfrag(Qr, qst, xs, 1, g);
-        x2[0] = rowfrag(Dr, dst_, xs, 0, g); x2[1] = rowfrag(Dr, dst_, xs, 1, g);
-        const float lse_x = lse_s[xs], del_x = del_s[xs];
-        f32x4 o[4];
+    {
+        const bf16* Qr = ALL4 ? Qs : qh;   const size_t qst = ALL4 ? LDR : 64;
+        const bf16* Dr = ALL4 ? dOs : doh; const size_t dst_ = ALL4 ? LDR : (size_t)lddo;
+        for (int xt = wid; xt < ntile; xt += NW) {
+            const int xq = 16 * xt + c16;
+            const int xs = xq < N ? xq : N - 1;
+            bf16x8 x1[2], x2[2];
+            x1[0] = rowfrag(Qr, qst, xs, 0, g);  x1[1] = rowfrag(Qr, qst, xs, 1, g);
+            x2[0] = rowfrag(Dr, dst_, xs, 0, g); x2[1] = rowfrag(Dr, dst_, xs, 1, g);
+            const float lse_x = lse_s[xs], del_x = del_s[xs];
+            f32x4 o[4];
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll(KT32 <= 2 ? KT32 : 1)
-        for (int s = 0; s < KT32; ++s) {
-            bf16x8 dsb;
+            for (int s = 0; s < KT32; ++s) {
+                bf16x8 dsb;
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const int yt = 2 * s + half;
-                int yr = 16 * yt + c16; yr = yr < N ? yr : N - 1;
-                f32x4 z1 = {0.f, 0.f, 0.f, 0.f}, z2 = {0.f, 0.f, 0.f, 0.f};
-                z1 = mfma16(rowfrag(Kr, kst, yr, 0, g), x1[0], z1);
-                z1 = mfma16(rowfrag(Kr, kst, yr, 1, g), x1[1], z1);
-                z2 = mfma16(rowfrag(Vr, vst, yr, 0, g), x2[0], z2);
-                z2 = mfma16(rowfrag(Vr, vst, yr, 1, g), x2[1], z2);
+                for (int half = 0; half < 2; ++half) {
+                    const int yr = 32 * s + 16 * half + c16;       // padded rows of the LDS tiles are zero
+                    f32x4 z1 = {0.f, 0.f, 0.f, 0.f}, z2 = {0.f, 0.f, 0.f, 0.f};
+                    z1 = mfma16(rowfrag(Ks, LDR, yr, 0, g), x1[0], z1);
+                    z1 = mfma16(rowfrag(Ks, LDR, yr, 1, g), x1[1], z1);
+                    z2 = mfma16(rowfrag(Vs, LDR, yr, 0, g), x2[0], z2);
+                    z2 = mfma16(rowfrag(Vs, LDR, yr, 1, g), x2[1], z2);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = 16 * yt + 4 * g + r;
-                    const float p = key < N ? __expf(z1[r] - lse_x) : 0.f;
-                    dsb[half * 4 + r] = f2bf(p * (z2[r] - del_x));
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = 32 * s + 16 * half + 4 * g + r;
+                        const float p = key < N ? __expf(z1[r] - lse_x) : 0.f;
+                        dsb[half * 4 + r] = f2bf(p * (z2[r] - del_x));
+                    }
                 }
-            }
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16(ROWLDS ? tfrag_tr(Ks, LDR, dt, s, lane) : tfrag(Kt, LDT, dt, s, lane), dsb, o[dt]);
+                for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16(tfrag_tr(Ks, LDR, dt, s, lane), dsb, o[dt]);
+            }
+            if (xq < N) store16(dqkv + ((size_t)b * N + xq) * ld + h * 64 + 16 * g, o, 1.0f);
         }
-        if (xq < N) store16(dqkv + ((size_t)b * N + xq) * ld + h * 64 + 16 * g, o, 1.0f);
     }
-    if (phase < 3) return;
+    if constexpr (!ALL4) {
+        __syncthreads();                       // every wave is done with K, V
+        stage_rows(Qs, LDR, qh, 64, N, NPAD);
+        stage_rows(dOs, LDR, doh, (size_t)lddo, N, NPAD);
+        __syncthreads();
+    }
     // ---------------- pass B: x = keys, y = queries -> dK, dV -------------------------
-    for (int xt = wid; xt < ntile; xt += 4) {
-        const int xk = 16 * xt + c16;
-        const int xs = xk < N ? xk : N - 1;
-        bf16x8 x1[2], x2[2];
-        x1[0] = rowfrag(Kr, kst, xs, 0, g); x1[1] = rowfrag(Kr, kst, xs, 1, g);
-        x2[0] = rowfrag(Vr, vst, xs, 0, g); x2[1] = rowfrag(Vr, vst, xs, 1, g);
-        f32x4 ok[4], ov[4];
+    {
+        const bf16* Kr = ALL4 ? Ks : kh;   const size_t kst = ALL4 ? LDR : 64;
+        const bf16* Vr = ALL4 ? Vs : vh;   const size_t vst = ALL4 ? LDR : 64;
+        for (int xt = wid; xt < ntile; xt += NW) {
+            const int xk = 16 * xt + c16;
+            const int xs = xk < N ? xk : N - 1;
+            bf16x8 x1[2], x2[2];
+            x1[0] = rowfrag(Kr, kst, xs, 0, g); x1[1] = rowfrag(Kr, kst, xs, 1, g);
+            x2[0] = rowfrag(Vr, vst, xs, 0, g); x2[1] = rowfrag(Vr, vst, xs, 1, g);
+            f32x4 ok[4], ov[4];
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) { ok[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; ov[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            for (int dt = 0; dt < 4; ++dt) { ok[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; ov[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll(KT32 <= 2 ? KT32 : 1)
-        for (int s = 0; s < KT32; ++s) {
-            bf16x8 dsb, pb;
+            for (int s = 0; s < KT32; ++s) {
+                bf16x8 dsb, pb;
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const int yt = 2 * s + half;
-                int yr = 16 * yt + c16; yr = yr < N ? yr : N - 1;
-                f32x4 z1 = {0.f, 0.f, 0.f, 0.f}, z2 = {0.f, 0.f, 0.f, 0.f};
-                z1 = mfma16(rowfrag(Qr, qst, yr, 0, g), x1[0], z1);
-                z1 = mfma16(rowfrag(Qr, qst, yr, 1, g), x1[1], z1);
-                z2 = mfma16(rowfrag(Dr, dst_, yr, 0, g), x2[0], z2);
-                z2 = mfma16(rowfrag(Dr, dst_, yr, 1, g), x2[1], z2);
-                const f32x4 lse_y = *reinterpret_cast<const f32x4*>(lse_s + 16 * yt + 4 * g);
-                const f32x4 del_y = *reinterpret_cast<const f32x4*>(del_s + 16 * yt + 4 * g);
+                for (int half = 0; half < 2; ++half) {
+                    const int yt = 2 * s + half;
+                    const int yr = 16 * yt + c16;
+                    f32x4 z1 = {0.f, 0.f, 0.f, 0.f}, z2 = {0.f, 0.f, 0.f, 0.f};
+                    z1 = mfma16(rowfrag(Qs, LDR, yr, 0, g), x1[0], z1);
+                    z1 = mfma16(rowfrag(Qs, LDR, yr, 1, g), x1[1], z1);
+                    z2 = mfma16(rowfrag(dOs, LDR, yr, 0, g), x2[0], z2);
+                    z2 = mfma16(rowfrag(dOs, LDR, yr, 1, g), x2[1], z2);
+                    const f32x4 lse_y = *reinterpret_cast<const f32x4*>(lse_s + 16 * yt + 4 * g);
+                    const f32x4 del_y = *reinterpret_cast<const f32x4*>(del_s + 16 * yt + 4 * g);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int qy = 16 * yt + 4 * g + r;
-                    const float p = qy < N ? __expf(z1[r] - lse_y[r]) : 0.f;
-                    pb[half * 4 + r] = f2bf(p);
-                    dsb[half * 4 + r] = f2bf(p * (z2[r] - del_y[r]));
+                    for (int r = 0; r < 4; ++r) {
+                        const int qy = 16 * yt + 4 * g + r;
+                        const float p = qy < N ? __expf(z1[r] - lse_y[r]) : 0.f;
+                        pb[half * 4 + r] = f2bf(p);
+                        dsb[half * 4 + r] = f2bf(p * (z2[r] - del_y[r]));
+                    }
+                }
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    ok[dt] = mfma16(tfrag_tr(Qs, LDR, dt, s, lane), dsb, ok[dt]);
+                    ov[dt] = mfma16(tfrag_tr(dOs, LDR, dt, s, lane), pb, ov[dt]);
                 }
             }
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                ok[dt] = mfma16(ROWLDS ? tfrag_tr(Qs, LDR, dt, s, lane) : tfrag(Qt, LDT, dt, s, lane), dsb, ok[dt]);
-                ov[dt] = mfma16(ROWLDS ? tfrag_tr(dOs, LDR, dt, s, lane) : tfrag(dOt, LDT, dt, s, lane), pb, ov[dt]);
+            if (xk < N) {
+                bf16* dst = dqkv + ((size_t)b * N + xk) * ld + h * 64 + 16 * g;
+                store16(dst + E, ok, 1.0f);
+                store16(dst + 2 * E, ov, 1.0f);
             }
-        }
-        if (xk < N) {
-            bf16* dst = dqkv + ((size_t)b * N + xk) * ld + h * 64 + 16 * g;
-            store16(dst + E, ok, 1.0f);
-            store16(dst + 2 * E, ov, 1.0f);
         }
     }
 }
 
-template <int KT32>
+template <int KT32, int NW>
 int launch_fwd(const bf16* q, const bf16* k, const bf16* v, bf16* out, int ldo, float* lse, int B, int H, int N,
                hipStream_t s) {
     constexpr int NPAD = 32 * KT32;
     const int bytes = 2 * NPAD * ATT_LDR * 2;
     static bool attr = false;
     if (!attr && bytes > 48 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<KT32>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<KT32, NW>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
             pevit_set_error("attn_fwd: cannot reserve %d bytes of LDS", bytes); return -1;
         }
         attr = true;
     }
-    hipLaunchKernelGGL(attn_fwd_kernel<KT32>, dim3(B * H), dim3(256), bytes, s, q, k, v, out, ldo, lse, H, N);
+    hipLaunchKernelGGL((attn_fwd_kernel<KT32, NW>), dim3(B * H), dim3(64 * NW), bytes, s, q, k, v, out, ldo, lse, H, N);
     LAUNCH_OK("attn_fwd_kernel");
     return 0;
 }
 
-template <int KT32, bool ROWLDS>
+template <int KT32, bool ALL4, int NW>
 int launch_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* out, int ldo, const bf16* dout, int lddo,
                const float* lse, bf16* dqkv, int ld, int B, int H, int N, hipStream_t s) {
     constexpr int NPAD = 32 * KT32;
-    const int bytes = 2 * NPAD * 4 + (ROWLDS ? 4 * NPAD * ATT_LDR * 2 : 3 * 64 * (NPAD + att_tpad(KT32)) * 2);
+    const int bytes = 2 * NPAD * 4 + (ALL4 ? 4 : 2) * NPAD * ATT_LDR * 2;
     static bool attr = false;
     if (!attr && bytes > 48 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<KT32, ROWLDS>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<KT32, ALL4, NW>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
             pevit_set_error("attn_bwd: cannot reserve %d bytes of LDS", bytes); return -1;
         }
         attr = true;
     }
-    hipLaunchKernelGGL((attn_bwd_kernel<KT32, ROWLDS>), dim3(B * H), dim3(256), bytes, s, q, k, v, out, ldo, dout, lddo, lse,
-                       dqkv, ld, H, N, 3);
+    hipLaunchKernelGGL((attn_bwd_kernel<KT32, ALL4, NW>), dim3(B * H), dim3(64 * NW), bytes, s, q, k, v, out, ldo, dout, lddo, lse,
+                       dqkv, ld, H, N);
     LAUNCH_OK("attn_bwd_kernel");
     return 0;
 }
 
 }  // namespace
 
+// waves per workgroup of the large-N variants (one or two workgroups per CU: the 13 / 17 sixteen-row tiles of a head are
+// spread over that many waves)
+#ifndef ATT_NW_BIG
+#define ATT_NW_BIG 16
+#endif
+#ifndef ATT_NW_MID
+#define ATT_NW_MID 8
+#endif
+#ifndef ATT_NW_BIG_F
+#define ATT_NW_BIG_F 8
+#endif
+#ifndef ATT_NW_MID_F
+#define ATT_NW_MID_F 4
+#endif
+
 int pevit_launch_attn_fwd(const bf16* q, const bf16* k, const bf16* v, bf16* out, int ldo, float* lse, int B, int H,
                           int N, hipStream_t s) {
     if (N < 1 || N > 288) { pevit_set_error("attn_fwd: tokens per image N=%d outside [1,288]", N); return -1; }
     if (ldo % 8) { pevit_set_error("attn_fwd: ldo must be a multiple of 8"); return -1; }
-    if (N <= 64) return launch_fwd<2>(q, k, v, out, ldo, lse, B, H, N, s);
-    if (N <= 224) return launch_fwd<7>(q, k, v, out, ldo, lse, B, H, N, s);
-    return launch_fwd<9>(q, k, v, out, ldo, lse, B, H, N, s);
+    if (N <= 64) return launch_fwd<2, 4>(q, k, v, out, ldo, lse, B, H, N, s);
+    if (N <= 224) return launch_fwd<7, ATT_NW_MID_F>(q, k, v, out, ldo, lse, B, H, N, s);
+    return launch_fwd<9, ATT_NW_BIG_F>(q, k, v, out, ldo, lse, B, H, N, s);
 }
 
 int pevit_launch_attn_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* out, int ldo, const bf16* dout,
                           int lddo, const float* lse, bf16* dqkv, int ld, int B, int H, int N, hipStream_t s) {
     if (N < 1 || N > 288) { pevit_set_error("attn_bwd: tokens per image N=%d outside [1,288]", N); return -1; }
     if ((ldo % 8) || (lddo % 8) || (ld % 8)) { pevit_set_error("attn_bwd: leading dims must be multiples of 8"); return -1; }
-    // N <= 64: row-major copies in LDS as well
-    if (N <= 64) return launch_bwd<2, true>(q, k, v, out, ldo, dout, lddo, lse, dqkv, ld, B, H, N, s);
-    if (N <= 224) return launch_bwd<7, false>(q, k, v, out, ldo, dout, lddo, lse, dqkv, ld, B, H, N, s);
-    return launch_bwd<9, false>(q, k, v, out, ldo, dout, lddo, lse, dqkv, ld, B, H, N, s);
+    // N <= 64: all four operands LDS-resident; above, the loop side of each pass
+    if (N <= 64) return launch_bwd<2, true, 4>(q, k, v, out, ldo, dout, lddo, lse, dqkv, ld, B, H, N, s);
+    if (N <= 224) return launch_bwd<7, false, ATT_NW_MID>(q, k, v, out, ldo, dout, lddo, lse, dqkv, ld, B, H, N, s);   // 74 KB: two workgroups per CU
+    return launch_bwd<9, false, ATT_NW_BIG>(q, k, v, out, ldo, dout, lddo, lse, dqkv, ld, B, H, N, s);           // 94 KB: one per CU
 }

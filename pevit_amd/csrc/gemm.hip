@@ -178,8 +178,12 @@ __global__ __launch_bounds__(WGM * WGN * 64, MINW) void gemm_kernel(GemmParams p
         auto k_tile = [&](int kt, auto issue_next) {
             constexpr bool ISSUE = decltype(issue_next)::value;
             constexpr int NG = KS * WM, NP = PA + PB;       // MFMA groups per k-tile, pieces per wave
+#ifdef GEMM_STREAM_FREE   // measurement build only (scripts/build_variants.sh): the stream-only ablation issues without waiting
+            if (!(p.dbg & 8)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
+#else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+#endif
             if constexpr (ISSUE && !SPREAD) issue_tile(kt + 1);
             const char* sa = smem + (kt & 1) * STAGE_BYTES;
             const char* sb = smem + ((BF8 ? (kt >> 1) : kt) & 1) * STAGE_BYTES;

@@ -101,7 +101,10 @@ __device__ __forceinline__ void split_bf16(const float* src, bf16x8& hi, bf16x8&
 // output rows are interleaved, tile 0: e = 8g+r, tile 1: e = 8g+4+r, so that a lane ends up with 8 consecutive e of
 // one row -> one 16-byte read-modify-write); the split Q fragments of a step are loaded once and reused for all
 // DA_RG row groups (they were 2/3 of this kernel's L2 traffic when every 16-row group re-read them).
-constexpr int DA_RG = 4, DA_COLS = 64;
+#ifndef DA_RG_V
+#define DA_RG_V 4
+#endif
+constexpr int DA_RG = DA_RG_V, DA_COLS = 64;
 template <typename ST>
 __global__ __launch_bounds__(256) void delta_add_kernel(bf16* qbuf, bf16* vbuf, const float* __restrict__ t,
                                                         const float* __restrict__ q32, const float* __restrict__ bias,
@@ -190,65 +193,84 @@ __device__ __forceinline__ const bf16* ddelta_slab(const bf16* dqkv, int ld, int
     return dqkv + ((size_t)b * N + n) * ld + col0 + h * 64;
 }
 
-// u = dDelta . Q : block = 16 reference rows, the 4 waves split E; LDS reduction.
-__global__ __launch_bounds__(256) void lowrank_u_kernel(const bf16* __restrict__ dqkv, int ld,
+// u = dDelta . Q : block = 16*LU_RG reference rows, the LU_WAVES waves split E (contraction); LDS reduction.
+// Every wave requests all of its dDelta fragments (HBM) up front; each Q fragment (L2) is used by LU_RG row groups.
+#ifndef LU_RG
+#define LU_RG 2
+#endif
+#ifndef LU_WAVES
+#define LU_WAVES 8
+#endif
+__global__ __launch_bounds__(64 * LU_WAVES) void lowrank_u_kernel(const bf16* __restrict__ dqkv, int ld,
                                                         const bf16* __restrict__ qT, float* __restrict__ u32,
                                                         bf16* __restrict__ ucols, int B, int H, int N, int E) {
-    __shared__ float red[4][4][64][4];
+    __shared__ float red[LU_WAVES][LU_RG][4][64][4];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, g = lane >> 4, c16 = lane & 15;
     const int T = B * N;
-    const int rr0 = blockIdx.x * 16;
-    int rr = rr0 + c16; rr = rr < T ? rr : T - 1;
-    f32x4 acc[4];
+    const int rr0 = blockIdx.x * 16 * LU_RG;
+    int rr[LU_RG];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // a wave's k-steps are s = wid, wid + 4, ...; the dDelta fragments (HBM) of LU_UNROLL steps are requested together,
-    // the Q fragments (L2 hits) follow -- one round trip per LU_UNROLL steps instead of one per step
-    constexpr int LU_UNROLL = 6;
+    for (int k = 0; k < LU_RG; ++k) { rr[k] = rr0 + 16 * k + c16; rr[k] = rr[k] < T ? rr[k] : T - 1; }
+    f32x4 acc[LU_RG][4];
+#pragma unroll
+    for (int k = 0; k < LU_RG; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[k][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int LU_UNROLL = 3;
     const int steps = E / 32;
-    for (int sb = wid; sb < steps; sb += 4 * LU_UNROLL) {
-        bf16x8 aq[LU_UNROLL], av[LU_UNROLL];
+    for (int sb = wid; sb < steps; sb += LU_WAVES * LU_UNROLL) {
+        bf16x8 aq[LU_UNROLL][LU_RG], av[LU_UNROLL][LU_RG];
 #pragma unroll
         for (int i = 0; i < LU_UNROLL; ++i) {
-            const int s = min(sb + 4 * i, steps - 1);
+            const int s = min(sb + LU_WAVES * i, steps - 1);
             const int e0 = (s >> 1) * 64, doff = (s & 1) * 32 + 8 * g;
-            aq[i] = load_bf16x8(ddelta_slab(dqkv, ld, 0, rr, e0, E, H, N) + doff);
-            av[i] = load_bf16x8(ddelta_slab(dqkv, ld, 2 * E, rr, e0, E, H, N) + doff);
+#pragma unroll
+            for (int k = 0; k < LU_RG; ++k) {
+                aq[i][k] = load_bf16x8(ddelta_slab(dqkv, ld, 0, rr[k], e0, E, H, N) + doff);
+                av[i][k] = load_bf16x8(ddelta_slab(dqkv, ld, 2 * E, rr[k], e0, E, H, N) + doff);
+            }
         }
 #pragma unroll
         for (int i = 0; i < LU_UNROLL; ++i) {
-            const int s = sb + 4 * i;
+            const int s = sb + LU_WAVES * i;
             if (s < steps) {
                 const int ke = 32 * s + 8 * g;
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
                     const bf16x8 bq = load_bf16x8(qT + (size_t)(16 * nt + c16) * E + ke);
                     const bf16x8 bv = load_bf16x8(qT + (size_t)(32 + 16 * nt + c16) * E + ke);
-                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[i], bq, acc[nt], 0, 0, 0);
-                    acc[2 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[i], bv, acc[2 + nt], 0, 0, 0);
+#pragma unroll
+                    for (int k = 0; k < LU_RG; ++k) {
+                        acc[k][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[i][k], bq, acc[k][nt], 0, 0, 0);
+                        acc[k][2 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[i][k], bv, acc[k][2 + nt], 0, 0, 0);
+                    }
                 }
             }
         }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) red[wid][i][lane][r] = acc[i][r];
-    __syncthreads();
-    if (wid == 0) {
+    for (int k = 0; k < LU_RG; ++k)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float v = red[0][i][lane][r] + red[1][i][lane][r] + red[2][i][lane][r] + red[3][i][lane][r];
-                const int rro = rr0 + 4 * g + r;
-                if (rro < T) {
-                    const int row = row_of_ref(rro, B, N);
-                    const int col = (i >> 1) * 32 + (i & 1) * 16 + c16;
-                    u32[(size_t)row * 64 + col] = v;
-                    ucols[(size_t)row * ld + col] = f2bf(v);
-                }
+            for (int r = 0; r < 4; ++r) red[wid][k][i][lane][r] = acc[k][i][r];
+    __syncthreads();
+    // wave w sums (row group k, tile i) pairs w, w + LU_WAVES, ... in a fixed order
+    for (int pi = wid; pi < LU_RG * 4; pi += LU_WAVES) {
+        const int k = pi >> 2, i = pi & 3;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < LU_WAVES; ++w) v += red[w][k][i][lane][r];
+            const int rro = rr0 + 16 * k + 4 * g + r;
+            if (rro < T) {
+                const int row = row_of_ref(rro, B, N);
+                const int col = (i >> 1) * 32 + (i & 1) * 16 + c16;
+                u32[(size_t)row * 64 + col] = v;
+                ucols[(size_t)row * ld + col] = f2bf(v);
             }
+        }
     }
 }
 
@@ -265,9 +287,12 @@ __global__ __launch_bounds__(256) void lowrank_u_kernel(const bf16* __restrict__
 // lane group g = token 32ks + 4g + idx (idx < 4) and 32ks + 16 + 4g + idx - 4.  The Y fragments are the same for every
 // slab: they are read once into registers, and the X panel of the next slab is in flight (registers) while the current
 // one is multiplied.  One deterministic partial per chunk goes to HBM.
+#ifndef LG_ES_V
+#define LG_ES_V 2
+#endif
 constexpr int LG_ROWS = 256;
 constexpr int LG_LD = 72;          // row stride (elements) of the LDS tiles: 36 dwords, 8 consecutive rows cover all banks
-constexpr int LG_ES = 2;           // 64-column slabs per workgroup
+constexpr int LG_ES = LG_ES_V;           // 64-column slabs per workgroup
 
 __device__ __forceinline__ bf16x8 lg_trfrag(const bf16* tile, int ks, int col0, int lane) {
     typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
@@ -542,7 +567,7 @@ int pevit_launch_delta_add(bf16* qbuf, bf16* vbuf, const float* t, const float* 
 int pevit_launch_lowrank_u(const bf16* dqkv, int ld, const bf16* qT, float* u32, bf16* u_bf16_cols, int B, int H,
                            int N, int E, hipStream_t s) {
     const int T = B * N;
-    hipLaunchKernelGGL(lowrank_u_kernel, dim3(ceil_div(T, 16)), dim3(256), 0, s, dqkv, ld, qT, u32, u_bf16_cols, B, H,
+    hipLaunchKernelGGL(lowrank_u_kernel, dim3(ceil_div(T, 16 * LU_RG)), dim3(64 * LU_WAVES), 0, s, dqkv, ld, qT, u32, u_bf16_cols, B, H,
                        N, E);
     LAUNCH_OK("lowrank_u_kernel");
     return 0;
