@@ -210,9 +210,17 @@ int pevit_op_im2col(void* stream, const float* images, void* patches_bf16, int B
  * configuration: 128x128, 64x128, 64x64 with 4 waves; 256x128, 256x256, 320x256 with 8 waves; 6 = 128x64 with 4 waves),
  * "gemm_persistent", "gemm_big" (0 = never pick the 8-wave tiles), "gemm_big_bias", "gemm_kswitch", "gemm_cfg_longk" /
  * "gemm_cfg_shortk" (configuration of the few-tile problems above / below kswitch), "gemm_ablate" (bit 0 skips the
- * k-loop, bit 1 the epilogue stores, bit 2 the operand stream, bit 3 ds_read + MFMA), "side_stream" (ctx only);
+ * k-loop, bit 1 the epilogue stores, bit 2 the operand stream, bit 3 ds_read + MFMA), "side_stream" (ctx only),
+ * "gemm_streamk" (0 = never use the stream-K decomposition of the few-tile long-K products);
  * returns 0, or -1 for an unknown key */
 int pevit_tune(pevit_ctx* ctx, const char* key, int value);
+
+/* Stream-K GEMMs hand partial tiles from workgroup to workgroup inside one launch; a consumer that waits ~1 s for a
+ * partial gives up (the tile is then wrong) and raises an error word instead of hanging the GPU.  Synchronises the
+ * stream, returns 1 if that ever happened on this context's workspace (ctx NULL: the workspace of the pevit_op_*
+ * entry points) and clears the word, 0 otherwise, -1 on a HIP error.  The reference has no counterpart (its GEMMs are
+ * ATen calls, model.py:675,817); the engine checks it after the first step. */
+int pevit_streamk_error(pevit_ctx* ctx, void* stream);
 
 #ifdef __cplusplus
 }

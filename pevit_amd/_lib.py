@@ -80,6 +80,7 @@ SIGNATURES = {
     "pevit_op_chain_bottleneck": (c_int, [P, c_int, P, P, P, P, P, c_int, c_size_t, c_size_t, c_size_t, c_size_t]),
     "pevit_op_im2col": (c_int, [P, P, P, c_int, c_int, c_int, c_int]),
     "pevit_tune": (c_int, [P, c_char_p, c_int]),
+    "pevit_streamk_error": (c_int, [P, P]),
 }
 
 _lib = None

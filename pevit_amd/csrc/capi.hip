@@ -70,6 +70,7 @@ struct pevit_ctx {
     char* arena = nullptr;
     // workspace
     LayerSaved* sav = nullptr;
+    size_t w_skflag = 0, w_skslab = 0; int sk_slots = 0;   // stream-K workspace (gemm.hip), sk_slots = 0: disabled
     size_t w_xfinal, w_xn2, w_g, w_dqkv, w_u32, w_dO, w_dh, w_dxn, w_dxa, w_dxb, w_dyb, w_partial, w_dbias;
     size_t w_G, w_rule, partial_layer, dbias_layer;
     size_t w_dpre, w_dht, w_dhb, w_tnU, w_tnD, w_csx, w_csy, w_lnp, w_Gd, w_Gu, tn_layer, csx_layer, csy_layer, lnp_layer;
@@ -115,6 +116,10 @@ inline bool post_mlp(const pevit_ctx* c) { return c->d.method == PEVIT_ADAPTER |
 void layout_workspace(pevit_ctx* c, int B, LayerSaved* sav, size_t* total, pevit_ctx* fill) {
     Carver cv;
     const size_t T = (size_t)B * c->N, E = c->E, es = c->es;
+    size_t o;
+    // stream-K hand-off flags (+1 error word) and partial-tile slabs: first, so that their place does not depend on the batch
+    o = cv.take((size_t)(PEVIT_SK_MAX_SLOTS + 1) * 4);                        if (fill) fill->w_skflag = o;
+    o = cv.take((size_t)c->sk_slots * PEVIT_SK_SLAB_FLOATS * 4);              if (fill) fill->w_skslab = o;
     for (int l = 0; l < c->L; ++l) {
         LayerSaved s;
         s.x_in = cv.take(T * E * 4);
@@ -135,7 +140,6 @@ void layout_workspace(pevit_ctx* c, int B, LayerSaved* sav, size_t* total, pevit
         if (sav) sav[l] = s;
     }
     const int chunks = pevit_lowrank_chunks((int)T);
-    size_t o;
     o = cv.take(T * E * 4);                 if (fill) fill->w_xfinal = o;
     o = cv.take(T * E * es);                 if (fill) fill->w_xn2 = o;
     o = cv.take(T * 4 * E * es);             if (fill) fill->w_g = o;
@@ -229,6 +233,7 @@ extern "C" int pevit_ctx_create(const pevit_dims* dims, pevit_ctx** out) {
     c->fp8 = d.weight_format == PEVIT_W_FP8_E4M3;
     c->f32 = d.weight_format == PEVIT_W_F32_VERIFY;
     c->es = c->f32 ? 4 : 2;
+    c->sk_slots = c->f32 ? 0 : pevit_gemm_sk_slots();
     if (c->N > 288) { pevit_set_error("ctx_create: %d tokens per image exceeds 288", c->N); delete c; return -1; }
 
     // ---- weight arena -------------------------------------------------------------
@@ -349,6 +354,8 @@ extern "C" int pevit_bind(pevit_ctx* c, void* arena, size_t arena_bytes, void* w
     if (ws_bytes < need) { pevit_set_error("bind: workspace too small (%zu < %zu)", ws_bytes, need); return -1; }
     if (((uintptr_t)arena | (uintptr_t)ws) & 255) { pevit_set_error("bind: buffers must be 256-byte aligned"); return -1; }
     c->arena = (char*)arena; c->ws = (char*)ws; c->max_batch = max_batch; c->ws_bytes_for_max = need;
+    // the stream-K flags must read 0 before the first launch (every launch leaves them 0 again)
+    HIP_OK(hipMemset(c->ws, 0, (size_t)(PEVIT_SK_MAX_SLOTS + 1) * 4));
     return 0;
 }
 
@@ -390,8 +397,9 @@ extern "C" int pevit_load_block(pevit_ctx* c, void* stream, int l, const float* 
         CHECK(pevit_launch_quant_transpose_fp8(pr_w, e, 4 * e, at<float>(A, b.spr), at<u8>(A, b.wprT), e, 0, 1.0f, s));
         // QKV backward (bf16): the transposed copy holds the DE-QUANTISED weights, exactly representable in bf16
         HIP_OK(hipMemsetAsync(A + b.wqkvT, 0, E * (size_t)c->NQ * 2, s));
-        float* tmp = at<float>(c->ws, 0);       // 3E*E floats of the (not yet used) workspace
-        if ((size_t)3 * E * E * 4 > c->ws_bytes_for_max) { pevit_set_error("load_block: workspace too small for the fp8 packing scratch"); return -1; }
+        const size_t skip = align_up((size_t)(PEVIT_SK_MAX_SLOTS + 1) * 4, 256);    // the stream-K flags stay zero
+        float* tmp = at<float>(c->ws, skip);    // 3E*E floats of the (not yet used) workspace
+        if (skip + (size_t)3 * E * E * 4 > c->ws_bytes_for_max) { pevit_set_error("load_block: workspace too small for the fp8 packing scratch"); return -1; }
         CHECK(pevit_launch_dequant_rows_fp8(at<u8>(A, b.wqkv), e, at<float>(A, b.sqkv), 3 * e, e, tmp, s));
         CHECK(pevit_launch_transpose_bf16(tmp, 3 * e, e, at<bf16>(A, b.wqkvT), c->NQ, 0, 1.0f, s));
     } else {
@@ -473,7 +481,11 @@ int prep_adapters(pevit_ctx* c, hipStream_t s) {
 }
 
 // every GEMM of the step goes through here so that it can be bracketed with HIP events
-int gemm(pevit_ctx* c, int epi, const GemmParams& p, hipStream_t s) {
+int gemm(pevit_ctx* c, int epi, const GemmParams& p_in, hipStream_t s) {
+    GemmParams p = p_in;
+    if (c->sk_slots && c->ws) {
+        p.sk_flag = at<unsigned>(c->ws, c->w_skflag); p.sk_slab = at<float>(c->ws, c->w_skslab); p.sk_slots = c->sk_slots;
+    }
     const bool rec = c->prof_on && c->prof_n < c->prof_cap;
     if (rec) (void)hipEventRecord(c->prof_ev[2 * c->prof_n], s);
     const int rc = c->f32 ? pevit_launch_gemm_f32(epi, p, s) : pevit_launch_gemm(epi, p, c->tune, s);
@@ -1025,6 +1037,19 @@ extern "C" int pevit_profile_end(pevit_ctx* c, double* total_ms, double* total_f
 
 // ------------------------------------------------------------------------------------
 // single-kernel entry points (parity tests, profiling)
+// stream-K workspace of the context-free entry point (tests / microbenchmarks): allocated on first use
+static int op_sk_workspace(GemmParams& p) {
+    static char* ws = nullptr;
+    const int slots = pevit_gemm_sk_slots();
+    const size_t flag_bytes = align_up((size_t)(PEVIT_SK_MAX_SLOTS + 1) * 4, 256);
+    if (!ws) {
+        HIP_OK(hipMalloc((void**)&ws, flag_bytes + (size_t)slots * PEVIT_SK_SLAB_FLOATS * 4));
+        HIP_OK(hipMemset(ws, 0, flag_bytes));
+    }
+    p.sk_flag = reinterpret_cast<unsigned*>(ws); p.sk_slab = reinterpret_cast<float*>(ws + flag_bytes); p.sk_slots = slots;
+    return 0;
+}
+
 extern "C" int pevit_op_gemm(void* stream, int epi, const void* A, int lda, const void* Bm, int ldb, int b_rows, int M,
                              int N, int K, const float* bias, const float* resid, int ldr, float* outf, int ldo,
                              void* outb, int ldob, void* outb2, int ldob2, const void* aux, int ldaux,
@@ -1033,7 +1058,20 @@ extern "C" int pevit_op_gemm(void* stream, int epi, const void* A, int lda, cons
     p.bias = bias; p.resid = resid; p.ldr = ldr; p.outf = outf; p.ldo = ldo; p.outb = (bf16*)outb; p.ldob = ldob;
     p.outb2 = (bf16*)outb2; p.ldob2 = ldob2; p.aux = (const bf16*)aux; p.ldaux = ldaux; p.head_stride = head_stride;
     p.E = E; p.H = H; p.Ntok = tokens;
+    if (g_default_tune.streamk) CHECK(op_sk_workspace(p));
     return pevit_launch_gemm(epi, p, g_default_tune, (hipStream_t)stream);
+}
+// 1 if a stream-K consumer ever gave up waiting for a partial tile (context-free workspace when ctx is null); clears it
+extern "C" int pevit_streamk_error(pevit_ctx* c, void* stream) {
+    GemmParams p; memset(&p, 0, sizeof(p));
+    unsigned* flag = nullptr;
+    if (c) { if (!c->ws || !c->sk_slots) return 0; flag = at<unsigned>(c->ws, c->w_skflag) + c->sk_slots; }
+    else { if (op_sk_workspace(p)) return -1; flag = p.sk_flag + p.sk_slots; }
+    unsigned v = 0;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return -1;
+    if (hipMemcpy(&v, flag, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (v) (void)hipMemset(flag, 0, 4);
+    return v ? 1 : 0;
 }
 extern "C" int pevit_op_gemm_fp8(void* stream, int epi, const void* A, int lda, const void* Bcodes, int ldb, int b_rows,
                                  const float* bscale, const float* oscale, int M, int N, int K, const float* bias,
@@ -1150,6 +1188,8 @@ extern "C" int pevit_tune(pevit_ctx* c, const char* key, int value) {
     if (key && !strcmp(key, "gemm_cfg_shortk")) { t.cfg_shortk = value; return 0; }
     if (key && !strcmp(key, "gemm_big_bias")) { t.big_bias = value; return 0; }
     if (key && c && !strcmp(key, "side_stream")) { c->side_stream = value; return 0; }
+    if (key && !strcmp(key, "gemm_streamk")) { t.streamk = value; return 0; }
+    if (key && !strcmp(key, "gemm_sk_share")) { t.sk_share = value; return 0; }
     if (key && c && !strcmp(key, "dx_stored")) { c->dx_stored = value; return 0; }
     pevit_set_error("tune: unknown key %s", key ? key : "(null)");
     return -1;

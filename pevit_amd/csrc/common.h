@@ -72,6 +72,20 @@ template <typename ST> __device__ __forceinline__ void st_store4(bf16* base, siz
     }
 }
 
+// 8 consecutive elements: one 16-byte store in bf16 storage (off must be a multiple of 8), two in f32 storage
+template <typename ST> __device__ __forceinline__ void st_store8(bf16* base, size_t off, const float (&v)[8]) {
+    if constexpr (sizeof(ST) == 2) {
+        bf16x8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = f2bf(v[i]);
+        *reinterpret_cast<bf16x8*>(base + off) = o;
+    } else {
+        float* f = reinterpret_cast<float*>(base) + off;
+        *reinterpret_cast<float4*>(f) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(f + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+}
+
 // Asynchronous global -> LDS copy, 16 bytes per lane.  The LDS destination is
 // wave-uniform: the hardware writes lane l's 16 bytes at lds_wave_base + 16*l.
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {

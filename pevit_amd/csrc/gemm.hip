@@ -41,6 +41,13 @@
 
 namespace {
 
+// measurement bits of GemmParams::dbg; -DGEMM_NO_DBG compiles them out
+#ifdef GEMM_NO_DBG
+#define GEMM_DBG(p, bit) false
+#else
+#define GEMM_DBG(p, bit) ((p).dbg & (bit))
+#endif
+
 constexpr int TILE_BAND = 6;
 
 int num_cus() {
@@ -133,7 +140,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, MINW) void gemm_kernel(GemmParams p
     // k-tile kt of A (and of a bf16 B) -> stage kt&1.  fp8 B: rows of 128 codes = k-tiles 2j, 2j+1 -> B stage j&1,
     // requested together with the even k-tile of A.  Piece q of this wave: q < PA -> A, else B.
     auto issue_piece = [&](int kt, int q) {
-        if (p.dbg & 4) return;                              // measurement only: no operand stream
+        if (GEMM_DBG(p, 4)) return;                              // measurement only: no operand stream
         if (q < PA) {
             glds16(a_src[q] + kt * 128, smem + (kt & 1) * STAGE_BYTES + (wid * PA + q) * 1024);
         } else if constexpr (BF8) {
@@ -155,7 +162,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, MINW) void gemm_kernel(GemmParams p
 #pragma unroll
     for (int j = 0; j < WN; ++j) b_off[j] = A_BYTES + (wn * WN * 32 + j * 32 + frow) * ROWB;
 
-    const int nk = (p.dbg & 1) ? 0 : p.K / BK;
+    const int nk = GEMM_DBG(p, 1) ? 0 : p.K / BK;
     int tile = blockIdx.x;
     int m0, n0;
     tile_origin<BM, BN>(p, tile, m0, n0);
@@ -179,7 +186,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, MINW) void gemm_kernel(GemmParams p
             constexpr bool ISSUE = decltype(issue_next)::value;
             constexpr int NG = KS * WM, NP = PA + PB;       // MFMA groups per k-tile, pieces per wave
 #ifdef GEMM_STREAM_FREE   // measurement build only (scripts/build_variants.sh): the stream-only ablation issues without waiting
-            if (!(p.dbg & 8)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
+            if (!GEMM_DBG(p, 8)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
 #else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -187,7 +194,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, MINW) void gemm_kernel(GemmParams p
             if constexpr (ISSUE && !SPREAD) issue_tile(kt + 1);
             const char* sa = smem + (kt & 1) * STAGE_BYTES;
             const char* sb = smem + ((BF8 ? (kt >> 1) : kt) & 1) * STAGE_BYTES;
-            if (p.dbg & 8) {                                // measurement only: operand stream without ds_read / MFMA
+            if (GEMM_DBG(p, 8)) {                                // measurement only: operand stream without ds_read / MFMA
                 if constexpr (ISSUE) issue_tile(kt + 1);
                 return;
             }
@@ -341,7 +348,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, MINW) void gemm_kernel(GemmParams p
                     const int col = cn0 + wn * WN * 32 + j * 32 + lc;
                     const float4 x0 = *reinterpret_cast<const float4*>(cw + lr * 32 + lc);
                     const float4 x1 = *reinterpret_cast<const float4*>(cw + lr * 32 + lc + 4);
-                    if (row < p.M && col < p.N && !(p.dbg & 2)) {
+                    if (row < p.M && col < p.N && !GEMM_DBG(p, 2)) {
                         float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
                         if constexpr (BF8) { if (p.bscale) mul8(v, p.bscale + col); }
                         epilogue_store<EPI, bf16>(p, row, col, v);
@@ -352,6 +359,217 @@ __global__ __launch_bounds__(WGM * WGN * 64, MINW) void gemm_kernel(GemmParams p
             }
         if (next >= ntiles) break;
         tile = next;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Stream-K form of the 128x128 tile (4 waves, 2 workgroups per CU, bf16 B) for the few-tile long-K products: at ViT-B/32,
+// B = 128 the N = E products have 300 tiles for 512 residency slots, so 44 CUs stream two whole tiles while 212 stream one,
+// and the kernel takes as long as the 44 (54 us; a problem whose 512 tiles carry 28 k-iterations each, the same work per
+// slot, takes 33 us -- scripts/gpu_streamk_bound.py).  Here the tiles x k-iterations space is cut into gridDim.x equal
+// ranges, one per resident workgroup, walked in increasing order.  A range that starts inside a tile (k0 > 0) computes that
+// tile's tail FIRST and publishes the partial accumulators (one f32 slab per workgroup); the workgroup that holds the
+// tile's first iterations has them LAST in its own range, so by the time it has finished and polls, the partials it needs
+// were published long ago: no dependency chains, no stalls beyond the hand-off itself.  It adds the slabs in ascending
+// order (a fixed order: results are deterministic), runs the epilogue and clears the flags for the next launch.
+//
+// Hand-off (MI355X_MICROARCH.md, inter-workgroup visibility): write-through (sc1) 16-byte slab stores -> every wave drains
+// vmcnt -> barrier -> relaxed agent-scope flag store; consumer: relaxed agent-scope poll by one lane (bounded: a lost
+// producer turns into a wrong tile and a raised sk_flag[slots] error word, never into a hang) -> agent acquire -> barrier ->
+// plain loads.  All gridDim.x workgroups must be resident at once: the launcher sizes the grid to the 2-per-CU residency.
+__device__ __forceinline__ void sk_tile_origin(const GemmParams& p, int t, int& m0, int& n0) {
+    const int tiles_n = (p.N + 127) / 128, tiles_m = (p.M + 127) / 128;
+    const int band = t / (TILE_BAND * tiles_n), within = t - band * (TILE_BAND * tiles_n);
+    const int mb = min(TILE_BAND, tiles_m - band * TILE_BAND);
+    const int tn = within / mb, tm = band * TILE_BAND + (within - tn * mb);
+    m0 = tm * 128; n0 = tn * 128;
+}
+
+__device__ __forceinline__ void sk_store16_sc1(float* dst, f32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_streamk_kernel(GemmParams p, int ntiles) {
+    constexpr int NW = 4, WGN = 2, WM = 2, WN = 2, BM = 128, BN = 128, BK = 64;
+    constexpr int ROWB = 128, CH = 8, RPP = 8;
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int PA = BM / RPP / NW, PB = BN / RPP / NW, KS = BK / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wid / WGN, wn = wid % WGN;
+    const char* a_src[PA];
+    const char* b_src[PB];
+    auto set_sources = [&](int m0, int n0) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int row = (wid * PA + i) * RPP + lane / CH;
+            const int chunk = (lane % CH) ^ ((row >> 1) & (CH - 1));
+            int ar = m0 + row; ar = ar < p.M ? ar : p.M - 1;
+            a_src[i] = reinterpret_cast<const char*>(p.A + (size_t)ar * p.lda) + chunk * 16;
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const int row = (wid * PB + i) * RPP + lane / CH;
+            const int chunk = (lane % CH) ^ ((row >> 1) & (CH - 1));
+            int br = n0 + row; br = br < p.Nb ? br : p.Nb - 1;
+            b_src[i] = reinterpret_cast<const char*>(p.B) + (size_t)br * p.ldb * 2 + chunk * 16;
+        }
+    };
+    auto issue_tile = [&](int kt, int st) {      // k-tile kt -> LDS stage st
+#pragma unroll
+        for (int q = 0; q < PA; ++q) glds16(a_src[q] + kt * 128, smem + st * STAGE_BYTES + (wid * PA + q) * 1024);
+#pragma unroll
+        for (int q = 0; q < PB; ++q) glds16(b_src[q] + kt * 128, smem + st * STAGE_BYTES + A_BYTES + (wid * PB + q) * 1024);
+    };
+    const int frow = lane & 31, fswz = (frow >> 1) & (CH - 1), fhalf = lane >> 5;
+    int a_off[WM], b_off[WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) a_off[i] = (wm * WM * 32 + i * 32 + frow) * ROWB;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) b_off[j] = A_BYTES + (wn * WN * 32 + j * 32 + frow) * ROWB;
+
+    const int nk = p.K / BK;
+    const int slots = gridDim.x;
+    // block b runs on XCD b % 8: position = XCD-major, so that an XCD's workgroups walk consecutive tiles
+    const int pos = (blockIdx.x & 7) * (slots >> 3) + (blockIdx.x >> 3);
+    const long long total = (long long)ntiles * nk;
+    auto range_start = [&](int q) -> long long { return min(total, (long long)q * p.sk_share); };
+    long long it = range_start(pos);
+    const long long it_end = range_start(pos + 1);
+    if (it >= it_end) return;
+    int tile = (int)(it / nk), k0 = (int)(it - (long long)tile * nk);
+    int m0, n0;
+    sk_tile_origin(p, tile, m0, n0);
+    set_sources(m0, n0);
+    issue_tile(k0, 0);
+    while (true) {
+        const int k1 = (int)min((long long)nk, k0 + (it_end - it));     // this segment: k-tiles [k0, k1) of `tile`
+        f32x16 acc[WM][WN];
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        for (int kt = k0; kt < k1; ++kt) {
+            const int st = (kt - k0) & 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (kt + 1 < k1) issue_tile(kt + 1, st ^ 1);
+            const char* sa = smem + st * STAGE_BYTES;
+            bf16x8 af[KS][WM], bfr[KS][WN];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int coff = (((ks * 2 + fhalf) ^ fswz) << 4);
+#pragma unroll
+                for (int i = 0; i < WM; ++i) af[ks][i] = *reinterpret_cast<const bf16x8*>(sa + a_off[i] + coff);
+#pragma unroll
+                for (int j = 0; j < WN; ++j) bfr[ks][j] = *reinterpret_cast<const bf16x8*>(sa + b_off[j] + coff);
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();                                   // both stages idle
+        it += k1 - k0;
+        const int ctile = tile, ck0 = k0, cm0 = m0, cn0 = n0;
+        const bool more = it < it_end;
+        if (more) {                                        // the rest of the range starts the next tile at k = 0
+            tile = ctile + 1; k0 = 0;
+            sk_tile_origin(p, tile, m0, n0);
+            set_sources(m0, n0);
+            issue_tile(0, 0);                              // lands in stage 0 while stage 1 serves the epilogue
+        }
+        if (ck0 > 0) {
+            // ---- tail of a tile another workgroup started: publish the partial accumulators
+            if (p.dbg & 16) { if (!more) break; continue; }   // measurement only: no hand-off
+            float* slab = p.sk_slab + (size_t)pos * (BM * BN);
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                        sk_store16_sc1(slab + ((((wid * 4 + i * 2 + j) * 4 + q) * 64 + lane) << 2), v);
+                    }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_store(p.sk_flag + pos, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (k1 < nk && !(p.dbg & 16)) {
+                // ---- head of a tile: the workgroups pos+1, ... computed the rest, early in their ranges
+                const long long tile_end = (long long)(ctile + 1) * nk;
+                int np = 0;
+                while (pos + 1 + np < slots && range_start(pos + 1 + np) < tile_end) ++np;
+                if (threadIdx.x == 0) {
+                    for (int pp = pos + 1; pp <= pos + np; ++pp) {
+                        unsigned spins = 0;
+                        while (__hip_atomic_load(p.sk_flag + pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u) {
+                            __builtin_amdgcn_s_sleep(8);
+                            if (++spins > (1u << 20)) {   // ~1 s: give up loudly instead of hanging the GPU
+                                __hip_atomic_store(p.sk_flag + p.sk_slots, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                break;
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                }
+                __syncthreads();
+                for (int pp = pos + 1; pp <= pos + np; ++pp) {
+                    const float* slab = p.sk_slab + (size_t)pp * (BM * BN);
+#pragma unroll
+                    for (int i = 0; i < WM; ++i)
+#pragma unroll
+                        for (int j = 0; j < WN; ++j)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const f32x4 v = *reinterpret_cast<const f32x4*>(slab + ((((wid * 4 + i * 2 + j) * 4 + q) * 64 + lane) << 2));
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) acc[i][j][4 * q + r] += v[r];
+                            }
+                }
+                __syncthreads();
+                if (threadIdx.x == 0)
+                    for (int pp = pos + 1; pp <= pos + np; ++pp)
+                        __hip_atomic_store(p.sk_flag + pp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            float* cw = reinterpret_cast<float*>(smem + STAGE_BYTES + wid * 4096);
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        cw[row * 32 + (lane & 31)] = acc[i][j][r];
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                    for (int pass = 0; pass < 2; ++pass) {
+                        const int lr = pass * 16 + (lane >> 2);
+                        const int lc = (lane & 3) * 8;
+                        const int row = cm0 + wm * WM * 32 + i * 32 + lr;
+                        const int col = cn0 + wn * WN * 32 + j * 32 + lc;
+                        const float4 x0 = *reinterpret_cast<const float4*>(cw + lr * 32 + lc);
+                        const float4 x1 = *reinterpret_cast<const float4*>(cw + lr * 32 + lc + 4);
+                        if (row < p.M && col < p.N) {
+                            float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                            epilogue_store<EPI, bf16>(p, row, col, v);
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+        }
+        if (!more) break;
     }
 }
 
@@ -444,9 +662,65 @@ int pick_config(const GemmParams& p, const GemmTune& t) {
     return (p.K >= t.kswitch && t128 <= 2L * cus) ? t.cfg_longk : t.cfg_shortk;
 }
 
+// Stream-K share (k-iterations per workgroup) of a few-tile problem, 0 = keep the plain tiling.  Measured on the N = 768
+// products of ViT-B/32 (scripts/gpu_streamk_sweep.py, profiles/r02_gemm_experiments.md section 13): the k-loops only get
+// faster when workgroups that share an A panel -- TILE_BAND tiles = TILE_BAND * nk iterations apart in the walk -- stay in
+// PHASE (same k at the same time), i.e. when the share divides TILE_BAND * nk: otherwise every workgroup streams its own
+// k-slices through the XCD's 4 MiB L2 and the kernel becomes fabric-bound (63-75 us against 54 plain).  A share of at
+// least nk / 2 keeps the hand-offs at one partial per tile.  K = 3072: share 32 (450 workgroups), 54.8 -> 43.0 us.
+int sk_pick_share(long tiles, int nk, int slots) {
+    const long total = tiles * nk;
+    const int lo = (int)max((total + slots - 1) / slots, (long)(nk + 1) / 2);
+    for (int s = lo; 4 * s <= 3 * nk; ++s)
+        if ((TILE_BAND * nk) % s == 0) return s;
+    return 0;
+}
+
+// stream-K applies where the heuristic would take the 128x128 tile for a problem with fewer tiles than residency slots
+// (the long-K, N = E products), bf16 B, the three epilogues those products use
+int streamk_share(const GemmParams& p, const GemmTune& t, int cfg) {
+    if (!t.streamk || !p.sk_slab || !p.sk_flag || !t.persistent) return 0;
+    const long tiles = (long)ceil_div(p.M, 128) * ceil_div(p.N, 128);
+    const int slots = min(pevit_gemm_sk_slots(), p.sk_slots);
+    const int nk = p.K / 64;
+    if (slots < 8) return 0;
+    if (t.streamk == 2) return (t.sk_share && tiles * nk / t.sk_share <= slots) ? t.sk_share : 0;   // measurement only
+    if (t.config >= 0 || cfg != 0 || t.ablate || tiles >= slots || nk < 16) return 0;
+    const int s = sk_pick_share(tiles, nk, slots);
+    if (s) return s;
+    return t.streamk == 3 ? nk : 0;          // 3: the whole-tile walk through this kernel as well (measurement)
+}
+
+template <int EPI>
+int launch_streamk(const GemmParams& p_in, int share, hipStream_t stream) {
+    constexpr int lds = 2 * (128 + 128) * 128;
+    auto kern = gemm_streamk_kernel<EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+            pevit_set_error("hipFuncSetAttribute(stream-K gemm epi %d) failed", EPI);
+            return -1;
+        }
+        attr_set = true;
+    }
+    GemmParams p = p_in;
+    p.sk_share = share;
+    const int tiles = ceil_div(p.M, 128) * ceil_div(p.N, 128);
+    // every workgroup must be resident: the grid never exceeds the 2-per-CU slots (streamk_share checked that)
+    const int grid = (int)(((long)tiles * (p.K / 64) + share - 1) / share + 7) & ~7;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p, tiles);
+    LAUNCH_OK("gemm (stream-K)");
+    return 0;
+}
+
 template <int EPI, bool BF8>
 int launch_epi(const GemmParams& p, const GemmTune& t, hipStream_t stream) {
-    switch (pick_config(p, t)) {
+    const int cfg = pick_config(p, t);
+    if constexpr (!BF8 && (EPI == EPI_BIAS_RESID_F32 || EPI == EPI_F32 || EPI == EPI_BF16)) {
+        const int share = streamk_share(p, t, cfg);
+        if (share) return launch_streamk<EPI>(p, share, stream);
+    }
+    switch (cfg) {
         case 0: return launch_cfg<EPI, 0, BF8>(p, t, stream);
         case 1: return launch_cfg<EPI, 1, BF8>(p, t, stream);
         case 2: return launch_cfg<EPI, 2, BF8>(p, t, stream);
@@ -460,6 +734,8 @@ int launch_epi(const GemmParams& p, const GemmTune& t, hipStream_t stream) {
 }
 
 }  // namespace
+
+int pevit_gemm_sk_slots() { return min(2 * num_cus(), PEVIT_SK_MAX_SLOTS) & ~7; }
 
 int pevit_launch_gemm(int epi, const GemmParams& p_in, const GemmTune& t, hipStream_t stream) {
     GemmParams p = p_in;

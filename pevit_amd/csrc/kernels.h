@@ -36,6 +36,8 @@ struct GemmParams {
     size_t head_stride;   // elements between the q, k and v planes
     int E, H, Ntok;
     int dbg;              // measurement only: bit 0 skips the k-loop, bit 1 the epilogue stores, bit 2 the operand stream, bit 3 ds_read + MFMA
+    // stream-K workspace (gemm.hip gemm_streamk_kernel): one 128x128 f32 slab and one flag per residency slot, or null
+    float* sk_slab; unsigned* sk_flag; int sk_slots; int sk_share;   // sk_share: k-iterations per workgroup (0: total / grid)
 };
 
 // A/B-measurement knobs.  They live in the context (pevit_tune(ctx, ...)); the single-kernel pevit_op_* entry
@@ -48,7 +50,12 @@ struct GemmTune {
     int big = 1;          // allow the 8-wave tiles
     int cfg_longk = 0, cfg_shortk = 1;   // tile configuration of the few-tile problems (N = 768 at M = 6400): K >= kswitch / K < kswitch
     int big_bias = 100;   // the 8-wave tile is taken when its stream cost is below big_bias % of the 128x128 tiling's
+    int sk_share = 0;     // measurement: k-iterations per stream-K workgroup (0 = equal split over the residency slots)
+    int streamk = 1;      // few-tile long-K problems: stream-K decomposition of the 128x128 tiling (needs GemmParams::sk_slab)
 };
+constexpr int PEVIT_SK_SLAB_FLOATS = 128 * 128;   // one partial tile per residency slot
+constexpr int PEVIT_SK_MAX_SLOTS = 1024;
+int pevit_gemm_sk_slots();                         // residency slots of the stream-K kernel on this device (2 per CU, multiple of 8)
 
 int pevit_launch_gemm(int epi, const GemmParams& p, const GemmTune& t, hipStream_t stream);
 

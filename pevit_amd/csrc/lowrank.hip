@@ -176,8 +176,7 @@ __global__ __launch_bounds__(256) void delta_add_kernel(bf16* qbuf, bf16* vbuf, 
                 o[4 + r] = (float)cur[st][k][4 + r] + ascale * a1[r] + bb[4 + r];
             }
             if (rok[k]) {
-                st_store4<ST>(base, boff[k] + eb + 8 * g, o[0], o[1], o[2], o[3]);
-                st_store4<ST>(base, boff[k] + eb + 8 * g + 4, o[4], o[5], o[6], o[7]);
+                st_store8<ST>(base, boff[k] + eb + 8 * g, o);
             }
         }
     }

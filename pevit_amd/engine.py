@@ -285,7 +285,17 @@ class HipEngine:
         flags = int(self._steps == 0) | (2 if nesterov else 0)
         _lib.check(self.lib.pevit_sgd_step(self._ctx, _lib.stream_ptr(), lr, momentum, weight_decay, grad_scale, flags),
                    "pevit_sgd_step")
+        if self._steps == 0:
+            self.check_streamk()          # once, on the first step (synchronises the stream)
         self._steps += 1
+
+    def check_streamk(self):
+        """Stream-K GEMMs hand partial tiles between workgroups inside one launch; a consumer that never saw its
+        producer gives up after ~1 s and raises an error word instead of hanging.  Fails loudly if that happened."""
+        rc = self.lib.pevit_streamk_error(self._ctx, _lib.stream_ptr())
+        if rc != 0:
+            raise _lib.PevitError("stream-K GEMM hand-off timed out (results of that step are invalid)" if rc > 0
+                                  else "pevit_streamk_error failed")
 
     def profile_gemms(self, fn, max_launches=4096):
         """Run ``fn()`` with HIP events around every GEMM launch; returns (ms, flops, launches); the algorithmic

@@ -93,6 +93,49 @@ def test_gemm_every_tile_config_is_bit_identical(lib, cfg, M, N, K):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("M,N,K", [(6400, 768, 3072), (6400, 768, 2368 + 0), (2500, 768, 3072), (6333, 760, 2048), (8224, 1024, 1024)])
+def test_gemm_streamk_hand_off(lib, M, N, K):
+    """Few-tile long-K products run as stream-K: the tiles x k-iterations space is cut into one range per resident
+    workgroup and tiles that span ranges are completed through partial slabs in HBM.  Checked against the torch
+    product, against the plain tiling (different summation split: close, not equal), for run-to-run bit identity, and
+    repeatedly with other kernels in flight and warm caches (stale hand-offs show up only under uneven load)."""
+    K = K // 64 * 64
+    A = rnd(M, K, seed=1, dtype=torch.bfloat16)
+    B = rnd((N + 255) // 256 * 256, K, seed=2, scale=0.05, dtype=torch.bfloat16)
+    bias = rnd(N, seed=5, scale=0.1)
+    resid = rnd(M, N, seed=6)
+    ref = A.float() @ B[:N].float().T
+    filler = torch.randn(4096, 4096, device="cuda")
+
+    def run():
+        o1 = torch.full((M, N), float("nan"), device="cuda")
+        gemm(lib, EPI["BIAS_RESID"], A, B, M, N, K, bias=bias, resid=resid, outf=o1, b_rows=B.shape[0])
+        o2 = torch.full((M, N), float("nan"), device="cuda")
+        gemm(lib, EPI["F32"], A, B, M, N, K, outf=o2, b_rows=B.shape[0])
+        o3 = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
+        gemm(lib, EPI["BF16"], A, B, M, N, K, outb=o3, b_rows=B.shape[0])
+        return o1, o2, o3
+
+    sk = run()
+    assert lib.pevit_streamk_error(None, S()) == 0
+    assert max_rel(sk[0].cpu(), (ref + bias + resid).cpu()) < 2e-4
+    assert max_rel(sk[1].cpu(), ref.cpu()) < 2e-4
+    assert max_rel(sk[2].float().cpu(), ref.cpu()) < 1e-2
+    assert lib.pevit_tune(None, b"gemm_streamk", 0) == 0
+    try:
+        plain = run()
+    finally:
+        lib.pevit_tune(None, b"gemm_streamk", 1)
+    assert max_rel(sk[1].cpu(), plain[1].cpu()) < 2e-5
+    for it in range(12):
+        if it % 3 == 0:
+            (filler @ filler).sum()            # other work in flight, caches disturbed
+        again = run()
+        for a, b in zip(sk, again):
+            assert torch.equal(a, b), f"stream-K result changed on repetition {it}"
+    assert lib.pevit_streamk_error(None, S()) == 0
+
+
 def test_gemm_detects_transposes_with_identity(lib):
     """A = I (padded) with an asymmetric B must reproduce B^T exactly (cdna guide: asymmetric check)."""
     K = 128
