@@ -224,6 +224,7 @@ def main():
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt)
     final_loss = float(loss)
+    eng.check_streamk()          # a stream-K hand-off that timed out would make the timed steps invalid: fail loudly
 
     # ---- dominant kernel (MFMA GEMM family): HIP events around every GEMM launch, measured over
     # extra steps right after the timed region so that event recording does not perturb `value`.
