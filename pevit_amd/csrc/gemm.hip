@@ -378,10 +378,10 @@ __global__ __launch_bounds__(WGM * WGN * 64, MINW) void gemm_kernel(GemmParams p
 // producer turns into a wrong tile and a raised sk_flag[slots] error word, never into a hang) -> agent acquire -> barrier ->
 // plain loads.  All gridDim.x workgroups must be resident at once: the launcher sizes the grid to the 2-per-CU residency.
 __device__ __forceinline__ void sk_tile_origin(const GemmParams& p, int t, int& m0, int& n0) {
-    const int tiles_n = (p.N + 127) / 128, tiles_m = (p.M + 127) / 128;
-    const int band = t / (TILE_BAND * tiles_n), within = t - band * (TILE_BAND * tiles_n);
-    const int mb = min(TILE_BAND, tiles_m - band * TILE_BAND);
-    const int tn = within / mb, tm = band * TILE_BAND + (within - tn * mb);
+    const int tiles_n = (p.N + 127) / 128, tiles_m = (p.M + 127) / 128, tb = p.sk_band;
+    const int band = t / (tb * tiles_n), within = t - band * (tb * tiles_n);
+    const int mb = min(tb, tiles_m - band * tb);
+    const int tn = within / mb, tm = band * tb + (within - tn * mb);
     m0 = tm * 128; n0 = tn * 128;
 }
 
@@ -662,37 +662,44 @@ int pick_config(const GemmParams& p, const GemmTune& t) {
     return (p.K >= t.kswitch && t128 <= 2L * cus) ? t.cfg_longk : t.cfg_shortk;
 }
 
-// Stream-K share (k-iterations per workgroup) of a few-tile problem, 0 = keep the plain tiling.  Measured on the N = 768
-// products of ViT-B/32 (scripts/gpu_streamk_sweep.py, profiles/r02_gemm_experiments.md section 13): the k-loops only get
-// faster when workgroups that share an A panel -- TILE_BAND tiles = TILE_BAND * nk iterations apart in the walk -- stay in
-// PHASE (same k at the same time), i.e. when the share divides TILE_BAND * nk: otherwise every workgroup streams its own
-// k-slices through the XCD's 4 MiB L2 and the kernel becomes fabric-bound (63-75 us against 54 plain).  A share of at
-// least nk / 2 keeps the hand-offs at one partial per tile.  K = 3072: share 32 (450 workgroups), 54.8 -> 43.0 us.
-int sk_pick_share(long tiles, int nk, int slots) {
+// Stream-K share (k-iterations per workgroup), 0 = keep the plain tiling.  Measured on the N = 768 products of ViT-B/32
+// (scripts/gpu_streamk_sweep.py, profiles/r02_gemm_experiments.md section 13): the k-loops only get faster when workgroups
+// that share an A panel -- TILE_BAND tiles = TILE_BAND * nk iterations apart in the walk -- stay in PHASE (same k at the
+// same time), i.e. when the share divides TILE_BAND * nk: otherwise every workgroup streams its own k-slices through the
+// XCD's 4 MiB L2 and the kernel becomes fabric-bound (63-75 us against 54 plain).  A share of at least nk / 2 keeps the
+// hand-offs at one partial per tile.  K = 3072, 300 tiles: share 32 (450 workgroups), 54.8 -> 43.0 us.  Problems with MORE
+// tiles than slots (ViT-B/16 at B = 64: 594, ViT-L/14 at B = 32: 520) were tried with the band chosen along with the share
+// (band 7 / share 56, band 9 / share 72): +0.6 % and -3.2 % per step, so they keep the 64x128 tiling.
+struct SkPlan { int share, band; };
+SkPlan sk_plan(long tiles, int nk, int slots) {
     const long total = tiles * nk;
     const int lo = (int)max((total + slots - 1) / slots, (long)(nk + 1) / 2);
     for (int s = lo; 4 * s <= 3 * nk; ++s)
-        if ((TILE_BAND * nk) % s == 0) return s;
-    return 0;
+        if ((TILE_BAND * nk) % s == 0) return SkPlan{s, TILE_BAND};
+    return SkPlan{0, 0};
 }
 
-// stream-K applies where the heuristic would take the 128x128 tile for a problem with fewer tiles than residency slots
-// (the long-K, N = E products), bf16 B, the three epilogues those products use
-int streamk_share(const GemmParams& p, const GemmTune& t, int cfg) {
-    if (!t.streamk || !p.sk_slab || !p.sk_flag || !t.persistent) return 0;
-    const long tiles = (long)ceil_div(p.M, 128) * ceil_div(p.N, 128);
+// stream-K applies where the heuristic takes the 128x128 tile for a long-K problem with fewer tiles than residency slots
+// (the N = E products of ViT-B/32), bf16 B, the three epilogues those products use
+SkPlan streamk_plan(const GemmParams& p, const GemmTune& t, int cfg) {
+    const SkPlan none{0, 0};
+    if (!t.streamk || !p.sk_slab || !p.sk_flag || !t.persistent) return none;
+    const int tiles_m = ceil_div(p.M, 128);
+    const long tiles = (long)tiles_m * ceil_div(p.N, 128);
     const int slots = min(pevit_gemm_sk_slots(), p.sk_slots);
     const int nk = p.K / 64;
-    if (slots < 8) return 0;
-    if (t.streamk == 2) return (t.sk_share && tiles * nk / t.sk_share <= slots) ? t.sk_share : 0;   // measurement only
-    if (t.config >= 0 || cfg != 0 || t.ablate || tiles >= slots || nk < 16) return 0;
-    const int s = sk_pick_share(tiles, nk, slots);
-    if (s) return s;
-    return t.streamk == 3 ? nk : 0;          // 3: the whole-tile walk through this kernel as well (measurement)
+    if (slots < 8) return none;
+    if (t.streamk == 2)        // measurement only
+        return (t.sk_share && (tiles * nk + t.sk_share - 1) / t.sk_share <= slots) ? SkPlan{t.sk_share, t.sk_band ? t.sk_band : TILE_BAND} : none;
+    if (t.config >= 0 || cfg != 0 || t.ablate || nk < 16 || tiles >= slots) return none;
+    const SkPlan pl = sk_plan(tiles, nk, slots);
+    if (pl.share) return pl;
+    return t.streamk == 3 ? SkPlan{nk, TILE_BAND} : none;     // 3: the whole-tile walk through this kernel (measurement)
 }
 
 template <int EPI>
-int launch_streamk(const GemmParams& p_in, int share, hipStream_t stream) {
+int launch_streamk(const GemmParams& p_in, SkPlan plan, hipStream_t stream) {
+    const int share = plan.share;
     constexpr int lds = 2 * (128 + 128) * 128;
     auto kern = gemm_streamk_kernel<EPI>;
     static bool attr_set = false;
@@ -704,7 +711,7 @@ int launch_streamk(const GemmParams& p_in, int share, hipStream_t stream) {
         attr_set = true;
     }
     GemmParams p = p_in;
-    p.sk_share = share;
+    p.sk_share = share; p.sk_band = plan.band;
     const int tiles = ceil_div(p.M, 128) * ceil_div(p.N, 128);
     // every workgroup must be resident: the grid never exceeds the 2-per-CU slots (streamk_share checked that)
     const int grid = (int)(((long)tiles * (p.K / 64) + share - 1) / share + 7) & ~7;
@@ -717,8 +724,8 @@ template <int EPI, bool BF8>
 int launch_epi(const GemmParams& p, const GemmTune& t, hipStream_t stream) {
     const int cfg = pick_config(p, t);
     if constexpr (!BF8 && (EPI == EPI_BIAS_RESID_F32 || EPI == EPI_F32 || EPI == EPI_BF16)) {
-        const int share = streamk_share(p, t, cfg);
-        if (share) return launch_streamk<EPI>(p, share, stream);
+        const SkPlan plan = streamk_plan(p, t, cfg);
+        if (plan.share) return launch_streamk<EPI>(p, plan, stream);
     }
     switch (cfg) {
         case 0: return launch_cfg<EPI, 0, BF8>(p, t, stream);

@@ -37,7 +37,8 @@ struct GemmParams {
     int E, H, Ntok;
     int dbg;              // measurement only: bit 0 skips the k-loop, bit 1 the epilogue stores, bit 2 the operand stream, bit 3 ds_read + MFMA
     // stream-K workspace (gemm.hip gemm_streamk_kernel): one 128x128 f32 slab and one flag per residency slot, or null
-    float* sk_slab; unsigned* sk_flag; int sk_slots; int sk_share;   // sk_share: k-iterations per workgroup (0: total / grid)
+    float* sk_slab; unsigned* sk_flag; int sk_slots;
+    int sk_share, sk_band;   // set by the launcher: k-iterations per workgroup, m-tiles per band of the tile walk
 };
 
 // A/B-measurement knobs.  They live in the context (pevit_tune(ctx, ...)); the single-kernel pevit_op_* entry
@@ -50,7 +51,7 @@ struct GemmTune {
     int big = 1;          // allow the 8-wave tiles
     int cfg_longk = 0, cfg_shortk = 1;   // tile configuration of the few-tile problems (N = 768 at M = 6400): K >= kswitch / K < kswitch
     int big_bias = 100;   // the 8-wave tile is taken when its stream cost is below big_bias % of the 128x128 tiling's
-    int sk_share = 0;     // measurement: k-iterations per stream-K workgroup (0 = equal split over the residency slots)
+    int sk_share = 0, sk_band = 0;   // measurement (gemm_streamk = 2): k-iterations per stream-K workgroup, m-tiles per band
     int streamk = 1;      // few-tile long-K problems: stream-K decomposition of the 128x128 tiling (needs GemmParams::sk_slab)
 };
 constexpr int PEVIT_SK_SLAB_FLOATS = 128 * 128;   // one partial tile per residency slot

@@ -33,10 +33,14 @@ def per_kernel(db_path, counter):
     return {name: (n, total) for name, n, total in rows}
 
 
-def family(stats, needle):
-    n = sum(c for k, (c, _) in stats.items() if needle in k)
-    tot = sum(t for k, (_, t) in stats.items() if needle in k)
+def family(stats, needles):
+    hit = lambda k: any(x in k for x in needles)
+    n = sum(c for k, (c, _) in stats.items() if hit(k))
+    tot = sum(t for k, (_, t) in stats.items() if hit(k))
     return n, tot
+
+
+GEMM_FAMILY = ("gemm_kernel<", "gemm_streamk_kernel<")   # every kernel of pevit_amd/csrc/gemm.hip
 
 
 def main():
@@ -56,8 +60,8 @@ def main():
     w_counter = calib(write_db, "WRITE_SIZE", cal_w[0])
     read_factor = CAL_ELEMS * 4 / f_counter
     write_factor = CAL_ELEMS * 2 / w_counter
-    gn_f, gf = family(fetch, "gemm_kernel<")
-    gn_w, gw = family(write, "gemm_kernel<")
+    gn_f, gf = family(fetch, GEMM_FAMILY)
+    gn_w, gw = family(write, GEMM_FAMILY)
     assert gn_f == gn_w and gn_f > 0, (gn_f, gn_w)
     rd = gf * 1024.0 / gn_f * read_factor
     wr = gw * 1024.0 / gn_w * write_factor
@@ -66,7 +70,7 @@ def main():
                  "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr},
         "calibration": {"kernel": "cast_f32_to_bf16 over 2^28 elements (1 GiB read, 0.5 GiB written)",
                         "read_factor_true_over_counter": read_factor, "write_factor_true_over_counter": write_factor},
-        "how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, KiB), summed over every gemm_kernel<...> "
+        "how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, KiB), summed over every gemm_kernel<...> / gemm_streamk_kernel<...> "
                "dispatch of `bench.py --steps 3 --warmup 1`, / dispatches, x the true/counter factor measured in the same pass "
                "on a 1 GiB streaming cast (read %.3f, write %.3f)" % (read_factor, write_factor),
     }

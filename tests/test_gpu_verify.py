@@ -160,4 +160,6 @@ def test_verification_mode_and_production_mode_share_the_layout():
     b = HipEngine(ARCHS["tiny-128"], "kadaptation", 10, 4, weight_format="f32-verify")
     assert a.n_params == b.n_params and torch.equal(a.grad_mask_host, b.grad_mask_host)
     assert list(a.param_views()) == list(b.param_views())
-    assert b.arena.numel() > a.arena.numel() and b.workspace.numel() > a.workspace.numel()
+    # (the production workspace also carries the stream-K slabs, 64 KiB per residency slot, which verification mode lacks)
+    sk_bytes = 2 * torch.cuda.get_device_properties(0).multi_processor_count * 128 * 128 * 4
+    assert b.arena.numel() > a.arena.numel() and b.workspace.numel() > a.workspace.numel() - sk_bytes
