@@ -20,8 +20,20 @@
 namespace {
 
 constexpr int TG_ROWS = 256;
-constexpr int TG_LDT = TG_ROWS + 8;
-__device__ __forceinline__ int tg_col(int row_e, int y) { return y ^ (((row_e >> 3) & 7) << 3); }
+constexpr int TG_LD = 72;           // row stride (elements) of the row-major LDS tiles
+// MFMA fragment of the TRANSPOSE of a row-major LDS tile [token][TG_LD] by ds_read_b64_tr_b16 (see lowrank.hip lg_trfrag):
+// lane (m, g) gets column col0 + m for the tokens 32ks + 4g + 0..3 and 32ks + 16 + 4g + 0..3
+__device__ __forceinline__ bf16x8 tg_trfrag(const bf16* tile, int ks, int col0, int lane) {
+    typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+    const int m = lane & 15, g = lane >> 4;
+    const bf16* src = tile + (32 * ks + 4 * g + (m >> 2)) * TG_LD + col0 + 4 * (m & 3);
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(src));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(src + 16 * TG_LD));
+    bf16x8 o;
+    o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
+    o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
+    return o;
+}
 
 // ---------------------------------------------------------------------------------------------
 // panels: wd [64][E] (B operand of the down GEMM), wdT [E][64] (d z GEMM), wu [E][64] (up GEMM),
@@ -86,13 +98,14 @@ __global__ void prep_compacter_kernel(const float* __restrict__ rule, const floa
 // ---------------------------------------------------------------------------------------------
 // G[e][j] = sum_r X[r][e] Y[r][j]   X: bf16 [T][ldx] (64-column slab per workgroup), Y: bf16 [T][ldy]
 // (64 columns).  Workgroup = (chunk of TG_ROWS rows, 64 columns e).  Same structure as
-// lowrank_grad_kernel: coalesced 16-byte loads, transposed LDS images, bf16 MFMA.
+// lowrank_grad_kernel: coalesced 16-byte loads, ROW-major LDS images (16-byte writes), both MFMA operands by the
+// transposing LDS read.
 // partial[chunk][E][64]; optional column sums of X -> csx[chunk][E], of Y -> csy[chunk][64].
 __global__ __launch_bounds__(256) void tn_gemm64_kernel(const bf16* __restrict__ X, int ldx, const bf16* __restrict__ Y,
                                                         int ldy, float* __restrict__ partial, float* __restrict__ csx,
                                                         float* __restrict__ csy, int T, int E) {
-    __shared__ __attribute__((aligned(16))) bf16 Xt[64 * TG_LDT];
-    __shared__ __attribute__((aligned(16))) bf16 Yt[64 * TG_LDT];
+    __shared__ __attribute__((aligned(16))) bf16 Xs[TG_ROWS * TG_LD];
+    __shared__ __attribute__((aligned(16))) bf16 Ys[TG_ROWS * TG_LD];
     __shared__ float cs[2][4][64];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, c16 = lane & 15;
     const int eslabs = E / 64;
@@ -115,12 +128,10 @@ __global__ __launch_bounds__(256) void tn_gemm64_kernel(const bf16* __restrict__
 #pragma unroll
     for (int it = 0; it < TG_ROWS / 32; ++it) {
         const int y = (tid >> 3) + 32 * it;
+        *reinterpret_cast<bf16x8*>(Xs + y * TG_LD + 8 * c) = xv[it];
+        *reinterpret_cast<bf16x8*>(Ys + y * TG_LD + 8 * c) = yv[it];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            Xt[(8 * c + i) * TG_LDT + tg_col(8 * c + i, y)] = xv[it][i];
-            Yt[(8 * c + i) * TG_LDT + tg_col(8 * c + i, y)] = yv[it][i];
-            sx[i] += bf2f(xv[it][i]); sy[i] += bf2f(yv[it][i]);
-        }
+        for (int i = 0; i < 8; ++i) { sx[i] += bf2f(xv[it][i]); sy[i] += bf2f(yv[it][i]); }
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -133,17 +144,12 @@ __global__ __launch_bounds__(256) void tn_gemm64_kernel(const bf16* __restrict__
     f32x4 acc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int ea = 16 * wid + c16;
 #pragma unroll
     for (int ks = 0; ks < TG_ROWS / 32; ++ks) {
-        const int y0 = 32 * ks + 8 * g;
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(Xt + ea * TG_LDT + tg_col(ea, y0));
+        const bf16x8 a = tg_trfrag(Xs, ks, 16 * wid, lane);
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const int jb = 16 * nt + c16;
-            const bf16x8 b = *reinterpret_cast<const bf16x8*>(Yt + jb * TG_LDT + tg_col(jb, y0));
-            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[nt], 0, 0, 0);
-        }
+        for (int nt = 0; nt < 4; ++nt)
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, tg_trfrag(Ys, ks, 16 * nt, lane), acc[nt], 0, 0, 0);
     }
     float* out = partial + (size_t)chunk * E * 64;
 #pragma unroll
