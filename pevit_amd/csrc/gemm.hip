@@ -680,7 +680,8 @@ SkPlan sk_plan(long tiles, int nk, int slots) {
 }
 
 // stream-K applies where the heuristic takes the 128x128 tile for a long-K problem with fewer tiles than residency slots
-// (the N = E products of ViT-B/32), bf16 B, the four epilogues those products use
+// (the N = E products of ViT-B/32), bf16 B, the five epilogues those products use (c_proj forward with and without the kept MLP output, the
+// dX products in f32 / bf16, the patch embedding)
 SkPlan streamk_plan(const GemmParams& p, const GemmTune& t, int cfg) {
     const SkPlan none{0, 0};
     if (!t.streamk || !p.sk_slab || !p.sk_flag || !t.persistent) return none;
@@ -723,7 +724,7 @@ int launch_streamk(const GemmParams& p_in, SkPlan plan, hipStream_t stream) {
 template <int EPI, bool BF8>
 int launch_epi(const GemmParams& p, const GemmTune& t, hipStream_t stream) {
     const int cfg = pick_config(p, t);
-    if constexpr (!BF8 && (EPI == EPI_BIAS_RESID_F32 || EPI == EPI_F32 || EPI == EPI_BF16 || EPI == EPI_BIAS_RESID_KEEP)) {
+    if constexpr (!BF8 && (EPI == EPI_BIAS_RESID_F32 || EPI == EPI_F32 || EPI == EPI_BF16 || EPI == EPI_BIAS_RESID_KEEP || EPI == EPI_PATCH_EMBED)) {
         const SkPlan plan = streamk_plan(p, t, cfg);
         if (plan.share) return launch_streamk<EPI>(p, plan, stream);
     }
