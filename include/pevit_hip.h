@@ -211,7 +211,8 @@ int pevit_op_im2col(void* stream, const float* images, void* patches_bf16, int B
  * "gemm_persistent", "gemm_big" (0 = never pick the 8-wave tiles), "gemm_big_bias", "gemm_kswitch", "gemm_cfg_longk" /
  * "gemm_cfg_shortk" (configuration of the few-tile problems above / below kswitch), "gemm_ablate" (bit 0 skips the
  * k-loop, bit 1 the epilogue stores, bit 2 the operand stream, bit 3 ds_read + MFMA), "side_stream" (ctx only),
- * "gemm_streamk" (0 = never use the stream-K decomposition of the few-tile long-K products);
+ * "gemm_streamk" (0 = never use the stream-K decomposition of the few-tile long-K products), "gemm_ksplit" (0 = never
+ * use the 160x128 tile whose two wave groups take alternate k-tiles);
  * returns 0, or -1 for an unknown key */
 int pevit_tune(pevit_ctx* ctx, const char* key, int value);
 

@@ -573,6 +573,194 @@ __global__ __launch_bounds__(256, 2) void gemm_streamk_kernel(GemmParams p, int 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// One-tile-per-CU form for the N = E products: a 160x128 tile gives M = 6400, N = 768 exactly 240 tiles for 256 CUs (the
+// vendor library picks the same shape class for these problems: MT128x160 / MT160x128, profiles/r02_vendor_gemm_shapes.md),
+// so every CU streams the same 288 rows per k-tile -- 10 % fewer bytes than two 128x128 halves and no imbalance.  With one
+// 4-wave workgroup per CU that tile ran at ~19 B/clk/CU of operand stream whatever the depth of the LDS ring (2, 3 or 4
+// stages: 45.8 / 45.8 / 45.4 us for c_proj; profiles/r02_gemm_experiments.md section 15): the stream rate depends on how
+// many waves issue requests.  Hence:
+// The same tile with TWO wave groups that take alternate k-tiles (k-tile 2i -> group 0, 2i+1 -> group 1): twice the waves
+// issue LDS-DMA requests and twice the bytes are in flight per CU, which is what the L2 -> LDS stream rate depends on
+// (4-wave tiles measure ~19-25 B/clk/CU, 8-wave tiles 32; profiles/r02_gemm_experiments.md section 12), without shrinking the
+// tile or the per-wave fragment block.  Each group double-buffers its own k-tiles (4 LDS stages in all); one workgroup
+// barrier per pair of k-tiles; at the end the two partial sums (even k-tiles, odd k-tiles) meet through LDS, every 32x32
+// fragment being finished and stored by one of the two groups.
+template <int EPI, int WGM, int WGN, int WM, int WN>
+__global__ __launch_bounds__(2 * WGM * WGN * 64, 1) void gemm_ksplit_kernel(GemmParams p, int ntiles) {
+    constexpr int NWG = WGM * WGN;                         // waves per group
+    constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32, BK = 64;
+    constexpr int ROWB = 128, CH = 8, RPP = 8;
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int PA = BM / RPP / NWG, PB = BN / RPP / NWG, KS = BK / 16;
+    static_assert(PA * RPP * NWG == BM && PB * RPP * NWG == BN, "tile rows must split evenly over a group's loader waves");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = wid / NWG, gw = wid - grp * NWG;
+    const int wm = gw / WGN, wn = gw % WGN;
+    int m0, n0;
+    tile_origin<BM, BN>(p, blockIdx.x, m0, n0);
+    const char* a_src[PA];
+    const char* b_src[PB];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int row = (gw * PA + i) * RPP + lane / CH;
+        const int chunk = (lane % CH) ^ ((row >> 1) & (CH - 1));
+        int ar = m0 + row; ar = ar < p.M ? ar : p.M - 1;
+        a_src[i] = reinterpret_cast<const char*>(p.A + (size_t)ar * p.lda) + chunk * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+        const int row = (gw * PB + i) * RPP + lane / CH;
+        const int chunk = (lane % CH) ^ ((row >> 1) & (CH - 1));
+        int br = n0 + row; br = br < p.Nb ? br : p.Nb - 1;
+        b_src[i] = reinterpret_cast<const char*>(p.B) + (size_t)br * p.ldb * 2 + chunk * 16;
+    }
+    char* gbase = smem + grp * 2 * STAGE_BYTES;            // this group's two stages
+    auto issue_tile = [&](int kt, int st) {
+#pragma unroll
+        for (int q = 0; q < PA; ++q) glds16(a_src[q] + kt * 128, gbase + st * STAGE_BYTES + (gw * PA + q) * 1024);
+#pragma unroll
+        for (int q = 0; q < PB; ++q) glds16(b_src[q] + kt * 128, gbase + st * STAGE_BYTES + A_BYTES + (gw * PB + q) * 1024);
+    };
+    const int frow = lane & 31, fswz = (frow >> 1) & (CH - 1), fhalf = lane >> 5;
+    int a_off[WM], b_off[WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) a_off[i] = (wm * WM * 32 + i * 32 + frow) * ROWB;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) b_off[j] = A_BYTES + (wn * WN * 32 + j * 32 + frow) * ROWB;
+    const int nk = p.K / BK;
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    if (grp < nk) issue_tile(grp, 0);
+    // residual epilogues: this wave's residual values (the fragments its group will finish) are requested now, so that the
+    // epilogue -- which every CU reaches at the same moment with one tile per CU -- only has its stores left
+    constexpr bool PRE = (EPI == EPI_BIAS_RESID_F32 || EPI == EPI_BIAS_RESID_KEEP);
+    constexpr int NOWN = PRE ? (WM * WN + 1) / 2 : 1;
+    float4 rpre[NOWN][2][2];
+    if constexpr (PRE) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                if (((i * WN + j) & 1) != grp) continue;
+#pragma unroll
+                for (int pass = 0; pass < 2; ++pass) {
+                    const int row = m0 + wm * WM * 32 + i * 32 + pass * 16 + (lane >> 2);
+                    const int col = n0 + wn * WN * 32 + j * 32 + (lane & 3) * 8;
+                    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
+                    if (row < p.M && col < p.N) {
+                        const float* src = p.resid + (size_t)row * p.ldr + col;
+                        r0 = *reinterpret_cast<const float4*>(src); r1 = *reinterpret_cast<const float4*>(src + 4);
+                    }
+                    rpre[(i * WN + j) >> 1][pass][0] = r0; rpre[(i * WN + j) >> 1][pass][1] = r1;
+                }
+            }
+    }
+    const int iters = (nk + 1) >> 1;
+    for (int it = 0; it < iters; ++it) {
+        const int kt = 2 * it + grp;
+        wait_vmcnt<0>();
+        __syncthreads();                                   // both groups' k-tiles have landed; the other stages are free
+        if (kt + 2 < nk) issue_tile(kt + 2, (it + 1) & 1);
+        if (kt < nk) {
+            const char* sa = gbase + (it & 1) * STAGE_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int coff = (((ks * 2 + fhalf) ^ fswz) << 4);
+                bf16x8 af[WM], bfr[WN];
+#pragma unroll
+                for (int i = 0; i < WM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa + a_off[i] + coff);
+#pragma unroll
+                for (int j = 0; j < WN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(sa + b_off[j] + coff);
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- the two partial sums meet through LDS: fragment f = i * WN + j is FINISHED by group f % 2, which receives the other
+    // group's partial at hand[((gw * NF + f) * 16 + r) * 64 + lane] and runs that fragment's epilogue -- both groups store
+    constexpr int NF = WM * WN;
+    float* hand = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+            if (((i * WN + j) & 1) != grp) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) hand[((gw * NF + i * WN + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+            }
+    __syncthreads();
+    static_assert(3 * STAGE_BYTES >= NWG * NF * 16 * 64 * 4, "epilogue scratch must not overlap the hand-off area");
+    static_assert(STAGE_BYTES >= 2 * NWG * 4096, "4 KiB of epilogue scratch per wave in the last stage");
+    float* cw = reinterpret_cast<float*>(smem + 3 * STAGE_BYTES + wid * 4096);
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            if (((i * WN + j) & 1) != grp) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                cw[row * 32 + (lane & 31)] = acc[i][j][r] + hand[((gw * NF + i * WN + j) * 16 + r) * 64 + lane];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                const int lr = pass * 16 + (lane >> 2);
+                const int lc = (lane & 3) * 8;
+                const int row = m0 + wm * WM * 32 + i * 32 + lr;
+                const int col = n0 + wn * WN * 32 + j * 32 + lc;
+                const float4 x0 = *reinterpret_cast<const float4*>(cw + lr * 32 + lc);
+                const float4 x1 = *reinterpret_cast<const float4*>(cw + lr * 32 + lc + 4);
+                if (row < p.M && col < p.N) {
+                    float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                    if constexpr (PRE) {          // epilogue_store<EPI_BIAS_RESID_*> with the residual already in registers
+                        add8(v, p.bias + col);
+                        if constexpr (EPI == EPI_BIAS_RESID_KEEP) store8f(p.outf2 + (size_t)row * p.ldo2 + col, v);
+                        const float4 r0 = rpre[(i * WN + j) >> 1][pass][0], r1 = rpre[(i * WN + j) >> 1][pass][1];
+                        v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
+                        v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+                        store8f(p.outf + (size_t)row * p.ldo + col, v);
+                    } else {
+                        epilogue_store<EPI, bf16>(p, row, col, v);
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+}
+
+template <int EPI, int WGM, int WGN, int WM, int WN>
+int launch_ksplit(const GemmParams& p, hipStream_t stream) {
+    constexpr int bm = WGM * WM * 32, bn = WGN * WN * 32, lds = 4 * (bm + bn) * 128;
+    auto kern = gemm_ksplit_kernel<EPI, WGM, WGN, WM, WN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+            pevit_set_error("hipFuncSetAttribute(k-split gemm epi %d) failed", EPI);
+            return -1;
+        }
+        attr_set = true;
+    }
+    const int tiles = ceil_div(p.M, bm) * ceil_div(p.N, bn);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(2 * WGM * WGN * 64), lds, stream, p, tiles);
+    LAUNCH_OK("gemm (k-split)");
+    return 0;
+}
+
 // wgm x wgn waves of wm x wn fragments; wgs = workgroups per CU the LDS and registers are sized for
 struct TileConfig { int wgm, wgn, wm, wn, wgs; bool hoist, spread, pipe; };
 constexpr TileConfig kConfigs[] = {
@@ -721,10 +909,20 @@ int launch_streamk(const GemmParams& p_in, SkPlan plan, hipStream_t stream) {
     return 0;
 }
 
+// the 160x128 two-group tile: where the heuristic takes a 4-wave tile for a long-K problem whose 160x128 tiling gives (almost)
+// every CU exactly one tile -- the N = E products of ViT-B/32 at B = 128 (240 tiles)
+bool use_ksplit(const GemmParams& p, const GemmTune& t, int cfg) {
+    if (!t.ksplit || t.config >= 0 || (cfg != 0 && cfg != 1) || t.ablate) return false;
+    const long tiles = (long)ceil_div(p.M, 160) * ceil_div(p.N, 128);
+    const int cus = num_cus();
+    return p.K >= 1024 && tiles <= cus && 4 * tiles >= 3 * cus;
+}
+
 template <int EPI, bool BF8>
 int launch_epi(const GemmParams& p, const GemmTune& t, hipStream_t stream) {
     const int cfg = pick_config(p, t);
     if constexpr (!BF8 && (EPI == EPI_BIAS_RESID_F32 || EPI == EPI_F32 || EPI == EPI_BF16 || EPI == EPI_BIAS_RESID_KEEP || EPI == EPI_PATCH_EMBED)) {
+        if (use_ksplit(p, t, cfg)) return launch_ksplit<EPI, 1, 4, 5, 1>(p, stream);
         const SkPlan plan = streamk_plan(p, t, cfg);
         if (plan.share) return launch_streamk<EPI>(p, plan, stream);
     }

@@ -52,6 +52,7 @@ struct GemmTune {
     int cfg_longk = 0, cfg_shortk = 1;   // tile configuration of the few-tile problems (N = 768 at M = 6400): K >= kswitch / K < kswitch
     int big_bias = 100;   // the 8-wave tile is taken when its stream cost is below big_bias % of the 128x128 tiling's
     int sk_share = 0, sk_band = 0;   // measurement (gemm_streamk = 2): k-iterations per stream-K workgroup, m-tiles per band
+    int ksplit = 1;       // N = E long-K products with ~one 160x128 tile per CU: 8-wave tile, two wave groups on alternate k-tiles
     int streamk = 1;      // few-tile long-K problems: stream-K decomposition of the 128x128 tiling (needs GemmParams::sk_slab)
 };
 constexpr int PEVIT_SK_SLAB_FLOATS = 128 * 128;   // one partial tile per residency slot

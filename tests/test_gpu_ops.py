@@ -95,8 +95,10 @@ def test_gemm_every_tile_config_is_bit_identical(lib, cfg, M, N, K):
 
 @pytest.mark.parametrize("M,N,K", [(6400, 768, 3072), (6400, 768, 2368 + 0), (2500, 768, 3072), (6333, 760, 2048), (8224, 1024, 1024)])
 def test_gemm_streamk_hand_off(lib, M, N, K):
-    """Few-tile long-K products run as stream-K: the tiles x k-iterations space is cut into one range per resident
-    workgroup and tiles that span ranges are completed through partial slabs in HBM.  Checked against the torch
+    """Few-tile long-K products leave the plain tiling: with (almost) one 160x128 tile per CU they run on the 8-wave tile
+    whose two wave groups take alternate k-tiles (M = 6400 / 6333), with fewer tiles as stream-K -- the tiles x
+    k-iterations space cut into one range per resident workgroup, tiles that span ranges completed through partial slabs in
+    HBM (M = 2500).  Both change the summation split, both are deterministic.  Checked against the torch
     product, against the plain tiling (different summation split: close, not equal), for run-to-run bit identity, and
     repeatedly with other kernels in flight and warm caches (stale hand-offs show up only under uneven load)."""
     K = K // 64 * 64
@@ -118,14 +120,18 @@ def test_gemm_streamk_hand_off(lib, M, N, K):
 
     sk = run()
     assert lib.pevit_streamk_error(None, S()) == 0
+    # in place on the residual buffer (how the engine calls it): the k-split tile reads its residual values before its k-loop
+    r2 = resid.clone()
+    gemm(lib, EPI["BIAS_RESID"], A, B, M, N, K, bias=bias, resid=r2, outf=r2, b_rows=B.shape[0])
+    assert torch.equal(r2, sk[0])
     assert max_rel(sk[0].cpu(), (ref + bias + resid).cpu()) < 2e-4
     assert max_rel(sk[1].cpu(), ref.cpu()) < 2e-4
     assert max_rel(sk[2].float().cpu(), ref.cpu()) < 1e-2
-    assert lib.pevit_tune(None, b"gemm_streamk", 0) == 0
+    assert lib.pevit_tune(None, b"gemm_streamk", 0) == 0 and lib.pevit_tune(None, b"gemm_ksplit", 0) == 0
     try:
         plain = run()
     finally:
-        lib.pevit_tune(None, b"gemm_streamk", 1)
+        lib.pevit_tune(None, b"gemm_streamk", 1); lib.pevit_tune(None, b"gemm_ksplit", 1)
     assert max_rel(sk[1].cpu(), plain[1].cpu()) < 2e-5
     for it in range(12):
         if it % 3 == 0:
