@@ -599,8 +599,17 @@ __global__ __launch_bounds__(2 * WGM * WGN * 64, 1) void gemm_ksplit_kernel(Gemm
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int grp = wid / NWG, gw = wid - grp * NWG;
     const int wm = gw / WGN, wn = gw % WGN;
+    const int frow = lane & 31, fswz = (frow >> 1) & (CH - 1), fhalf = lane >> 5;
+    int a_off[WM], b_off[WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) a_off[i] = (wm * WM * 32 + i * 32 + frow) * ROWB;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) b_off[j] = A_BYTES + (wn * WN * 32 + j * 32 + frow) * ROWB;
+    char* gbase = smem + grp * 2 * STAGE_BYTES;            // this group's two stages
+    const int nk = p.K / BK;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {      // one tile per workgroup in the measured cases; more when tiles > CUs
     int m0, n0;
-    tile_origin<BM, BN>(p, blockIdx.x, m0, n0);
+    tile_origin<BM, BN>(p, tile, m0, n0);
     const char* a_src[PA];
     const char* b_src[PB];
 #pragma unroll
@@ -617,20 +626,12 @@ __global__ __launch_bounds__(2 * WGM * WGN * 64, 1) void gemm_ksplit_kernel(Gemm
         int br = n0 + row; br = br < p.Nb ? br : p.Nb - 1;
         b_src[i] = reinterpret_cast<const char*>(p.B) + (size_t)br * p.ldb * 2 + chunk * 16;
     }
-    char* gbase = smem + grp * 2 * STAGE_BYTES;            // this group's two stages
     auto issue_tile = [&](int kt, int st) {
 #pragma unroll
         for (int q = 0; q < PA; ++q) glds16(a_src[q] + kt * 128, gbase + st * STAGE_BYTES + (gw * PA + q) * 1024);
 #pragma unroll
         for (int q = 0; q < PB; ++q) glds16(b_src[q] + kt * 128, gbase + st * STAGE_BYTES + A_BYTES + (gw * PB + q) * 1024);
     };
-    const int frow = lane & 31, fswz = (frow >> 1) & (CH - 1), fhalf = lane >> 5;
-    int a_off[WM], b_off[WN];
-#pragma unroll
-    for (int i = 0; i < WM; ++i) a_off[i] = (wm * WM * 32 + i * 32 + frow) * ROWB;
-#pragma unroll
-    for (int j = 0; j < WN; ++j) b_off[j] = A_BYTES + (wn * WN * 32 + j * 32 + frow) * ROWB;
-    const int nk = p.K / BK;
     f32x16 acc[WM][WN];
 #pragma unroll
     for (int i = 0; i < WM; ++i)
@@ -741,6 +742,8 @@ __global__ __launch_bounds__(2 * WGM * WGN * 64, 1) void gemm_ksplit_kernel(Gemm
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
+    __syncthreads();                                       // the LDS scratch is free before the next tile's first k-tile lands in it
+  }
 }
 
 template <int EPI, int WGM, int WGN, int WM, int WN>
@@ -756,7 +759,8 @@ int launch_ksplit(const GemmParams& p, hipStream_t stream) {
         attr_set = true;
     }
     const int tiles = ceil_div(p.M, bm) * ceil_div(p.N, bn);
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(2 * WGM * WGN * 64), lds, stream, p, tiles);
+    const int grid = min(tiles, num_cus() & ~7);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(2 * WGM * WGN * 64), lds, stream, p, tiles);
     LAUNCH_OK("gemm (k-split)");
     return 0;
 }
@@ -914,8 +918,10 @@ int launch_streamk(const GemmParams& p_in, SkPlan plan, hipStream_t stream) {
 bool use_ksplit(const GemmParams& p, const GemmTune& t, int cfg) {
     if (!t.ksplit || t.config >= 0 || (cfg != 0 && cfg != 1) || t.ablate) return false;
     const long tiles = (long)ceil_div(p.M, 160) * ceil_div(p.N, 128);
-    const int cus = num_cus();
-    return p.K >= 1024 && tiles <= cus && 4 * tiles >= 3 * cus;
+    const int cus = num_cus() & ~7;
+    const long rounds = (tiles + cus - 1) / cus;
+    if (t.ksplit == 1 && rounds > 1) return false;          // 2: also problems of several rounds (measurement)
+    return p.K >= 1024 && 4 * tiles >= 3 * rounds * cus;    // the last round at least 3/4 full on average
 }
 
 template <int EPI, bool BF8>
