@@ -185,6 +185,10 @@ __global__ __launch_bounds__(WGM * WGN * 64, MINW) void gemm_kernel(GemmParams p
         auto k_tile = [&](int kt, auto issue_next) {
             constexpr bool ISSUE = decltype(issue_next)::value;
             constexpr int NG = KS * WM, NP = PA + PB;       // MFMA groups per k-tile, pieces per wave
+            // ... and only between the groups of the FIRST HALF of the k-tile: a request issued late in the iteration is
+            // still in flight at the top of the next one (the windows 3 ... 10 of 20 groups all measure +1.0-1.4 % per step
+            // over the full spread; profiles/r02_gemm_experiments.md section 16)
+            constexpr int SPREAD_NG = NG / 2 > 0 ? NG / 2 : 1;
 #ifdef GEMM_STREAM_FREE   // measurement build only (scripts/build_variants.sh): the stream-only ablation issues without waiting
             if (!GEMM_DBG(p, 8)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
 #else
@@ -229,7 +233,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, MINW) void gemm_kernel(GemmParams p
                         if constexpr (ISSUE && SPREAD) {
 #pragma unroll
                             for (int q = 0; q < NP; ++q)
-                                if (q * NG / NP == ks * WM + i) issue_piece(kt + 1, q);
+                                if (q * SPREAD_NG / NP == ks * WM + i) issue_piece(kt + 1, q);
                         }
 #pragma unroll
                         for (int j = 0; j < WN; ++j)
@@ -252,7 +256,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, MINW) void gemm_kernel(GemmParams p
                         if constexpr (ISSUE && SPREAD) {
 #pragma unroll
                             for (int q = 0; q < NP; ++q)
-                                if (q * NG / NP == ks * WM + i) issue_piece(kt + 1, q);
+                                if (q * SPREAD_NG / NP == ks * WM + i) issue_piece(kt + 1, q);
                         }
 #pragma unroll
                         for (int j = 0; j < WN; ++j)
