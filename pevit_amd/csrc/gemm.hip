@@ -48,6 +48,10 @@ namespace {
 #define GEMM_DBG(p, bit) ((p).dbg & (bit))
 #endif
 
+#ifndef GEMM8_ABLATE
+#define GEMM8_ABLATE 0   // measurement builds of gemm8_kernel (scripts/build_variants.sh): 4 = no operand stream, 8 = no ds_read / MFMA
+#endif
+
 constexpr int TILE_BAND = 6;
 
 int num_cus() {
@@ -69,14 +73,17 @@ __device__ __forceinline__ void wait_vmcnt() {
 // tile coordinates of this workgroup.  Order: XCD-contiguous (xcd_remap), and inside that a band
 // of TILE_BAND m-tiles is walked n-major, so the tiles an XCD has in flight share TILE_BAND
 // A-panels and only a few B-panels (a 128x768 bf16 panel is 192 KiB; the XCD's L2 is 4 MiB).
+// GemmParams::band overrides the band height: a one-round launch whose tiles split evenly over the 8 XCDs gives every XCD
+// whole bands, so that no A panel is fetched by two private L2s (xcd_band below).
 template <int BM, int BN>
 __device__ __forceinline__ void tile_origin(const GemmParams& p, int tile, int& m0, int& n0) {
     const int tiles_n = (p.N + BN - 1) / BN;
     const int tiles_m = (p.M + BM - 1) / BM;
     const int t = xcd_remap(tile, tiles_m * tiles_n);
-    const int band = t / (TILE_BAND * tiles_n), within = t - band * (TILE_BAND * tiles_n);
-    const int mb = min(TILE_BAND, tiles_m - band * TILE_BAND);
-    const int tn = within / mb, tm = band * TILE_BAND + (within - tn * mb);
+    const int tb = p.band > 0 ? p.band : TILE_BAND;
+    const int band = t / (tb * tiles_n), within = t - band * (tb * tiles_n);
+    const int mb = min(tb, tiles_m - band * tb);
+    const int tn = within / mb, tm = band * tb + (within - tn * mb);
     m0 = tm * BM; n0 = tn * BN;
 }
 
@@ -355,6 +362,196 @@ __global__ __launch_bounds__(WGM * WGN * 64, MINW) void gemm_kernel(GemmParams p
                     if (row < p.M && col < p.N && !GEMM_DBG(p, 2)) {
                         float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
                         if constexpr (BF8) { if (p.bscale) mul8(v, p.bscale + col); }
+                        epilogue_store<EPI, bf16>(p, row, col, v);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        if (next >= ntiles) break;
+        tile = next;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 8-wave tiles (2 x 4 waves of WM x 2 fragments: 256x256 / 320x256, one workgroup per CU, bf16 B) with a STAGGERED
+// two-group schedule (round 3).  In gemm_kernel above hipcc serialises every pair of MFMAs behind a ds_read_b128 it has just
+// issued (one fragment register set, re-used: the 160 accumulator registers leave room for nothing else), all eight waves
+// cross the k-tile barrier together, read together and compute together: "compute only" that loop keeps the matrix pipe 46 %
+// busy (profiles/r02_gemm_experiments.md section 1).  Here a k-tile is cut into phases of KSP k-steps; in a phase a wave
+//     LOAD : reads ALL its fragments of the phase (KSP * (WM + 2) ds_read_b128), requests its share of the next k-tile
+//            (LDS-DMA), waits for its reads                                          -> s_barrier
+//     MFMA : KSP * WM * 2 MFMAs back to back at raised priority                      -> s_barrier
+// and the upper half of the workgroup (waves 4-7, the partners of waves 0-3 on the four SIMDs) runs ONE barrier behind the
+// lower half: between two barriers one wave of every SIMD is in its MFMA section while its partner reads and requests, so the
+// matrix pipe always has a wave whose operands are already in registers (cdna guide 5.5 T3/T5: role split + setprio).
+// LDS hazards, by barrier count (2 stages; interval numbering: group 0 LOADs in even intervals, group 1 in odd ones):
+//   * WAR: every LOAD section waits for its own ds_reads BEFORE its barrier, so a stage is free for the DMA of the k-tile
+//     after next as soon as the last reader has passed that barrier;
+//   * RAW: a wave's requests for k-tile t+1 go out in its LOAD sections of k-tile t (never in the last one) and every wave
+//     waits for its own requests before the barrier that precedes group 0's first LOAD of k-tile t+1 (group 0: after its last
+//     MFMA section of k-tile t; group 1: at the end of its last LOAD section).
+// Operands are requested with buffer_load ... lds: one SGPR descriptor per operand, a 32-bit byte offset per 1 KiB piece and
+// the k-tile offset in an SGPR, instead of nine 64-bit pointers per lane (which spilled: 256 VGPRs, 44 bytes of scratch).
+// Same MFMA order per accumulator as gemm_kernel: bit-identical results.
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+
+// 16 bytes per lane, buffer form of the LDS-DMA: descriptor {base, bytes} + per-lane byte offset + scalar byte offset.
+// Kept in a __device__ function: written inline in the kernel (or in a lambda of it) the HOST pass of hipcc silently drops the
+// whole kernel stub (a deferred diagnostic on the builtin's operands that is never printed) and the library fails to load
+// with an undefined symbol.
+__device__ __forceinline__ void buffer_lds16(const void* base, int bytes, char* lds_wave_base, int voff, int soff) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_ptr)lds_wave_base, 16, voff, soff, 0, 0);
+}
+
+template <int EPI, int WM, int KSP>
+__global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmParams p, int ntiles) {
+    constexpr int WGN = 4, WN = 2, NW = 8;
+    constexpr int BM = 2 * WM * 32, BN = WGN * WN * 32, BK = 64;
+    constexpr int ROWB = 128, CH = 8, RPP = 8;
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int PA = BM / RPP / NW, PB = BN / RPP / NW, NP = PA + PB;
+    constexpr int KS = BK / 16, NPH = KS / KSP;          // MFMA k-steps per k-tile, phases per k-tile
+    constexpr int ISSUE_PH = NPH > 1 ? NPH - 1 : 1;     // phases whose LOAD section carries LDS-DMA requests
+    static_assert(PA * RPP * NW == BM && PB * RPP * NW == BN && NPH * KSP == KS, "tile geometry");
+    static_assert(STAGE_BYTES >= NW * 4096, "the epilogue borrows 4 KiB per wave of stage 1");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = wid >> 2, wm = grp, wn = wid & 3;
+
+    // (rows - 1) * pitch + K elements are readable; the launcher has checked that both fit 31 bits
+    const int a_bytes = ((p.M - 1) * p.lda + p.K) * 2, b_bytes = ((p.Nb - 1) * p.ldb + p.K) * 2;
+    int a_voff[PA], b_voff[PB];
+    auto set_sources = [&](int m0, int n0) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int row = (wid * PA + i) * RPP + lane / CH;
+            const int chunk = (lane % CH) ^ ((row >> 1) & (CH - 1));
+            int ar = m0 + row; ar = ar < p.M ? ar : p.M - 1;
+            a_voff[i] = ar * (p.lda * 2) + chunk * 16;
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const int row = (wid * PB + i) * RPP + lane / CH;
+            const int chunk = (lane % CH) ^ ((row >> 1) & (CH - 1));
+            int br = n0 + row; br = br < p.Nb ? br : p.Nb - 1;
+            b_voff[i] = br * (p.ldb * 2) + chunk * 16;
+        }
+    };
+    auto issue_piece = [&](int kt, int q) {
+#if GEMM8_ABLATE != 4   // measurement builds: 4 = no operand stream, 8 = no ds_read / MFMA
+        char* dst = smem + (kt & 1) * STAGE_BYTES;
+        if (q < PA) buffer_lds16(p.A, a_bytes, dst + (wid * PA + q) * 1024, a_voff[q], kt * 128);
+        else buffer_lds16(p.B, b_bytes, dst + A_BYTES + (wid * PB + q - PA) * 1024, b_voff[q - PA], kt * 128);
+#endif
+    };
+    const int frow = lane & 31, fswz = (frow >> 1) & (CH - 1), fhalf = lane >> 5;
+    const int a_base = (wm * WM * 32 + frow) * ROWB, b_base = A_BYTES + (wn * WN * 32 + frow) * ROWB;
+    int coff[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) coff[ks] = ((ks * 2 + fhalf) ^ fswz) << 4;
+
+    const int nk = GEMM_DBG(p, 1) ? 0 : p.K / BK;
+    int tile = blockIdx.x;
+    int m0, n0;
+    tile_origin<BM, BN>(p, tile, m0, n0);
+    set_sources(m0, n0);
+    if (nk > 0) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) issue_piece(0, q);
+    }
+    while (true) {
+        f32x16 acc[WM][WN];
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+        // k-tile 0 has landed for every wave, and the previous epilogue no longer uses stage 1 as scratch
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (grp) __builtin_amdgcn_s_barrier();                      // the upper half runs one barrier behind
+        for (int kt = 0; kt < nk; ++kt) {
+            const char* st = smem + (kt & 1) * STAGE_BYTES;
+            const bool more = kt + 1 < nk;
+#pragma unroll
+            for (int ph = 0; ph < NPH; ++ph) {
+                // ---- LOAD
+                bf16x8 af[KSP][WM], bfr[KSP][WN];
+#if GEMM8_ABLATE != 8
+#pragma unroll
+                for (int s = 0; s < KSP; ++s) {
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) bfr[s][j] = *reinterpret_cast<const bf16x8*>(st + b_base + j * 32 * ROWB + coff[ph * KSP + s]);
+#pragma unroll
+                    for (int i = 0; i < WM; ++i) af[s][i] = *reinterpret_cast<const bf16x8*>(st + a_base + i * 32 * ROWB + coff[ph * KSP + s]);
+                }
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+                if (ph < ISSUE_PH && more) {
+#pragma unroll
+                    for (int q = ph * NP / ISSUE_PH; q < (ph + 1) * NP / ISSUE_PH; ++q) issue_piece(kt + 1, q);
+                }
+                if (ph == NPH - 1 && grp) wait_vmcnt<0>();
+                __builtin_amdgcn_s_waitcnt(0xC07F);                  // lgkmcnt(0): this wave's reads are in registers
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- MFMA
+#if GEMM8_ABLATE != 8
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int s = 0; s < KSP; ++s)
+#pragma unroll
+                    for (int i = 0; i < WM; ++i)
+#pragma unroll
+                        for (int j = 0; j < WN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][i], bfr[s][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+                if (ph == NPH - 1 && !grp) wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+        if (!grp) __builtin_amdgcn_s_barrier();                     // ... and the lower half waits for it here
+        // both stages are idle: stage 0 receives the next tile's first k-tile while the epilogue transposes through
+        // (this wave's 4 KiB of) stage 1
+        const int cm0 = m0, cn0 = n0;
+        const int next = tile + gridDim.x;
+        if (next < ntiles) {
+            tile_origin<BM, BN>(p, next, m0, n0);
+            set_sources(m0, n0);
+            if (nk > 0) {
+#pragma unroll
+                for (int q = 0; q < NP; ++q) issue_piece(0, q);
+            }
+        }
+        float* cw = reinterpret_cast<float*>(smem + STAGE_BYTES + wid * 4096);
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    cw[row * 32 + (lane & 31)] = acc[i][j][r];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int pass = 0; pass < 2; ++pass) {
+                    const int lr = pass * 16 + (lane >> 2);
+                    const int lc = (lane & 3) * 8;
+                    const int row = cm0 + wm * WM * 32 + i * 32 + lr;
+                    const int col = cn0 + wn * WN * 32 + j * 32 + lc;
+                    const float4 x0 = *reinterpret_cast<const float4*>(cw + lr * 32 + lc);
+                    const float4 x1 = *reinterpret_cast<const float4*>(cw + lr * 32 + lc + 4);
+                    if (row < p.M && col < p.N && !GEMM_DBG(p, 2)) {
+                        float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
                         epilogue_store<EPI, bf16>(p, row, col, v);
                     }
                 }
@@ -750,8 +947,19 @@ __global__ __launch_bounds__(2 * WGM * WGN * 64, 1) void gemm_ksplit_kernel(Gemm
   }
 }
 
+// band height (m-tiles) that hands every XCD whole bands: tiles / 8 consecutive tile indices per XCD (xcd_remap) = k bands of
+// tiles_n * band tiles.  0 = keep TILE_BAND (several rounds, or no even split).
+int xcd_band(int tiles, int tiles_n, int grid, const GemmTune& t) {
+    if (t.band >= 0) return t.band;
+    if (tiles > grid || tiles % 8 || (tiles / 8) % tiles_n) return 0;
+    const int per_xcd_m = tiles / 8 / tiles_n;          // m-tiles per XCD
+    for (int b = min(per_xcd_m, 8); b >= 1; --b)
+        if (per_xcd_m % b == 0) return b;
+    return 0;
+}
+
 template <int EPI, int WGM, int WGN, int WM, int WN>
-int launch_ksplit(const GemmParams& p, hipStream_t stream) {
+int launch_ksplit(const GemmParams& p, const GemmTune& t, hipStream_t stream) {
     constexpr int bm = WGM * WM * 32, bn = WGN * WN * 32, lds = 4 * (bm + bn) * 128;
     auto kern = gemm_ksplit_kernel<EPI, WGM, WGN, WM, WN>;
     static bool attr_set = false;
@@ -764,7 +972,9 @@ int launch_ksplit(const GemmParams& p, hipStream_t stream) {
     }
     const int tiles = ceil_div(p.M, bm) * ceil_div(p.N, bn);
     const int grid = min(tiles, num_cus() & ~7);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(2 * WGM * WGN * 64), lds, stream, p, tiles);
+    GemmParams pb = p;
+    pb.band = xcd_band(tiles, ceil_div(p.N, bn), grid, t);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(2 * WGM * WGN * 64), lds, stream, pb, tiles);
     LAUNCH_OK("gemm (k-split)");
     return 0;
 }
@@ -925,14 +1135,48 @@ bool use_ksplit(const GemmParams& p, const GemmTune& t, int cfg) {
     const int cus = num_cus() & ~7;
     const long rounds = (tiles + cus - 1) / cus;
     if (t.ksplit == 1 && rounds > 1) return false;          // 2: also problems of several rounds (measurement)
-    return p.K >= 1024 && 4 * tiles >= 3 * rounds * cus;    // the last round at least 3/4 full on average
+    return p.K >= t.ksplit_mink && 4 * tiles >= 3 * rounds * cus;    // the last round at least 3/4 full on average
+}
+
+// the staggered 8-wave kernel: 256x256 (configuration 4) and 320x256 (5), bf16 B, operands addressable with 31-bit byte offsets
+template <int EPI, int WM, int KSP>
+int launch_big8(const GemmParams& p, const GemmTune& t, hipStream_t stream) {
+    constexpr int bm = 2 * WM * 32, bn = 256, lds = 2 * (bm + bn) * 128;
+    auto kern = gemm8_kernel<EPI, WM, KSP>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+            pevit_set_error("hipFuncSetAttribute(staggered gemm epi %d) failed", EPI);
+            return -1;
+        }
+        attr_set = true;
+    }
+    const int tiles = ceil_div(p.M, bm) * ceil_div(p.N, bn);
+    int grid = tiles;
+    if (t.persistent && tiles > num_cus()) grid = num_cus();
+    GemmParams pb = p;
+    pb.band = xcd_band(tiles, ceil_div(p.N, bn), grid, t);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, pb, tiles);
+    LAUNCH_OK("gemm (staggered 8-wave)");
+    return 0;
+}
+bool big8_ok(const GemmParams& p, const GemmTune& t, int cfg) {
+    if (!t.stagger || (cfg != 4 && cfg != 5) || t.ablate > 3) return false;
+    const long long a = ((long long)p.M * p.lda + p.K) * 2, b = ((long long)p.Nb * p.ldb + p.K) * 2;
+    return a < (1LL << 31) && b < (1LL << 31);
 }
 
 template <int EPI, bool BF8>
 int launch_epi(const GemmParams& p, const GemmTune& t, hipStream_t stream) {
     const int cfg = pick_config(p, t);
+    if constexpr (!BF8) {
+        if (big8_ok(p, t, cfg)) {
+            if (cfg == 5) return t.ksp == 2 ? launch_big8<EPI, 5, 2>(p, t, stream) : launch_big8<EPI, 5, 1>(p, t, stream);
+            return t.ksp == 2 ? launch_big8<EPI, 4, 2>(p, t, stream) : launch_big8<EPI, 4, 1>(p, t, stream);
+        }
+    }
     if constexpr (!BF8 && (EPI == EPI_BIAS_RESID_F32 || EPI == EPI_F32 || EPI == EPI_BF16 || EPI == EPI_BIAS_RESID_KEEP || EPI == EPI_PATCH_EMBED)) {
-        if (use_ksplit(p, t, cfg)) return launch_ksplit<EPI, 1, 4, 5, 1>(p, stream);
+        if (use_ksplit(p, t, cfg)) return launch_ksplit<EPI, 1, 4, 5, 1>(p, t, stream);
         const SkPlan plan = streamk_plan(p, t, cfg);
         if (plan.share) return launch_streamk<EPI>(p, plan, stream);
     }

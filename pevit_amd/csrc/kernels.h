@@ -39,6 +39,7 @@ struct GemmParams {
     // stream-K workspace (gemm.hip gemm_streamk_kernel): one 128x128 f32 slab and one flag per residency slot, or null
     float* sk_slab; unsigned* sk_flag; int sk_slots;
     int sk_share, sk_band;   // set by the launcher: k-iterations per workgroup, m-tiles per band of the tile walk
+    int band;                // set by the launcher: m-tiles per band of gemm.hip tile_origin (0 = TILE_BAND)
 };
 
 // A/B-measurement knobs.  They live in the context (pevit_tune(ctx, ...)); the single-kernel pevit_op_* entry
@@ -53,6 +54,10 @@ struct GemmTune {
     int big_bias = 100;   // the 8-wave tile is taken when its stream cost is below big_bias % of the 128x128 tiling's
     int sk_share = 0, sk_band = 0;   // measurement (gemm_streamk = 2): k-iterations per stream-K workgroup, m-tiles per band
     int ksplit = 1;       // N = E long-K products with ~one 160x128 tile per CU: 8-wave tile, two wave groups on alternate k-tiles
+    int ksplit_mink = 1024;   // ... from this K on
+    int band = -1;        // >= 0 forces GemmParams::band of the one-round 8-wave launches (measurement); -1 = XCD-aligned
+    int stagger = 1;      // 8-wave tiles (bf16 B): the staggered two-group kernel (gemm8_kernel) instead of gemm_kernel
+    int ksp = 1;          // ... k-steps (of 16) per phase of that kernel: 1 or 2
     int streamk = 1;      // few-tile long-K problems: stream-K decomposition of the 128x128 tiling (needs GemmParams::sk_slab)
 };
 constexpr int PEVIT_SK_SLAB_FLOATS = 128 * 128;   // one partial tile per residency slot
