@@ -340,6 +340,25 @@ __global__ __launch_bounds__(WGM * WGN * 64, MINW) void gemm_kernel(GemmParams p
             if (nk > 0) issue_tile(0);
         }
         float* cw = reinterpret_cast<float*>(smem + STAGE_BYTES + wid * 4096);
+        // column constants (bias; fp8: channel scale of the accumulator) of this lane's 8 columns per fragment column j, loaded
+        // ONCE: a load between the stores below would make hipcc wait with vmcnt(0), which on gfx950 waits for the stores
+        // issued so far as well
+        float cc[WN][8], bs[WN][8];
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int col = cn0 + wn * WN * 32 + j * 32 + (lane & 3) * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { cc[j][e] = 0.f; bs[j][e] = 1.f; }
+            if (col < p.N) {
+                if constexpr (epi_has_pre<EPI>) epi_load_cols<EPI>(p, col, cc[j]);
+                if constexpr (BF8) {
+                    if (p.bscale) {
+                        const float4 b0 = *reinterpret_cast<const float4*>(p.bscale + col), b1 = *reinterpret_cast<const float4*>(p.bscale + col + 4);
+                        bs[j][0] = b0.x; bs[j][1] = b0.y; bs[j][2] = b0.z; bs[j][3] = b0.w; bs[j][4] = b1.x; bs[j][5] = b1.y; bs[j][6] = b1.z; bs[j][7] = b1.w;
+                    }
+                }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -361,8 +380,12 @@ __global__ __launch_bounds__(WGM * WGN * 64, MINW) void gemm_kernel(GemmParams p
                     const float4 x1 = *reinterpret_cast<const float4*>(cw + lr * 32 + lc + 4);
                     if (row < p.M && col < p.N && !GEMM_DBG(p, 2)) {
                         float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-                        if constexpr (BF8) { if (p.bscale) mul8(v, p.bscale + col); }
-                        epilogue_store<EPI, bf16>(p, row, col, v);
+                        if constexpr (BF8) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] *= bs[j][e];
+                        }
+                        if constexpr (epi_has_pre<EPI> && !epi_reads_aux<EPI>) epilogue_store_pre<EPI, bf16>(p, row, col, v, cc[j], cc[j]);
+                        else epilogue_store<EPI, bf16>(p, row, col, v);
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -415,7 +438,6 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmParams p, int ntiles)
     constexpr int KS = BK / 16, NPH = KS / KSP;          // MFMA k-steps per k-tile, phases per k-tile
     constexpr int ISSUE_PH = NPH > 1 ? NPH - 1 : 1;     // phases whose LOAD section carries LDS-DMA requests
     static_assert(PA * RPP * NW == BM && PB * RPP * NW == BN && NPH * KSP == KS, "tile geometry");
-    static_assert(STAGE_BYTES >= NW * 4096, "the epilogue borrows 4 KiB per wave of stage 1");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -475,6 +497,9 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmParams p, int ntiles)
         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         if (grp) __builtin_amdgcn_s_barrier();                      // the upper half runs one barrier behind
+        // (Tried: one dword per 128-byte line of the dGELU epilogue's saved-activation block requested here, so that the
+        // lines travel to the L2 under the k-loop.  In step the kernel got SLOWER, 42.4 vs 38.4 us: the requests compete
+        // with the operand stream and the lines are evicted again before the epilogue; profiles/r03_gemm_epilogues.md.)
         for (int kt = 0; kt < nk; ++kt) {
             const char* st = smem + (kt & 1) * STAGE_BYTES;
             const bool more = kt + 1 < nk;
@@ -519,7 +544,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmParams p, int ntiles)
         }
         if (!grp) __builtin_amdgcn_s_barrier();                     // ... and the lower half waits for it here
         // both stages are idle: stage 0 receives the next tile's first k-tile while the epilogue transposes through
-        // (this wave's 4 KiB of) stage 1
+        // (this wave's 8 KiB of) stage 1
         const int cm0 = m0, cn0 = n0;
         const int next = tile + gridDim.x;
         if (next < ntiles) {
@@ -530,34 +555,93 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmParams p, int ntiles)
                 for (int q = 0; q < NP; ++q) issue_piece(0, q);
             }
         }
-        float* cw = reinterpret_cast<float*>(smem + STAGE_BYTES + wid * 4096);
+        // Epilogue: a fragment ROW (32 x 64 = both fragments j) goes through this wave's 8 KiB of stage 1 and comes back as
+        // whole output rows: 8 lanes cover the 64 columns of a row = one 128-byte line of a bf16 output (two of an f32 one),
+        // 8 rows per pass.  (gemm_kernel's 32 x 32 transposes write half lines, 16 rows at a time.)  16-byte chunk c of row r
+        // sits at chunk c ^ (r & 1): the ds_read_b128 lane groups then touch every bank once.
+        // FAST path (this wave's 32*WM x 64 block lies inside the matrix, epilogue with column constants only): no branch
+        // and no load between the stores -- the column constants are loaded once, the saved activation of the dGELU
+        // epilogue one fragment row ahead -- so that every s_waitcnt the compiler places is an exact vmcnt(N).  With a
+        // bounds branch around each access it falls back to vmcnt(0) before every use of a loaded value, and on gfx950
+        // that also waits for all STORES issued so far: the dGELU epilogue then ran one store latency per pass, 24 us for
+        // 78 MB in step (profiles/r03_gemm_epilogues.md).
+        float* cw = reinterpret_cast<float*>(smem + STAGE_BYTES + wid * 8192);
+        static_assert(STAGE_BYTES >= NW * 8192, "the epilogue borrows 8 KiB per wave of stage 1");
+        const int erow = lane >> 3, ec8 = lane & 7;                    // pass-local row, 8-column group of this lane
+        const int gr0 = cm0 + wm * WM * 32, gc0 = cn0 + wn * WN * 32, gc = gc0 + ec8 * 8;
+        auto to_lds = [&](int i) {
 #pragma unroll
-        for (int i = 0; i < WM; ++i)
-#pragma unroll
-            for (int j = 0; j < WN; ++j) {
+            for (int j = 0; j < WN; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    cw[row * 32 + (lane & 31)] = acc[i][j][r];
+                    const int col = j * 32 + (lane & 31);
+                    cw[row * 64 + ((((col >> 2) ^ (row & 1)) << 2) | (col & 3))] = acc[i][j][r];
                 }
+        };
+        auto from_lds = [&](int ps, float (&v)[8]) {
+            const int lr = ps * 8 + erow;
+            const float4 x0 = *reinterpret_cast<const float4*>(cw + lr * 64 + (((2 * ec8) ^ (lr & 1)) << 2));
+            const float4 x1 = *reinterpret_cast<const float4*>(cw + lr * 64 + (((2 * ec8 + 1) ^ (lr & 1)) << 2));
+            v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+        };
+        const bool inside = gr0 + WM * 32 <= p.M && gc0 + WN * 32 <= p.N;        // wave-uniform
+        if (gc0 >= p.N || gr0 >= p.M || GEMM_DBG(p, 2)) {
+            // nothing of this wave's block is inside the matrix (the 64 adapter columns of the QKV product fill a quarter
+            // of their 256-column tile), or a measurement run without stores
+        } else if (epi_has_pre<EPI> && inside) {
+            if constexpr (epi_has_pre<EPI>) {
+                float cc[8];
+                epi_load_cols<EPI>(p, gc, cc);
+                bf16x8 aux_nxt[4];
+                auto load_aux = [&](int i) {
+                    if constexpr (epi_reads_aux<EPI>) {
+#pragma unroll
+                        for (int ps = 0; ps < 4; ++ps)
+                            aux_nxt[ps] = load_bf16x8(p.aux + (size_t)(gr0 + i * 32 + ps * 8 + erow) * p.ldaux + gc);
+                    }
+                };
+                load_aux(0);
+#pragma unroll
+                for (int i = 0; i < WM; ++i) {
+                    to_lds(i);
+                    float h[4][8];
+                    if constexpr (epi_reads_aux<EPI>) {
+#pragma unroll
+                        for (int ps = 0; ps < 4; ++ps)
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) h[ps][e] = bf2f(aux_nxt[ps][e]);
+                        if (i + 1 < WM) load_aux(i + 1);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                    for (int ps = 0; ps < 4; ++ps) {
+                        float v[8];
+                        from_lds(ps, v);
+                        epilogue_store_pre<EPI, bf16>(p, gr0 + i * 32 + ps * 8 + erow, gc, v, cc, h[ps]);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < WM; ++i) {
+                to_lds(i);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-                for (int pass = 0; pass < 2; ++pass) {
-                    const int lr = pass * 16 + (lane >> 2);
-                    const int lc = (lane & 3) * 8;
-                    const int row = cm0 + wm * WM * 32 + i * 32 + lr;
-                    const int col = cn0 + wn * WN * 32 + j * 32 + lc;
-                    const float4 x0 = *reinterpret_cast<const float4*>(cw + lr * 32 + lc);
-                    const float4 x1 = *reinterpret_cast<const float4*>(cw + lr * 32 + lc + 4);
-                    if (row < p.M && col < p.N && !GEMM_DBG(p, 2)) {
-                        float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-                        epilogue_store<EPI, bf16>(p, row, col, v);
-                    }
+                for (int ps = 0; ps < 4; ++ps) {
+                    const int row = gr0 + i * 32 + ps * 8 + erow;
+                    float v[8];
+                    from_lds(ps, v);
+                    if (row < p.M && gc < p.N) epilogue_store<EPI, bf16>(p, row, gc, v);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
+        }
         if (next >= ntiles) break;
         tile = next;
     }
@@ -846,6 +930,22 @@ __global__ __launch_bounds__(2 * WGM * WGN * 64, 1) void gemm_ksplit_kernel(Gemm
     constexpr bool PRE = (EPI == EPI_BIAS_RESID_F32 || EPI == EPI_BIAS_RESID_KEEP);
     constexpr int NOWN = PRE ? (WM * WN + 1) / 2 : 1;
     float4 rpre[NOWN][2][2];
+    // ... and the bias of this lane's 8 columns per fragment column j: a load between the stores of the epilogue makes
+    // hipcc wait with vmcnt(0), which on gfx950 waits for the STORES issued so far as well (one store latency per pass)
+    float bpre[WN][8];
+    if constexpr (PRE) {
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int col = n0 + wn * WN * 32 + j * 32 + (lane & 3) * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bpre[j][e] = 0.f;
+            if (col < p.N) {
+                const float4 b0 = *reinterpret_cast<const float4*>(p.bias + col), b1 = *reinterpret_cast<const float4*>(p.bias + col + 4);
+                bpre[j][0] = b0.x; bpre[j][1] = b0.y; bpre[j][2] = b0.z; bpre[j][3] = b0.w;
+                bpre[j][4] = b1.x; bpre[j][5] = b1.y; bpre[j][6] = b1.z; bpre[j][7] = b1.w;
+            }
+        }
+    }
     if constexpr (PRE) {
 #pragma unroll
         for (int i = 0; i < WM; ++i)
@@ -928,8 +1028,9 @@ __global__ __launch_bounds__(2 * WGM * WGN * 64, 1) void gemm_ksplit_kernel(Gemm
                 const float4 x1 = *reinterpret_cast<const float4*>(cw + lr * 32 + lc + 4);
                 if (row < p.M && col < p.N) {
                     float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-                    if constexpr (PRE) {          // epilogue_store<EPI_BIAS_RESID_*> with the residual already in registers
-                        add8(v, p.bias + col);
+                    if constexpr (PRE) {          // epilogue_store<EPI_BIAS_RESID_*> with the residual and the bias already in registers
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += bpre[j][e];
                         if constexpr (EPI == EPI_BIAS_RESID_KEEP) store8f(p.outf2 + (size_t)row * p.ldo2 + col, v);
                         const float4 r0 = rpre[(i * WN + j) >> 1][pass][0], r1 = rpre[(i * WN + j) >> 1][pass][1];
                         v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
@@ -1161,7 +1262,7 @@ int launch_big8(const GemmParams& p, const GemmTune& t, hipStream_t stream) {
     return 0;
 }
 bool big8_ok(const GemmParams& p, const GemmTune& t, int cfg) {
-    if (!t.stagger || (cfg != 4 && cfg != 5) || t.ablate > 3) return false;
+    if (!t.stagger || (cfg != 4 && cfg != 5) || (t.ablate & 12)) return false;
     const long long a = ((long long)p.M * p.lda + p.K) * 2, b = ((long long)p.Nb * p.ldb + p.K) * 2;
     return a < (1LL << 31) && b < (1LL << 31);
 }

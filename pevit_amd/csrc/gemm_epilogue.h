@@ -65,32 +65,53 @@ template <typename ST> __device__ __forceinline__ float as_stored(float x) {
     if constexpr (sizeof(ST) == 2) return bf2f(f2bf(x)); else return x;
 }
 
+// epilogues that read a saved activation (GemmParams::aux) at the output position
+template <int EPI> constexpr bool epi_reads_aux = (EPI == EPI_DGELU_BF16 || EPI == EPI_DRELU_BF16 || EPI == EPI_DGELUNEW_BF16);
+// epilogues whose only other operand is a per-column constant (bias / channel scale): the staggered 8-wave kernel loads
+// it ONCE per lane and runs these epilogues branch-free (epilogue_store_pre)
+template <int EPI> constexpr bool epi_has_pre = (EPI == EPI_QKV_HEADS || EPI == EPI_BIAS_GELU || EPI == EPI_DGELU_BF16);
+
+// column constants of the 8 columns col..col+7: the bias; for dGELU the channel scale folded into the output (1 when absent)
+template <int EPI>
+__device__ __forceinline__ void epi_load_cols(const GemmParams& p, int col, float c[8]) {
+    const float* src = nullptr;
+    float fill = 0.0f;
+    if constexpr (EPI == EPI_QKV_HEADS) { if (col < 3 * p.E) src = p.bias + col; }
+    else if constexpr (EPI == EPI_BIAS_GELU) src = p.bias + col;
+    else if constexpr (EPI == EPI_DGELU_BF16) { fill = 1.0f; if (p.oscale) src = p.oscale + col; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) c[i] = fill;
+    if (src) {
+        const float4 b0 = *reinterpret_cast<const float4*>(src), b1 = *reinterpret_cast<const float4*>(src + 4);
+        c[0] = b0.x; c[1] = b0.y; c[2] = b0.z; c[3] = b0.w; c[4] = b1.x; c[5] = b1.y; c[6] = b1.z; c[7] = b1.w;
+    }
+}
+
+// the epi_has_pre epilogues with their column constants (and, for dGELU, the saved activation h) already in registers: no
+// load, no data-dependent branch around a memory operation -- so that hipcc can count its s_waitcnt vmcnt(N) exactly
+// instead of falling back to vmcnt(0), which on gfx950 also waits for every STORE issued so far
 template <int EPI, typename ST>
-__device__ __forceinline__ void epilogue_store(const GemmParams& p, int row, int col, float v[8]) {
-    // row < M and col < N (col multiple of 8) are guaranteed by the caller.
+__device__ __forceinline__ void epilogue_store_pre(const GemmParams& p, int row, int col, float v[8], const float c[8], const float h[8]) {
+    static_assert(epi_has_pre<EPI>, "epilogue with further operands");
     if constexpr (EPI == EPI_QKV_HEADS) {
         const int E3 = 3 * p.E;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] += c[i];
         if (col < E3) {
-            add8(v, p.bias + col);
             const int which = col / p.E, ce = col - which * p.E;
-            const int h = ce >> 6, d = ce & 63;
+            const int hh = ce >> 6, d = ce & 63;
             const int b = row / p.Ntok, n = row - b * p.Ntok;
-            store8s<ST>(p.outb, (size_t)which * p.head_stride + ((size_t)(b * p.H + h) * p.Ntok + n) * 64 + d, v);
+            store8s<ST>(p.outb, (size_t)which * p.head_stride + ((size_t)(b * p.H + hh) * p.Ntok + n) * 64 + d, v);
         } else {
             store8f(p.outf + (size_t)row * p.ldo + (col - E3), v);
         }
-    } else if constexpr (EPI == EPI_BIAS_RESID_F32) {
-        add8(v, p.bias + col);
-        add8(v, p.resid + (size_t)row * p.ldr + col);
-        store8f(p.outf + (size_t)row * p.ldo + col, v);
     } else if constexpr (EPI == EPI_BIAS_GELU) {
-        add8(v, p.bias + col);
         float g[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             // QuickGELU (model.py:163-165) evaluated on the pre-activation AS STORED (bf16-rounded in production), which
             // is what the backward pass will see, so fwd and bwd agree on the same h.
-            v[i] = as_stored<ST>(v[i]);
+            v[i] = as_stored<ST>(v[i] + c[i]);
             g[i] = v[i] * sigmoidf_fast(1.702f * v[i]);
         }
         // the saved pre-activation is not read again before the backward pass: non-temporal store (+0.7 % per step)
@@ -103,19 +124,53 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int row, int
             store8s<ST>(p.outb, (size_t)row * p.ldob + col, v);
         }
         store8s<ST>(p.outb2, (size_t)row * p.ldob2 + col, g);
-    } else if constexpr (EPI == EPI_DGELU_BF16) {
-        float h[8];
-        load8s<ST>(p.aux, (size_t)row * p.ldaux + col, h);
+    } else {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const float hv = h[i];
             const float s = sigmoidf_fast(1.702f * hv);
-            v[i] = v[i] * (s * (1.0f + 1.702f * hv * (1.0f - s)));
+            // fp8 weights: the consumer (c_fc backward) contracts over these columns, whose power-of-two channel scales
+            // are folded into its A operand here (exact; c = 1 otherwise)
+            v[i] = v[i] * (s * (1.0f + 1.702f * hv * (1.0f - s))) * c[i];
         }
-        // fp8 weights: the consumer (c_fc backward) contracts over these columns, whose power-of-two
-        // channel scales are folded into its A operand here (exact)
-        if (p.oscale) mul8(v, p.oscale + col);
         store8s<ST>(p.outb, (size_t)row * p.ldob + col, v);
+    }
+}
+
+// ... the remaining aux epilogues (bottleneck adapters), activation in registers
+template <int EPI, typename ST>
+__device__ __forceinline__ void epilogue_store_aux(const GemmParams& p, int row, int col, float v[8], const float h[8]) {
+    static_assert(epi_reads_aux<EPI>, "epilogue without an aux operand");
+    if constexpr (EPI == EPI_DGELU_BF16) {
+        float c[8];
+        epi_load_cols<EPI>(p, col, c);
+        epilogue_store_pre<EPI, ST>(p, row, col, v, c, h);
+        return;
+    } else if constexpr (EPI == EPI_DRELU_BF16) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = h[i] > 0.f ? v[i] : 0.f;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = v[i] * gelu_new_grad_f(h[i]);
+    }
+    store8s<ST>(p.outb, (size_t)row * p.ldob + col, v);
+}
+
+template <int EPI, typename ST>
+__device__ __forceinline__ void epilogue_store(const GemmParams& p, int row, int col, float v[8]) {
+    // row < M and col < N (col multiple of 8) are guaranteed by the caller.
+    if constexpr (EPI == EPI_QKV_HEADS || EPI == EPI_BIAS_GELU) {
+        float c[8];
+        epi_load_cols<EPI>(p, col, c);
+        epilogue_store_pre<EPI, ST>(p, row, col, v, c, c);
+    } else if constexpr (EPI == EPI_BIAS_RESID_F32) {
+        add8(v, p.bias + col);
+        add8(v, p.resid + (size_t)row * p.ldr + col);
+        store8f(p.outf + (size_t)row * p.ldo + col, v);
+    } else if constexpr (epi_reads_aux<EPI>) {
+        float h[8];
+        load8s<ST>(p.aux, (size_t)row * p.ldaux + col, h);
+        epilogue_store_aux<EPI, ST>(p, row, col, v, h);
     } else if constexpr (EPI == EPI_F32) {
         store8f(p.outf + (size_t)row * p.ldo + col, v);
     } else if constexpr (EPI == EPI_BF16) {
@@ -144,18 +199,6 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int row, int
         }
         store8s<ST>(p.outb, (size_t)row * p.ldob + col, v);
         store8s<ST>(p.outb2, (size_t)row * p.ldob2 + col, g);
-    } else if constexpr (EPI == EPI_DRELU_BF16) {
-        float a[8];
-        load8s<ST>(p.aux, (size_t)row * p.ldaux + col, a);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = a[i] > 0.f ? v[i] : 0.f;
-        store8s<ST>(p.outb, (size_t)row * p.ldob + col, v);
-    } else if constexpr (EPI == EPI_DGELUNEW_BF16) {
-        float a[8];
-        load8s<ST>(p.aux, (size_t)row * p.ldaux + col, a);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = v[i] * gelu_new_grad_f(a[i]);
-        store8s<ST>(p.outb, (size_t)row * p.ldob + col, v);
     } else if constexpr (EPI == EPI_BIAS_RELU_BF16) {
         add8(v, p.bias + col);
 #pragma unroll

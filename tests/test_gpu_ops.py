@@ -80,13 +80,16 @@ def test_gemm_every_tile_config_is_bit_identical(lib, cfg, M, N, K):
     outs = []
     for c in (cfg, -1):
         assert lib.pevit_tune(None, b"gemm_config", c) == 0
+        # the heuristic's k-split tile (two wave groups on alternate k-tiles) changes the summation split: close, not equal
+        # (test_gemm_streamk_hand_off holds it to the torch product); here the comparison is between plain tilings
+        assert lib.pevit_tune(None, b"gemm_ksplit", 0) == 0
         try:
             o1 = torch.full((M, N), float("nan"), device="cuda")
             gemm(lib, EPI["BIAS_RESID"], A, B, M, N, K, bias=bias, resid=resid, outf=o1)
             h = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda"); g = torch.zeros_like(h)
             gemm(lib, EPI["BIAS_GELU"], A, B, M, N, K, bias=bias, outb=h, outb2=g)
         finally:
-            lib.pevit_tune(None, b"gemm_config", -1)
+            lib.pevit_tune(None, b"gemm_config", -1); lib.pevit_tune(None, b"gemm_ksplit", 1)
         outs.append((o1, h, g))
     assert max_rel(outs[0][0].cpu(), (ref + bias + resid).cpu()) < 2e-4
     for a, b in zip(*outs):
