@@ -361,3 +361,11 @@ class EmulTrainer(R.OracleTrainer):
         feat = visual_forward(images, self.p, self.method)
         out = F.batch_norm(feat, self.bn.running_mean, self.bn.running_var, None, None, self.bn.training, 0.1, 1e-5)
         return F.linear(out, self.head_w, self.head_b)
+
+
+def transformer_forward(x, p, layers, heads, method):
+    """The (N,B,E) -> (N,B,E) seam of pevit_transformer_forward (all rows of every block; no class-token pruning)."""
+    wcache = make_wcache(p)
+    for i in range(layers):
+        x = block(x, p, i, heads, method, wcache)
+    return x

@@ -1192,6 +1192,7 @@ extern "C" int pevit_tune(pevit_ctx* c, const char* key, int value) {
     if (key && !strcmp(key, "gemm_sk_share")) { t.sk_share = value; return 0; }
     if (key && !strcmp(key, "gemm_sk_band")) { t.sk_band = value; return 0; }
     if (key && !strcmp(key, "gemm_ksplit")) { t.ksplit = value; return 0; }
+    if (key && !strcmp(key, "gemm_ksplit_stagger")) { t.ksplit_stagger = value; return 0; }
     if (key && !strcmp(key, "gemm_ksplit_mink")) { t.ksplit_mink = value; return 0; }
     if (key && !strcmp(key, "gemm_band")) { t.band = value; return 0; }
     if (key && !strcmp(key, "gemm_stagger")) { t.stagger = value; return 0; }

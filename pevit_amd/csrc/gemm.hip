@@ -871,7 +871,7 @@ __global__ __launch_bounds__(256, 2) void gemm_streamk_kernel(GemmParams p, int 
 // tile or the per-wave fragment block.  Each group double-buffers its own k-tiles (4 LDS stages in all); one workgroup
 // barrier per pair of k-tiles; at the end the two partial sums (even k-tiles, odd k-tiles) meet through LDS, every 32x32
 // fragment being finished and stored by one of the two groups.
-template <int EPI, int WGM, int WGN, int WM, int WN>
+template <int EPI, int WGM, int WGN, int WM, int WN, bool STAG>
 __global__ __launch_bounds__(2 * WGM * WGN * 64, 1) void gemm_ksplit_kernel(GemmParams p, int ntiles) {
     constexpr int NWG = WGM * WGN;                         // waves per group
     constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32, BK = 64;
@@ -966,10 +966,18 @@ __global__ __launch_bounds__(2 * WGM * WGN * 64, 1) void gemm_ksplit_kernel(Gemm
             }
     }
     const int iters = (nk + 1) >> 1;
+    // STAG: group 1 runs ONE barrier behind group 0 (two barriers per pair of k-tiles).  A group requests its next k-tile
+    // right after its own barrier and needs it two barriers later, so the requests of the two groups reach the L2 half an
+    // iteration apart and one group's are in flight while the other's are issued: the operand stream -- what bounds these
+    // products, 1.77 MB per CU at <= 32 B/clk -- no longer drains to empty at every iteration boundary (unstaggered, every
+    // wave waits for its k-tile, crosses the barrier, and only then are the next requests issued: one L2 latency per
+    // iteration with nothing in flight).  Also the two waves of a SIMD no longer want the matrix pipe at the same time.
+    if (STAG && grp) __builtin_amdgcn_s_barrier();
     for (int it = 0; it < iters; ++it) {
         const int kt = 2 * it + grp;
-        wait_vmcnt<0>();
-        __syncthreads();                                   // both groups' k-tiles have landed; the other stages are free
+        wait_vmcnt<0>();                                   // this wave's pieces of k-tile kt have landed
+        if constexpr (STAG) __builtin_amdgcn_s_barrier();  // ... and those of the other waves of the group; the group's other stage is free
+        else __syncthreads();                              // both groups' k-tiles have landed; the other stages are free
         if (kt + 2 < nk) issue_tile(kt + 2, (it + 1) & 1);
         if (kt < nk) {
             const char* sa = gbase + (it & 1) * STAGE_BYTES;
@@ -988,7 +996,12 @@ __global__ __launch_bounds__(2 * WGM * WGN * 64, 1) void gemm_ksplit_kernel(Gemm
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
             }
         }
+        if constexpr (STAG) {
+            __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): the stage this group just read may be requested again
+            __builtin_amdgcn_s_barrier();                  // (the other group's top-of-iteration barrier)
+        }
     }
+    if (STAG && !grp) __builtin_amdgcn_s_barrier();
     __syncthreads();
     // ---- the two partial sums meet through LDS: fragment f = i * WN + j is FINISHED by group f % 2, which receives the other
     // group's partial at hand[((gw * NF + f) * 16 + r) * 64 + lane] and runs that fragment's epilogue -- both groups store
@@ -1059,10 +1072,10 @@ int xcd_band(int tiles, int tiles_n, int grid, const GemmTune& t) {
     return 0;
 }
 
-template <int EPI, int WGM, int WGN, int WM, int WN>
+template <int EPI, int WGM, int WGN, int WM, int WN, bool STAG>
 int launch_ksplit(const GemmParams& p, const GemmTune& t, hipStream_t stream) {
     constexpr int bm = WGM * WM * 32, bn = WGN * WN * 32, lds = 4 * (bm + bn) * 128;
-    auto kern = gemm_ksplit_kernel<EPI, WGM, WGN, WM, WN>;
+    auto kern = gemm_ksplit_kernel<EPI, WGM, WGN, WM, WN, STAG>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
@@ -1277,7 +1290,8 @@ int launch_epi(const GemmParams& p, const GemmTune& t, hipStream_t stream) {
         }
     }
     if constexpr (!BF8 && (EPI == EPI_BIAS_RESID_F32 || EPI == EPI_F32 || EPI == EPI_BF16 || EPI == EPI_BIAS_RESID_KEEP || EPI == EPI_PATCH_EMBED)) {
-        if (use_ksplit(p, t, cfg)) return launch_ksplit<EPI, 1, 4, 5, 1>(p, t, stream);
+        if (use_ksplit(p, t, cfg))
+            return t.ksplit_stagger ? launch_ksplit<EPI, 1, 4, 5, 1, true>(p, t, stream) : launch_ksplit<EPI, 1, 4, 5, 1, false>(p, t, stream);
         const SkPlan plan = streamk_plan(p, t, cfg);
         if (plan.share) return launch_streamk<EPI>(p, plan, stream);
     }

@@ -93,6 +93,8 @@ def test_gemm_fp8_is_bit_identical_to_bf16_on_dequantised_weights(lib, cfg, M, N
     Wb[:N] = Wd.to(torch.bfloat16)
     assert torch.equal(Wb[:N].float(), Wd)
     assert lib.pevit_tune(None, b"gemm_config", cfg) == 0
+    # same GEMM decomposition on both sides: the k-split tile (two wave groups on alternate k-tiles) exists for bf16 weights only
+    assert lib.pevit_tune(None, b"gemm_ksplit", 0) == 0
     try:
         def both(epi, **kw):
             outs = []
@@ -124,7 +126,7 @@ def test_gemm_fp8_is_bit_identical_to_bf16_on_dequantised_weights(lib, cfg, M, N
         f, b = both(EPI["DGELU"], outb=z16, aux=aux)
         assert torch.equal(f["outb"], b["outb"])
     finally:
-        lib.pevit_tune(None, b"gemm_config", -1)
+        lib.pevit_tune(None, b"gemm_config", -1); lib.pevit_tune(None, b"gemm_ksplit", 1)
 
 
 def test_backward_form_column_scales_ride_on_the_a_operand(lib):
