@@ -42,6 +42,10 @@ def train_gflop_per_image(E, L, P, R, D, C, rank, attention_site=True):
 
 
 PEAK_TFLOPS_BF16 = 2500.0     # dense MFMA bf16, MI355X_MICROARCH.md
+CPU_BASELINE_THREADS = 32     # best of the sweep 8/16/32/64/128 on the GPU box's host (profiles/r03_cpu_thread_sweep.md)
+EPI_NAMES = {0: "qkv(+t) -> head layout", 1: "bias+residual f32", 2: "bias+QuickGELU", 3: "dQuickGELU", 4: "f32", 5: "bf16",
+             6: "bias bf16", 7: "patch embed", 8: "bias+ReLU", 9: "bias+residual (keep h)", 10: "bias+gelu_new",
+             11: "dReLU", 12: "dgelu_new"}
 
 
 def cpu_baseline(seconds_budget=25.0):
@@ -49,9 +53,10 @@ def cpu_baseline(seconds_budget=25.0):
     host cores: BASELINE config 1 (ViT-B/32 + KAdaptation, fp32, bs=32), bounded sample."""
     from oracle import ref_cpu
     from pevit_amd.synth import ARCHS, synth_batch, synth_state_dict
-    # one intra-op thread per core is pathological on a 256-core host (measured 166 s/step);
-    # 16 threads is where the reference's eager fp32 step stops scaling.
-    cores = min(16, os.cpu_count() or 1)
+    # Thread count: profiles/r03_cpu_thread_sweep.md (python bench.py --cpu-sweep on the GPU box's host) -- the eager fp32
+    # step of the reference scales to a few dozen threads and then falls apart (one intra-op thread per logical core of a
+    # 256-thread host: minutes per step); PEVIT_CPU_THREADS overrides.
+    cores = int(os.environ.get("PEVIT_CPU_THREADS", "0")) or min(CPU_BASELINE_THREADS, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     arch = ARCHS["ViT-B/32"]
     sd = {k: v for k, v in synth_state_dict(arch, seed=2, text_tower=False).items() if k.startswith("visual.")}
@@ -141,6 +146,7 @@ def main():
     ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8"],
                     help="frozen block weights: bf16, or e4m3 codes + per-channel scales (BASELINE config 5 with --arch ViT-L/14)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sweep", action="store_true", help="only time the CPU baseline at 8/16/32/64/128 threads and exit")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=INT",
                     help="library tuning knob for A/B runs, e.g. gemm_big=0 (see pevit_tune)")
     ap.add_argument("--dist-backend", default="nccl", help="(tests only) process-group backend; RCCL refuses two ranks on one device, "
@@ -151,6 +157,13 @@ def main():
                          "WRITE_SIZE counters of the same rocprofv3 pass can be calibrated (scripts/pmc_traffic.py)")
     args = ap.parse_args()
 
+    if args.cpu_sweep:
+        for n in (8, 16, 32, 64, 128):
+            if n <= (os.cpu_count() or 1):
+                os.environ["PEVIT_CPU_THREADS"] = str(n)
+                r = cpu_baseline(seconds_budget=20.0)
+                print(json.dumps({"threads": n, "images_per_sec": r["value"], "sample": r["sample"]}), flush=True)
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -204,6 +217,9 @@ def main():
         torch.cuda.synchronize()
         del src, dst16
 
+    if world > 1:
+        eng.sync_replicas()      # parameters, momentum and BatchNorm buffers of rank 0 on every rank, as a real run starts
+
     def step():
         return eng.train_step(images, labels, lr=0.01, momentum=0.9, weight_decay=1e-6, world_size=world)
 
@@ -219,6 +235,7 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
+    print(f"[bench rank {rank}/{world}] {dt / args.steps * 1e3:.3f} ms/step", file=sys.stderr, flush=True)   # stragglers show here
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -242,6 +259,14 @@ def main():
         algo_bytes = eng.last_profile_bytes / max(gemm_launches, 1)
         traffic, traffic_how = pmc_traffic(args.arch, args.method, args.batch) if args.weights == "bf16" else (None, "no PMC pass for fp8 weights")
         attainable = measured_attainable_peak(dev)
+        # the GEMM launches of a step by (epilogue, M, N, K), largest share of the time first: which product is furthest
+        # from the peak
+        per_kernel = []
+        for (epi, M, N, K), (cnt, ms_k, fl_k) in sorted(eng.last_profile_by_shape.items(), key=lambda kv: -kv[1][1])[:8]:
+            per_kernel.append({"epilogue": EPI_NAMES.get(epi, str(epi)), "M": M, "N": N, "K": K,
+                               "launches_per_step": cnt / prof_steps, "avg_us": ms_k * 1e3 / cnt,
+                               "share_of_gemm_time": ms_k / gemm_ms, "tflops": fl_k / (ms_k * 1e-3) / 1e12,
+                               "frac": fl_k / (ms_k * 1e-3) / 1e12 / PEAK_TFLOPS_BF16})
         headline = (args.arch, args.method, args.batch, args.weights) == ("ViT-B/32", "kadaptation", 128, "bf16")
         metric = "images/sec fine-tune, CLIP ViT-B/32 + KAdaptation, bs=128, 1/2/4/8 GPU" if headline else \
             f"images/sec fine-tune, CLIP {args.arch} + {args.method}, bs={args.batch}/GPU, {args.weights} weights"
@@ -249,7 +274,9 @@ def main():
             "metric": metric,
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
+            # the arithmetic type of the path: bf16 operands on the bf16 MFMA, f32 accumulate; with --weights fp8 the frozen
+            # weights are e4m3 codes converted to bf16 in the GEMM (the activation side stays bf16)
+            "dtype": "bf16" if args.weights == "bf16" else "bf16 x fp8-e4m3 weights", "data": "synthetic",
             "config": {"workload": f"CLIP {args.arch} + {args.method} fine-tune step (fwd+CE+bwd+SGD), "
                                    f"{args.batch} images/GPU 3x{arch.resolution}x{arch.resolution}, C={classes}, "
                                    f"synthetic OpenAI-layout checkpoint, adapters at reference init, frozen block "
@@ -266,6 +293,7 @@ def main():
                          "kernels_hash": kernels_hash(),
                          "traffic_how": traffic_how, "algorithmic_bytes_per_launch": algo_bytes,
                          "launches_per_step": gemm_launches / prof_steps,
+                         "per_kernel": per_kernel,
                          "avg_launch_us": gemm_ms * 1e3 / max(gemm_launches, 1),
                          "gemm_ms_per_step": gemm_ms / prof_steps,
                          "flops_per_launch": gemm_flops / max(gemm_launches, 1),

@@ -20,9 +20,11 @@
  *   pevit_load_block / pevit_load_stem      build_model's load_state_dict  model.py:1247-1250
  *
  * Conventions: extern "C"; every function returns 0 on success and a negative value on error
- * (pevit_last_error() gives the message); nothing throws; no device-memory allocation, ever
+ * (pevit_last_error() gives the message); nothing throws; no device-memory allocation by any context entry point
  * (the optional "side_stream" knob creates one stream + two events on first use, profiling its
- * events in pevit_profile_begin) -- all device memory (weight arena, workspace, parameter and gradient
+ * events in pevit_profile_begin; the CONTEXT-FREE test entry point pevit_op_gemm allocates a stream-K workspace of its own
+ * on first use, once per process).  One process drives one device: the kernel attributes and the CU count are cached
+ * per process -- all device memory (weight arena, workspace, parameter and gradient
  * buffers) is owned by the caller and only borrowed; all work is enqueued asynchronously on
  * the caller's hipStream_t (passed as void*); contexts are independent of each other (no
  * mutable process-wide state on the hot path; tuning knobs live in the context) but one context
@@ -147,6 +149,8 @@ int pevit_train_forward_backward(pevit_ctx* ctx, void* stream, const float* imag
  * family); totals over the launches recorded between begin and end ---------------------------- */
 int pevit_profile_begin(pevit_ctx* ctx, int max_launches);
 int pevit_profile_end(pevit_ctx* ctx, double* total_ms, double* total_flops, double* total_bytes, int* launches);
+/* launch i (0 <= i < *launches of the last pevit_profile_end): its duration, 2*M*N*K and {epilogue, M, N, K} */
+int pevit_profile_launch(pevit_ctx* ctx, int i, double* ms, double* flops, int* epi_mnk);
 
 /* ---- single kernels, exposed for parity tests and profiling ------------------------- */
 int pevit_op_gemm(void* stream, int epilogue, const void* A_bf16, int lda, const void* B_bf16, int ldb, int b_rows,

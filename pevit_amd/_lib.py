@@ -55,6 +55,7 @@ SIGNATURES = {
     "pevit_train_forward_backward": (c_int, [P, P, P, P, P, P, c_int, P, P, c_int]),
     "pevit_profile_begin": (c_int, [P, c_int]),
     "pevit_profile_end": (c_int, [P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_int)]),
+    "pevit_profile_launch": (c_int, [P, c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_int)]),
     "pevit_op_gemm": (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, c_int,
                               P, c_int, P, c_int, P, c_int, c_size_t, c_int, c_int, c_int]),
     "pevit_op_gemm_fp8": (c_int, [P, c_int, P, c_int, P, c_int, c_int, P, P, c_int, c_int, c_int, P, P, c_int, P, c_int,

@@ -95,6 +95,8 @@ struct pevit_ctx {
     hipEvent_t* prof_ev = nullptr;      // 2 per launch
     double* prof_flops = nullptr;
     double* prof_bytes = nullptr;       // algorithmic operand + result bytes of each launch
+    float* prof_ms = nullptr;           // filled by pevit_profile_end
+    int* prof_shape = nullptr;          // epilogue, M, N, K of each launch
     // second stream for work that is off the backward critical path (adapter-gradient contractions); created on
     // first use, so that contexts can still be sized on machines without a GPU
     hipStream_t side = nullptr;
@@ -311,6 +313,8 @@ extern "C" void pevit_ctx_destroy(pevit_ctx* c) {
     delete[] c->prof_ev;
     delete[] c->prof_flops;
     delete[] c->prof_bytes;
+    delete[] c->prof_ms;
+    delete[] c->prof_shape;
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->side) (void)hipStreamDestroy(c->side);
@@ -492,6 +496,8 @@ int gemm(pevit_ctx* c, int epi, const GemmParams& p_in, hipStream_t s) {
     if (rec) {
         (void)hipEventRecord(c->prof_ev[2 * c->prof_n + 1], s);
         c->prof_flops[c->prof_n] = 2.0 * (double)p.M * (double)p.N * (double)p.K;
+        int* sh = c->prof_shape + 4 * c->prof_n;
+        sh[0] = epi; sh[1] = p.M; sh[2] = p.N; sh[3] = p.K;
         // every operand read once, every result written once (the minimum any schedule must move)
         const double mn = (double)p.M * (double)p.N;
         c->prof_bytes[c->prof_n] = 2.0 * ((double)p.M + (double)p.N) * (double)p.K + (p.bias ? 4.0 * p.N : 0.0) +
@@ -855,8 +861,9 @@ extern "C" int pevit_zero_grads(pevit_ctx* c, void* stream) {
 extern "C" int pevit_sgd_step(pevit_ctx* c, void* stream, float lr, float momentum, float wd, float grad_scale,
                               int flags) {
     if (!c || !c->params || !c->grads || !c->mom) { pevit_set_error("sgd_step: parameters/momentum not set"); return -1; }
+    const unsigned* poison = (c->ws && c->sk_slots) ? at<unsigned>(c->ws, c->w_skflag) + c->sk_slots : nullptr;
     return pevit_launch_sgd(c->params, c->grads, c->mom, c->grad_mask, c->n_total, lr, momentum, wd, flags,
-                            grad_scale, (hipStream_t)stream);
+                            grad_scale, (hipStream_t)stream, poison);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1006,11 +1013,13 @@ extern "C" int pevit_profile_begin(pevit_ctx* c, int max_launches) {
     if (!c || max_launches <= 0) { pevit_set_error("profile_begin: bad argument"); return -1; }
     if (c->prof_cap < max_launches) {
         for (int i = 0; i < 2 * c->prof_cap; ++i) (void)hipEventDestroy(c->prof_ev[i]);
-        delete[] c->prof_ev; delete[] c->prof_flops; delete[] c->prof_bytes;
+        delete[] c->prof_ev; delete[] c->prof_flops; delete[] c->prof_bytes; delete[] c->prof_ms; delete[] c->prof_shape;
         c->prof_ev = new (std::nothrow) hipEvent_t[2 * max_launches];
         c->prof_flops = new (std::nothrow) double[max_launches];
         c->prof_bytes = new (std::nothrow) double[max_launches];
-        if (!c->prof_ev || !c->prof_flops || !c->prof_bytes) { pevit_set_error("profile_begin: out of host memory"); return -1; }
+        c->prof_ms = new (std::nothrow) float[max_launches];
+        c->prof_shape = new (std::nothrow) int[4 * max_launches];
+        if (!c->prof_ev || !c->prof_flops || !c->prof_bytes || !c->prof_ms || !c->prof_shape) { pevit_set_error("profile_begin: out of host memory"); return -1; }
         for (int i = 0; i < 2 * max_launches; ++i) HIP_OK(hipEventCreate(&c->prof_ev[i]));
         c->prof_cap = max_launches;
     }
@@ -1026,12 +1035,22 @@ extern "C" int pevit_profile_end(pevit_ctx* c, double* total_ms, double* total_f
         HIP_OK(hipEventSynchronize(c->prof_ev[2 * i + 1]));
         float t = 0.f;
         HIP_OK(hipEventElapsedTime(&t, c->prof_ev[2 * i], c->prof_ev[2 * i + 1]));
+        c->prof_ms[i] = t;
         ms += t; fl += c->prof_flops[i]; by += c->prof_bytes[i];
     }
     if (total_ms) *total_ms = ms;
     if (total_flops) *total_flops = fl;
     if (total_bytes) *total_bytes = by;
     if (launches) *launches = c->prof_n;
+    return 0;
+}
+
+// launch i of the last begin/end pair: duration, 2*M*N*K, and {epilogue, M, N, K}
+extern "C" int pevit_profile_launch(pevit_ctx* c, int i, double* ms, double* flops, int* epi_mnk) {
+    if (!c || c->prof_on || i < 0 || i >= c->prof_n) { pevit_set_error("profile_launch: no such recorded launch"); return -1; }
+    if (ms) *ms = c->prof_ms[i];
+    if (flops) *flops = c->prof_flops[i];
+    if (epi_mnk) for (int k = 0; k < 4; ++k) epi_mnk[k] = c->prof_shape[4 * i + k];
     return 0;
 }
 
@@ -1192,11 +1211,11 @@ extern "C" int pevit_tune(pevit_ctx* c, const char* key, int value) {
     if (key && !strcmp(key, "gemm_sk_share")) { t.sk_share = value; return 0; }
     if (key && !strcmp(key, "gemm_sk_band")) { t.sk_band = value; return 0; }
     if (key && !strcmp(key, "gemm_ksplit")) { t.ksplit = value; return 0; }
+    if (key && !strcmp(key, "gemm_ksplit_small")) { t.ksplit_small = value; return 0; }
     if (key && !strcmp(key, "gemm_ksplit_stagger")) { t.ksplit_stagger = value; return 0; }
     if (key && !strcmp(key, "gemm_ksplit_mink")) { t.ksplit_mink = value; return 0; }
     if (key && !strcmp(key, "gemm_band")) { t.band = value; return 0; }
     if (key && !strcmp(key, "gemm_stagger")) { t.stagger = value; return 0; }
-    if (key && !strcmp(key, "gemm_ksp")) { t.ksp = value; return 0; }
     if (key && c && !strcmp(key, "dx_stored")) { c->dx_stored = value; return 0; }
     pevit_set_error("tune: unknown key %s", key ? key : "(null)");
     return -1;

@@ -428,45 +428,48 @@ __device__ __forceinline__ void buffer_lds16(const void* base, int bytes, char* 
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_ptr)lds_wave_base, 16, voff, soff, 0, 0);
 }
 
-template <int EPI, int WM, int KSP>
+template <int EPI, int WGM, int WGN, int WM, int WN, int KSP>
 __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmParams p, int ntiles) {
-    constexpr int WGN = 4, WN = 2, NW = 8;
-    constexpr int BM = 2 * WM * 32, BN = WGN * WN * 32, BK = 64;
+    constexpr int NW = 8;
+    static_assert(WGM * WGN == NW && (WN == 1 || WN == 2), "eight waves; one or two fragment columns per wave");
+    constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32, BK = 64;
     constexpr int ROWB = 128, CH = 8, RPP = 8;
     constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE_BYTES = A_BYTES + B_BYTES;
-    constexpr int PA = BM / RPP / NW, PB = BN / RPP / NW, NP = PA + PB;
+    constexpr int PA_T = BM / RPP, NPT = (BM + BN) / RPP, NP = (NPT + NW - 1) / NW;   // A pieces, pieces per k-tile, per wave
     constexpr int KS = BK / 16, NPH = KS / KSP;          // MFMA k-steps per k-tile, phases per k-tile
     constexpr int ISSUE_PH = NPH > 1 ? NPH - 1 : 1;     // phases whose LOAD section carries LDS-DMA requests
-    static_assert(PA * RPP * NW == BM && PB * RPP * NW == BN && NPH * KSP == KS, "tile geometry");
+    static_assert(BM % RPP == 0 && BN % RPP == 0 && NPH * KSP == KS, "tile geometry");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int grp = wid >> 2, wm = grp, wn = wid & 3;
+    const int grp = wid >> 2, wm = wid / WGN, wn = wid % WGN;      // stagger groups: waves 0-3 / 4-7, whatever the wave grid
 
     // (rows - 1) * pitch + K elements are readable; the launcher has checked that both fit 31 bits
     const int a_bytes = ((p.M - 1) * p.lda + p.K) * 2, b_bytes = ((p.Nb - 1) * p.ldb + p.K) * 2;
-    int a_voff[PA], b_voff[PB];
+    // 1 KiB pieces (8 rows x 128 bytes) of a k-tile: [0, PA_T) = A, then B; wave w requests the pieces w, w + 8, ... (a tile
+    // whose piece count is no multiple of 8 -- 160x256: 52 -- leaves the last round to the first waves)
+    int voff[NP];
     auto set_sources = [&](int m0, int n0) {
 #pragma unroll
-        for (int i = 0; i < PA; ++i) {
-            const int row = (wid * PA + i) * RPP + lane / CH;
+        for (int i = 0; i < NP; ++i) {
+            const int q = i * NW + wid;                       // wave-uniform
+            const bool is_a = q < PA_T;
+            const int rb = is_a ? q : q - PA_T;
+            const int row = rb * RPP + lane / CH;
             const int chunk = (lane % CH) ^ ((row >> 1) & (CH - 1));
-            int ar = m0 + row; ar = ar < p.M ? ar : p.M - 1;
-            a_voff[i] = ar * (p.lda * 2) + chunk * 16;
-        }
-#pragma unroll
-        for (int i = 0; i < PB; ++i) {
-            const int row = (wid * PB + i) * RPP + lane / CH;
-            const int chunk = (lane % CH) ^ ((row >> 1) & (CH - 1));
-            int br = n0 + row; br = br < p.Nb ? br : p.Nb - 1;
-            b_voff[i] = br * (p.ldb * 2) + chunk * 16;
+            int r = (is_a ? m0 : n0) + row;
+            const int lim = is_a ? p.M : p.Nb;
+            r = r < lim ? r : lim - 1;
+            voff[i] = r * ((is_a ? p.lda : p.ldb) * 2) + chunk * 16;
         }
     };
-    auto issue_piece = [&](int kt, int q) {
+    auto issue_piece = [&](int kt, int i) {
 #if GEMM8_ABLATE != 4   // measurement builds: 4 = no operand stream, 8 = no ds_read / MFMA
-        char* dst = smem + (kt & 1) * STAGE_BYTES;
-        if (q < PA) buffer_lds16(p.A, a_bytes, dst + (wid * PA + q) * 1024, a_voff[q], kt * 128);
-        else buffer_lds16(p.B, b_bytes, dst + A_BYTES + (wid * PB + q - PA) * 1024, b_voff[q - PA], kt * 128);
+        const int q = i * NW + wid;
+        if ((NPT % NW) && q >= NPT) return;
+        char* dst = smem + (kt & 1) * STAGE_BYTES + q * 1024;
+        if (q < PA_T) buffer_lds16(p.A, a_bytes, dst, voff[i], kt * 128);
+        else buffer_lds16(p.B, b_bytes, dst, voff[i], kt * 128);
 #endif
     };
     const int frow = lane & 31, fswz = (frow >> 1) & (CH - 1), fhalf = lane >> 5;
@@ -565,9 +568,10 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmParams p, int ntiles)
         // bounds branch around each access it falls back to vmcnt(0) before every use of a loaded value, and on gfx950
         // that also waits for all STORES issued so far: the dGELU epilogue then ran one store latency per pass, 24 us for
         // 78 MB in step (profiles/r03_gemm_epilogues.md).
-        float* cw = reinterpret_cast<float*>(smem + STAGE_BYTES + wid * 8192);
-        static_assert(STAGE_BYTES >= NW * 8192, "the epilogue borrows 8 KiB per wave of stage 1");
-        const int erow = lane >> 3, ec8 = lane & 7;                    // pass-local row, 8-column group of this lane
+        constexpr int COLS = WN * 32, LPR = COLS / 8, RPASS = 64 / LPR, NPASS = 32 / RPASS;   // lanes per row, rows per pass, passes
+        float* cw = reinterpret_cast<float*>(smem + STAGE_BYTES + wid * (32 * COLS * 4));
+        static_assert(STAGE_BYTES >= NW * 32 * COLS * 4, "the epilogue borrows 32 x COLS floats per wave of stage 1");
+        const int erow = lane / LPR, ec8 = lane % LPR;                 // pass-local row, 8-column group of this lane
         const int gr0 = cm0 + wm * WM * 32, gc0 = cn0 + wn * WN * 32, gc = gc0 + ec8 * 8;
         auto to_lds = [&](int i) {
 #pragma unroll
@@ -576,13 +580,13 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmParams p, int ntiles)
                 for (int r = 0; r < 16; ++r) {
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     const int col = j * 32 + (lane & 31);
-                    cw[row * 64 + ((((col >> 2) ^ (row & 1)) << 2) | (col & 3))] = acc[i][j][r];
+                    cw[row * COLS + ((((col >> 2) ^ (row & 1)) << 2) | (col & 3))] = acc[i][j][r];
                 }
         };
         auto from_lds = [&](int ps, float (&v)[8]) {
-            const int lr = ps * 8 + erow;
-            const float4 x0 = *reinterpret_cast<const float4*>(cw + lr * 64 + (((2 * ec8) ^ (lr & 1)) << 2));
-            const float4 x1 = *reinterpret_cast<const float4*>(cw + lr * 64 + (((2 * ec8 + 1) ^ (lr & 1)) << 2));
+            const int lr = ps * RPASS + erow;
+            const float4 x0 = *reinterpret_cast<const float4*>(cw + lr * COLS + (((2 * ec8) ^ (lr & 1)) << 2));
+            const float4 x1 = *reinterpret_cast<const float4*>(cw + lr * COLS + (((2 * ec8 + 1) ^ (lr & 1)) << 2));
             v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
         };
         const bool inside = gr0 + WM * 32 <= p.M && gc0 + WN * 32 <= p.N;        // wave-uniform
@@ -593,22 +597,22 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmParams p, int ntiles)
             if constexpr (epi_has_pre<EPI>) {
                 float cc[8];
                 epi_load_cols<EPI>(p, gc, cc);
-                bf16x8 aux_nxt[4];
+                bf16x8 aux_nxt[NPASS];
                 auto load_aux = [&](int i) {
                     if constexpr (epi_reads_aux<EPI>) {
 #pragma unroll
-                        for (int ps = 0; ps < 4; ++ps)
-                            aux_nxt[ps] = load_bf16x8(p.aux + (size_t)(gr0 + i * 32 + ps * 8 + erow) * p.ldaux + gc);
+                        for (int ps = 0; ps < NPASS; ++ps)
+                            aux_nxt[ps] = load_bf16x8(p.aux + (size_t)(gr0 + i * 32 + ps * RPASS + erow) * p.ldaux + gc);
                     }
                 };
                 load_aux(0);
 #pragma unroll
                 for (int i = 0; i < WM; ++i) {
                     to_lds(i);
-                    float h[4][8];
+                    float h[NPASS][8];
                     if constexpr (epi_reads_aux<EPI>) {
 #pragma unroll
-                        for (int ps = 0; ps < 4; ++ps)
+                        for (int ps = 0; ps < NPASS; ++ps)
 #pragma unroll
                             for (int e = 0; e < 8; ++e) h[ps][e] = bf2f(aux_nxt[ps][e]);
                         if (i + 1 < WM) load_aux(i + 1);
@@ -616,10 +620,10 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmParams p, int ntiles)
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-                    for (int ps = 0; ps < 4; ++ps) {
+                    for (int ps = 0; ps < NPASS; ++ps) {
                         float v[8];
                         from_lds(ps, v);
-                        epilogue_store_pre<EPI, bf16>(p, gr0 + i * 32 + ps * 8 + erow, gc, v, cc, h[ps]);
+                        epilogue_store_pre<EPI, bf16>(p, gr0 + i * 32 + ps * RPASS + erow, gc, v, cc, h[ps]);
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -632,8 +636,8 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmParams p, int ntiles)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-                for (int ps = 0; ps < 4; ++ps) {
-                    const int row = gr0 + i * 32 + ps * 8 + erow;
+                for (int ps = 0; ps < NPASS; ++ps) {
+                    const int row = gr0 + i * 32 + ps * RPASS + erow;
                     float v[8];
                     from_lds(ps, v);
                     if (row < p.M && gc < p.N) epilogue_store<EPI, bf16>(p, row, gc, v);
@@ -1017,7 +1021,7 @@ __global__ __launch_bounds__(2 * WGM * WGN * 64, 1) void gemm_ksplit_kernel(Gemm
             }
     __syncthreads();
     static_assert(3 * STAGE_BYTES >= NWG * NF * 16 * 64 * 4, "epilogue scratch must not overlap the hand-off area");
-    static_assert(STAGE_BYTES >= 2 * NWG * 4096, "4 KiB of epilogue scratch per wave in the last stage");
+    // 4 KiB of epilogue scratch per wave behind the hand-off area (launch_ksplit sizes the LDS for it)
     float* cw = reinterpret_cast<float*>(smem + 3 * STAGE_BYTES + wid * 4096);
 #pragma unroll
     for (int i = 0; i < WM; ++i)
@@ -1074,7 +1078,9 @@ int xcd_band(int tiles, int tiles_n, int grid, const GemmTune& t) {
 
 template <int EPI, int WGM, int WGN, int WM, int WN, bool STAG>
 int launch_ksplit(const GemmParams& p, const GemmTune& t, hipStream_t stream) {
-    constexpr int bm = WGM * WM * 32, bn = WGN * WN * 32, lds = 4 * (bm + bn) * 128;
+    constexpr int bm = WGM * WM * 32, bn = WGN * WN * 32, stage = (bm + bn) * 128;
+    constexpr int scratch_end = 3 * stage + 2 * WGM * WGN * 4096;
+    constexpr int lds = 4 * stage > scratch_end ? 4 * stage : scratch_end;
     auto kern = gemm_ksplit_kernel<EPI, WGM, WGN, WM, WN, STAG>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -1149,17 +1155,21 @@ int launch_cfg(const GemmParams& p, const GemmTune& t, hipStream_t stream) {
 // Tile shape per problem.  Measured on MI355X (scripts/bench_gemm.py, profiles/r02_gemm_experiments.md).
 // The 8-wave tiles win when their tiling still gives (almost) every CU one tile per round;
 // the N = 768 products of the ViT-B step (75 tiles of 256x256) stay on the 4-wave tiles.
-int pick_config(const GemmParams& p, const GemmTune& t) {
+// configuration 9 = 160x256 on 1 x 8 waves: only the staggered kernel has it (gemm8_kernel; `allow9`).  It is what fills the
+// chip at the reference's own batch of 64 (M = 3200: 240 tiles for c_fc / dGELU where 320x256 has 120).
+constexpr int CFG_160x256 = 9;
+int pick_config(const GemmParams& p, const GemmTune& t, bool allow9) {
     if (t.config >= 0 && t.config < kNumConfigs) return t.config;
+    if (t.config == CFG_160x256 && allow9) return CFG_160x256;
     if (p.N <= 64) return 2;
     const int cus = num_cus();
     if (t.big) {
         // rounds of the persistent loop and the fraction of the last round that is filled
-        const int cand[3] = {5, 4, 3};
+        const int cand[4] = {5, 4, 3, CFG_160x256};
         int best = -1; double best_cost = 1e30;
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < (allow9 ? 4 : 3); ++i) {
             const int c = cand[i];
-            const int bm = c == 5 ? 320 : 256, bn = c == 3 ? 128 : 256;
+            const int bm = c == 5 ? 320 : c == CFG_160x256 ? 160 : 256, bn = c == 3 ? 128 : 256;
             const long tiles = (long)ceil_div(p.M, bm) * ceil_div(p.N, bn);
             if (tiles * 10 < (long)cus * 7) continue;                 // fewer than 0.7 tiles per CU: leave to the small tiles
             const long rounds = (tiles + cus - 1) / cus;
@@ -1243,20 +1253,26 @@ int launch_streamk(const GemmParams& p_in, SkPlan plan, hipStream_t stream) {
 
 // the 160x128 two-group tile: where the heuristic takes a 4-wave tile for a long-K problem whose 160x128 tiling gives (almost)
 // every CU exactly one tile -- the N = E products of ViT-B/32 at B = 128 (240 tiles)
-bool use_ksplit(const GemmParams& p, const GemmTune& t, int cfg) {
-    if (!t.ksplit || t.config >= 0 || (cfg != 0 && cfg != 1) || t.ablate) return false;
-    const long tiles = (long)ceil_div(p.M, 160) * ceil_div(p.N, 128);
+// returns the tile height in fragments: 5 (160x128), 3 (96x128: M = 3200, the reference's own batch of 64, gives 204 tiles where
+// 160x128 gives 120), or 0 = not this kernel
+int use_ksplit(const GemmParams& p, const GemmTune& t, int cfg) {
+    if (!t.ksplit || t.config >= 0 || (cfg != 0 && cfg != 1) || t.ablate || p.K < t.ksplit_mink) return 0;
     const int cus = num_cus() & ~7;
-    const long rounds = (tiles + cus - 1) / cus;
-    if (t.ksplit == 1 && rounds > 1) return false;          // 2: also problems of several rounds (measurement)
-    return p.K >= t.ksplit_mink && 4 * tiles >= 3 * rounds * cus;    // the last round at least 3/4 full on average
+    const int cand[2] = {5, 3};
+    for (int i = 0; i < (t.ksplit_small ? 2 : 1); ++i) {
+        const long tiles = (long)ceil_div(p.M, cand[i] * 32) * ceil_div(p.N, 128);
+        const long rounds = (tiles + cus - 1) / cus;
+        if (t.ksplit == 1 && rounds > 1) continue;          // 2: also problems of several rounds (measurement)
+        if (4 * tiles >= 3 * rounds * cus) return cand[i];  // the last round at least 3/4 full on average
+    }
+    return 0;
 }
 
 // the staggered 8-wave kernel: 256x256 (configuration 4) and 320x256 (5), bf16 B, operands addressable with 31-bit byte offsets
-template <int EPI, int WM, int KSP>
+template <int EPI, int WGM, int WGN, int WM, int WN, int KSP>
 int launch_big8(const GemmParams& p, const GemmTune& t, hipStream_t stream) {
-    constexpr int bm = 2 * WM * 32, bn = 256, lds = 2 * (bm + bn) * 128;
-    auto kern = gemm8_kernel<EPI, WM, KSP>;
+    constexpr int bm = WGM * WM * 32, bn = WGN * WN * 32, lds = 2 * (bm + bn) * 128;
+    auto kern = gemm8_kernel<EPI, WGM, WGN, WM, WN, KSP>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
@@ -1274,24 +1290,27 @@ int launch_big8(const GemmParams& p, const GemmTune& t, hipStream_t stream) {
     LAUNCH_OK("gemm (staggered 8-wave)");
     return 0;
 }
-bool big8_ok(const GemmParams& p, const GemmTune& t, int cfg) {
-    if (!t.stagger || (cfg != 4 && cfg != 5) || (t.ablate & 12)) return false;
+bool big8_ok(const GemmParams& p, const GemmTune& t) {
+    if (!t.stagger || (t.ablate & 12)) return false;
     const long long a = ((long long)p.M * p.lda + p.K) * 2, b = ((long long)p.Nb * p.ldb + p.K) * 2;
     return a < (1LL << 31) && b < (1LL << 31);
 }
 
 template <int EPI, bool BF8>
 int launch_epi(const GemmParams& p, const GemmTune& t, hipStream_t stream) {
-    const int cfg = pick_config(p, t);
+    const bool stag = !BF8 && big8_ok(p, t);
+    const int cfg = pick_config(p, t, stag);
     if constexpr (!BF8) {
-        if (big8_ok(p, t, cfg)) {
-            if (cfg == 5) return t.ksp == 2 ? launch_big8<EPI, 5, 2>(p, t, stream) : launch_big8<EPI, 5, 1>(p, t, stream);
-            return t.ksp == 2 ? launch_big8<EPI, 4, 2>(p, t, stream) : launch_big8<EPI, 4, 1>(p, t, stream);
+        if (stag) {
+            if (cfg == 5) return launch_big8<EPI, 2, 4, 5, 2, 1>(p, t, stream);
+            if (cfg == 4) return launch_big8<EPI, 2, 4, 4, 2, 1>(p, t, stream);
+            if (cfg == CFG_160x256) return launch_big8<EPI, 1, 8, 5, 1, 1>(p, t, stream);
         }
     }
     if constexpr (!BF8 && (EPI == EPI_BIAS_RESID_F32 || EPI == EPI_F32 || EPI == EPI_BF16 || EPI == EPI_BIAS_RESID_KEEP || EPI == EPI_PATCH_EMBED)) {
-        if (use_ksplit(p, t, cfg))
-            return t.ksplit_stagger ? launch_ksplit<EPI, 1, 4, 5, 1, true>(p, t, stream) : launch_ksplit<EPI, 1, 4, 5, 1, false>(p, t, stream);
+        const int kwm = use_ksplit(p, t, cfg);
+        if (kwm == 5) return t.ksplit_stagger ? launch_ksplit<EPI, 1, 4, 5, 1, true>(p, t, stream) : launch_ksplit<EPI, 1, 4, 5, 1, false>(p, t, stream);
+        if (kwm == 3) return launch_ksplit<EPI, 1, 4, 3, 1, true>(p, t, stream);
         const SkPlan plan = streamk_plan(p, t, cfg);
         if (plan.share) return launch_streamk<EPI>(p, plan, stream);
     }

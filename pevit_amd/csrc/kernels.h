@@ -54,11 +54,11 @@ struct GemmTune {
     int big_bias = 100;   // the 8-wave tile is taken when its stream cost is below big_bias % of the 128x128 tiling's
     int sk_share = 0, sk_band = 0;   // measurement (gemm_streamk = 2): k-iterations per stream-K workgroup, m-tiles per band
     int ksplit = 1;       // N = E long-K products with ~one 160x128 tile per CU: 8-wave tile, two wave groups on alternate k-tiles
+    int ksplit_small = 1;     // ... also as a 96x128 tile where that fills the chip and 160x128 does not (M = 3200)
     int ksplit_stagger = 1;   // ... its two wave groups half an iteration apart (two barriers per pair of k-tiles)
     int ksplit_mink = 512;    // ... from this K on
     int band = -1;        // >= 0 forces GemmParams::band of the one-round 8-wave launches (measurement); -1 = XCD-aligned
     int stagger = 1;      // 8-wave tiles (bf16 B): the staggered two-group kernel (gemm8_kernel) instead of gemm_kernel
-    int ksp = 1;          // ... k-steps (of 16) per phase of that kernel: 1 or 2
     int streamk = 1;      // few-tile long-K problems: stream-K decomposition of the 128x128 tiling (needs GemmParams::sk_slab)
 };
 constexpr int PEVIT_SK_SLAB_FLOATS = 128 * 128;   // one partial tile per residency slot
@@ -135,7 +135,8 @@ int pevit_launch_permute_rows(const float* src, float* dst, int N, int B, int E,
                               hipStream_t s);
 int pevit_launch_scale_f32(float* p, size_t n, float scale, hipStream_t s);
 int pevit_launch_sgd(float* p, const float* g, float* mom, const unsigned char* has_grad, size_t n,
-                     float lr, float momentum, float wd, int first_step, float grad_scale, hipStream_t s);
+                     float lr, float momentum, float wd, int first_step, float grad_scale, hipStream_t s,
+                     const unsigned* poison = nullptr);   // device word: non-zero = skip the update (stream-K hand-off error)
 
 // ---- fp8.hip (e4m3 codes + power-of-two channel scales of the frozen weights) -----------------
 int pevit_launch_quant_rows_fp8(const float* W, int rows, int cols, unsigned char* out, int ldo, float* scale, int scaled_rows,

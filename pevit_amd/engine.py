@@ -285,9 +285,13 @@ class HipEngine:
         flags = int(self._steps == 0) | (2 if nesterov else 0)
         _lib.check(self.lib.pevit_sgd_step(self._ctx, _lib.stream_ptr(), lr, momentum, weight_decay, grad_scale, flags),
                    "pevit_sgd_step")
-        if self._steps == 0:
-            self.check_streamk()          # once, on the first step (synchronises the stream)
+        # the fused SGD kernel skips the update on device when a stream-K hand-off of this step timed out; the host reads
+        # the error word on the first step and then every STREAMK_CHECK_EVERY steps (each check synchronises the stream)
+        if self._steps % self.STREAMK_CHECK_EVERY == 0:
+            self.check_streamk()
         self._steps += 1
+
+    STREAMK_CHECK_EVERY = 64
 
     def check_streamk(self):
         """Stream-K GEMMs hand partial tiles between workgroups inside one launch; a consumer that never saw its
@@ -306,6 +310,14 @@ class HipEngine:
         _lib.check(self.lib.pevit_profile_end(self._ctx, C.byref(ms), C.byref(fl), C.byref(by), C.byref(n)),
                    "pevit_profile_end")
         self.last_profile_bytes = by.value
+        # per launch: (epilogue, M, N, K) -> [launches, ms, flops]
+        per = {}
+        one_ms, one_fl, shape = C.c_double(), C.c_double(), (C.c_int * 4)()
+        for i in range(n.value):
+            _lib.check(self.lib.pevit_profile_launch(self._ctx, i, C.byref(one_ms), C.byref(one_fl), shape), "pevit_profile_launch")
+            e = per.setdefault(tuple(shape), [0, 0.0, 0.0])
+            e[0] += 1; e[1] += one_ms.value; e[2] += one_fl.value
+        self.last_profile_by_shape = per
         return ms.value, fl.value, n.value
 
     def reset_optimizer(self):
@@ -343,6 +355,11 @@ class HipEngine:
         import torch.distributed as dist
         B = images.shape[0]
         self._check_batch(images, labels)
+        if not getattr(self, "_dp_streamk_off", False):
+            # the RCCL kernels of the overlapped all-reduce share the CUs with the second half of the backward: stream-K's
+            # hand-off assumes all its workgroups are co-resident, so under DP the plain tilings are used instead
+            self.tune("gemm_streamk", 0)
+            self._dp_streamk_off = True
         self.zero_grad()
         feat = self.visual_forward(images, save=True)
         _lib.check(self.lib.pevit_head_forward_backward(

@@ -345,6 +345,11 @@ def train_one(train_loader, model, criterion, optimizer, epoch, config):
 def validate(val_loader, model, criterion, epoch, config, return_logits=False):
     metric = get_metric(config.TEST.METRIC)
     outputs, targets = [], []
+    # a stream-K hand-off error raised during the preceding training steps (whose SGD updates were skipped on device) must
+    # not pass silently into a validation score or a checkpoint
+    eng = getattr(getattr(getattr(model, "backbone", None), "visual", None), "_engine", None)
+    if eng is not None:
+        eng.check_streamk()
     model.eval()
     dev = config.GPUS[0]
     for batch in val_loader:

@@ -22,3 +22,20 @@ for arch, method, r, B, C in CASES:
     if os.environ.get("PARITY_VERBOSE"):
         for k, e in sorted(errs.items(), key=lambda kv: -kv[1])[:8]:
             print(f"    {e:.3e}  {k}")
+
+print()
+print("| single block (seam, teacher-forced) | y (rel L2) | dx (rel L2) | worst gradient | tensor | median gradient |")
+print("|---|---|---|---|---|---|")
+BLOCKS = [(768, 32, 224, 512, "kadaptation", 4, 128, 11), (768, 32, 224, 512, "kadaptation", 4, 128, 12), (768, 32, 224, 512, "lora", 8, 128, 13),
+          (768, 32, 224, 512, "adapter", 4, 128, 14), (768, 32, 224, 512, "compacter", 4, 128, 15), (768, 32, 224, 512, "kadaptation", 4, 64, 16),
+          (768, 16, 224, 512, "compacter", 4, 16, 17), (1024, 14, 224, 768, "kadaptation", 4, 8, 18), (128, 16, 48, 64, "kadaptation", 4, 4, 19)]
+for width, patch, res, embed, method, r, B, seed in BLOCKS:
+    if len(sys.argv) > 1 and not any(a in f"block|{method}" for a in sys.argv[1:]):
+        continue
+    ye, dxe, errs = T._run_block(width, patch, res, embed, method, r, B, seed)
+    worst = max(errs.items(), key=lambda kv: kv[1])
+    med = sorted(errs.values())[len(errs) // 2]
+    print(f"| E={width} patch {patch} {method} (r={r}) bs {B} | {ye:.2e} | {dxe:.2e} | {worst[1]:.2e} | {worst[0][-48:]} | {med:.2e} |", flush=True)
+    if os.environ.get("PARITY_VERBOSE"):
+        for k, e in sorted(errs.items(), key=lambda kv: -kv[1])[:8]:
+            print(f"    {e:.3e}  {k}")

@@ -238,13 +238,12 @@ def test_config5_vit_l14_fp8_bs8_vs_bf16_engine_and_oracle():
     # (gated) logits moved -- on this random-weight 24-layer tower bf16 operand rounding alone moves them by ~10 %
     assert abs(loss8 - float(ref_loss)) <= 2.0 * float((l8.cpu() - ref_logits).abs().max()) + 1e-5
     gv = e8.grad_views()
-    worst = 0.0
     for k in tr.names:
         if tr.p[k].grad is None:
             assert float(gv[k].abs().max()) == 0.0
         else:
             err = rel_err(gv[k].cpu(), tr.p[k].grad)
-            assert err < tol(DEEP_GRAD_TOL, noise[k], worst), (k, err, noise[k])
+            assert err < tol(DEEP_GRAD_TOL, noise[k]), (k, err, noise[k])
 
 
 def test_config5_vit_l14_fp8_per_gpu_shard_bs32():

@@ -66,10 +66,11 @@ def test_gemm_f32_and_bf16(lib, M, N, K):
     assert max_rel(outb.float().cpu(), ref.cpu()) < 1e-2
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
 @pytest.mark.parametrize("M,N,K", [(6400, 768, 768), (700, 2368, 256), (257, 136, 64), (1300, 640, 1024)])
 def test_gemm_every_tile_config_is_bit_identical(lib, cfg, M, N, K):
-    """The tile configurations (4-wave 128x128 / 64x128 / 64x64 / 128x64, 8-wave 256x128 / 256x256 / 320x256, and the plain-loop twins of the software-pipelined 4-wave kernels) walk K in the
+    """The tile configurations (4-wave 128x128 / 64x128 / 64x64 / 128x64, 8-wave 256x128 / 256x256 / 320x256 -- the last two on the
+    staggered kernel, like 9 = 160x256 on 1 x 8 waves, whose 52 pieces per k-tile do not divide by the 8 loader waves --, and the plain-loop twins of the software-pipelined 4-wave kernels) walk K in the
     same order, so forcing any of them must reproduce the heuristic's result bit for bit -- partial tiles in M and N,
     several tiles per persistent workgroup (M=6400 at 64x64) and the fused epilogues included."""
     A = rnd(M, K, seed=1, dtype=torch.bfloat16)
@@ -96,7 +97,8 @@ def test_gemm_every_tile_config_is_bit_identical(lib, cfg, M, N, K):
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("M,N,K", [(6400, 768, 3072), (6400, 768, 2368 + 0), (2500, 768, 3072), (6333, 760, 2048), (8224, 1024, 1024)])
+@pytest.mark.parametrize("M,N,K", [(6400, 768, 3072), (6400, 768, 2368 + 0), (2500, 768, 3072), (6333, 760, 2048), (8224, 1024, 1024),
+                                   (3200, 768, 3072), (3111, 768, 768)])     # M = 3200: the 96x128 k-split tile (204 tiles)
 def test_gemm_streamk_hand_off(lib, M, N, K):
     """Few-tile long-K products leave the plain tiling: with (almost) one 160x128 tile per CU they run on the 8-wave tile
     whose two wave groups take alternate k-tiles (M = 6400 / 6333), with fewer tiles as stream-K -- the tiles x

@@ -61,24 +61,30 @@ def bf16_noise(sd, method, classes, images, labels, head_w, head_b):
     errs = {n: rel_err(emu.p[n].grad, f32.p[n].grad) for n in f32.names if f32.p[n].grad is not None}
     errs["layers.0.weight"] = rel_err(emu.head_w.grad, f32.head_w.grad)
     errs["layers.0.bias"] = rel_err(emu.head_b.grad, f32.head_b.grad)
+    if method == "adapter":
+        # the bottleneck Adapter has a hard non-linearity on the trainable path (ReLU, adapter_model.py:271): WHICH gradient
+        # tensor absorbs the mask flips of near-zero pre-activations depends on where the rounding happens, so the noise of a
+        # tensor is taken as the larger of the two emulations of it
+        from oracle import emul_bf16
+        rp = emul_bf16.EmulTrainer(sd, method, classes)
+        with torch.no_grad():
+            rp.head_w.copy_(head_w); rp.head_b.copy_(head_b)
+        rp.loss_and_grads(images, labels)
+        for n in list(errs):
+            g = rp.head_w.grad if n == "layers.0.weight" else rp.head_b.grad if n == "layers.0.bias" else rp.p[n].grad
+            errs[n] = max(errs[n], rel_err(g, f32.head_w.grad if n == "layers.0.weight" else f32.head_b.grad if n == "layers.0.bias" else f32.p[n].grad))
     bf16_noise.last_loss_err = abs(float(lemu_loss) - float(loss32))      # same measure for the scalar loss
     return f32, l32, loss32, max_rel(lemu, l32), errs
 
 
-def tol(base, emulated, worst=0.0):
-    """Gate of the bf16 production path = the calibrated tolerance, widened per tensor only where bf16 operand rounding
-    ALONE (the f32 oracle with its contraction operands rounded to bf16, same inputs) already exceeds it.  The STATED gates
-    of BASELINE.md (2e-2 / 5e-2) are asserted without any widening in the f32-class verification mode
-    (tests/test_gpu_verify.py).  `worst` (see relu_worst) is non-zero only for the bottleneck Adapter."""
-    return max(base, 2.5 * emulated + 1e-2, 1.25 * worst)
-
-
-def relu_worst(method, noise):
-    """The bottleneck Adapter alone has a hard non-linearity on the trainable path (ReLU, adapter_model.py:271): under
-    operand rounding its mask flips for pre-activations near zero, and WHICH gradient tensor absorbs the flips is chaotic
-    (the f32 oracle with bf16-rounded operands moves single tensors by 5-70 % there, scripts/debug_adapter.py), so for
-    that method the per-tensor bound also admits 1.25x the worst tensor of the emulation.  Every other method: 0."""
-    return max(noise.values()) if method == "adapter" else 0.0
+def tol(base, emulated):
+    """Gate of the bf16 production path against the f32 fixtures = the calibrated tolerance, widened per tensor only where
+    bf16 rounding ALONE (bf16_noise: the f32 oracle with its contraction operands rounded to bf16 and, for the bottleneck
+    Adapter, also the rounding-point emulation oracle/emul_bf16.py -- same inputs, same tensor) already exceeds it.  The
+    STATED gates of BASELINE.md (2e-2 / 5e-2) are asserted without any widening in the f32-class verification mode
+    (tests/test_gpu_verify.py); the production kernels themselves are held per block to 2e-3 ... 1.2e-2 against the
+    rounding-point emulation (tests/test_gpu_emulation.py)."""
+    return max(base, 2.5 * emulated + 1e-2)
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -108,7 +114,7 @@ def test_train_step_matches_reference_fixture(case):
             assert float(g.abs().max()) == 0.0, name              # reference .grad is None
             continue
         err = rel_err(g.cpu(), t[key])
-        assert err < tol(GRAD_TOL, noise[name], relu_worst(meta["method"], noise)), (name, err, noise[name])
+        assert err < tol(GRAD_TOL, noise[name]), (name, err, noise[name])
 
 
 @pytest.mark.parametrize("case", ["tiny_kadaptation", "tiny_lora", "tiny_adapter", "tiny_compacter"])
@@ -121,16 +127,16 @@ def test_sgd_trajectory_matches_reference_fixture(case):
         _, loss = eng.train_step(images, labels, lr=meta["lr"], momentum=0.9, weight_decay=meta["wd"])
         losses.append(float(loss))
     for a, b in zip(losses, meta["losses"]):
-        assert abs(a - b) < 5e-2, (losses, meta["losses"])
+        assert abs(a - b) < 3.5e-2, (losses, meta["losses"])          # measured <= 1.7e-2 (profiles/r03_parity_errors.md)
     none = {n[len("backbone."):] for n in meta["grad_is_none"]}
     for name, p in eng.param_views().items():
         key = "final/" + (name if name.startswith("layers.") else "backbone." + name)
         if name in none:      # never updated: torch skips params without grad, even with weight decay
             assert torch.equal(p.cpu(), t["adapter/" + name]), name
             continue
-        assert rel_err(p.cpu(), t[key]) < 8e-2, (name, rel_err(p.cpu(), t[key]))
-    assert rel_err(eng.running_mean.cpu(), t["bn_mean"]) < 3e-2
-    assert rel_err(eng.running_var.cpu(), t["bn_var"]) < 5e-2
+        assert rel_err(p.cpu(), t[key]) < 8e-2, (name, rel_err(p.cpu(), t[key]))      # measured <= 6.4e-2
+    assert rel_err(eng.running_mean.cpu(), t["bn_mean"]) < 3e-2       # measured <= 1.4e-2
+    assert rel_err(eng.running_var.cpu(), t["bn_var"]) < 1.2e-2       # measured <= 5.2e-3
 
 
 @pytest.mark.parametrize("method,arch_name,B", [("kadaptation", "tiny-128", 6), ("kadaptation", "tiny-256", 5),
@@ -342,7 +348,7 @@ def test_long_sequences_full_step_vs_oracle(method, arch_name, B):
             assert float(gv[k].abs().max()) == 0.0
         else:
             err = rel_err(gv[k].cpu(), tr.p[k].grad)
-            assert err < tol(GRAD_TOL, noise[k], relu_worst(method, noise)), (k, err, noise[k])
+            assert err < tol(GRAD_TOL, noise[k]), (k, err, noise[k])
 
 
 # ---- the architectures of BASELINE configs 3-5 at full width/depth ---------------------------------------
@@ -389,19 +395,17 @@ def test_baseline_config_architectures_vs_oracle(arch_name, method, lora_r):
     torch.cuda.synchronize()
     assert torch.isfinite(logits).all() and torch.isfinite(eng.grads).all()
     assert max_rel(logits.cpu(), ref_logits) < tol(DEEP_LOGIT_TOL, logit_noise)
-    # mean cross-entropy is 2-Lipschitz in the sup norm of the logits: the loss may move by at most twice what the gated
-    # logits moved (24 random-weight layers move them by ~10 % under bf16 operand rounding alone)
-    assert abs(float(loss) - float(ref_loss)) <= max(5e-2, 2.0 * float((logits.cpu() - ref_logits).abs().max()))
+    # absolute loss gate, calibrated like the others (measured: 12 blocks <= 7e-3, ViT-L/14's 24 blocks 3.1e-2 -- profiles/r03_parity_errors.md)
+    assert abs(float(loss) - float(ref_loss)) <= (5e-2 if arch.layers <= 12 else 1.2e-1)
     gv = eng.grad_views()
-    worst = relu_worst(method, noise)
     for k in tr.names:
         if tr.p[k].grad is None:
             assert float(gv[k].abs().max()) == 0.0
         else:
             err = rel_err(gv[k].cpu(), tr.p[k].grad)
-            assert err < tol(DEEP_GRAD_TOL, noise[k], worst), (k, err, noise[k])
+            assert err < tol(DEEP_GRAD_TOL, noise[k]), (k, err, noise[k])
     for k, ref in (("layers.0.weight", tr.head_w.grad), ("layers.0.bias", tr.head_b.grad)):
-        assert rel_err(gv[k].cpu(), ref) < tol(DEEP_GRAD_TOL, noise[k], worst), k
+        assert rel_err(gv[k].cpu(), ref) < tol(DEEP_GRAD_TOL, noise[k]), k
 
 
 @pytest.mark.parametrize("method", ["kadaptation", "lora"])
@@ -436,7 +440,7 @@ def test_whole_train_step_at_b128_vs_oracle(method):
             assert float(gv[k].abs().max()) == 0.0
         else:
             err = rel_err(gv[k].cpu(), tr.p[k].grad)
-            assert err < tol(GRAD_TOL, noise[k]), (k, err, noise[k])          # no "worst tensor" widening here
+            assert err < tol(GRAD_TOL, noise[k]), (k, err, noise[k])
     assert rel_err(gv["layers.0.weight"].cpu(), tr.head_w.grad) < GRAD_TOL
     # the update itself: first SGD step = p - lr * (g + wd * p) on every tensor that has a gradient
     upd = p_before - 0.01 * (eng.grads + 1e-4 * p_before)
