@@ -143,7 +143,7 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="images per GPU (BASELINE config 2: 128)")
     ap.add_argument("--method", default="kadaptation")
     ap.add_argument("--arch", default="ViT-B/32")
-    ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8"],
+    ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8", "fp8-act"],
                     help="frozen block weights: bf16, or e4m3 codes + per-channel scales (BASELINE config 5 with --arch ViT-L/14)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sweep", action="store_true", help="only time the CPU baseline at 8/16/32/64/128 threads and exit")
@@ -276,7 +276,7 @@ def main():
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             # the arithmetic type of the path: bf16 operands on the bf16 MFMA, f32 accumulate; with --weights fp8 the frozen
             # weights are e4m3 codes converted to bf16 in the GEMM (the activation side stays bf16)
-            "dtype": "bf16" if args.weights == "bf16" else "bf16 x fp8-e4m3 weights", "data": "synthetic",
+            "dtype": {"bf16": "bf16", "fp8": "bf16 x fp8-e4m3 weights", "fp8-act": "fp8-e4m3 x fp8-e4m3 (forward frozen products), bf16 x fp8 (backward)"}[args.weights], "data": "synthetic",
             "config": {"workload": f"CLIP {args.arch} + {args.method} fine-tune step (fwd+CE+bwd+SGD), "
                                    f"{args.batch} images/GPU 3x{arch.resolution}x{arch.resolution}, C={classes}, "
                                    f"synthetic OpenAI-layout checkpoint, adapters at reference init, frozen block "

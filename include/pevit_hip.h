@@ -58,6 +58,13 @@ enum pevit_weight_format {
     PEVIT_W_FP8_E4M3 = 1, /* OCP e4m3 codes + one power-of-two f32 scale per output channel, packed by
                              pevit_load_block; activations stay bf16, accumulation f32 (BASELINE config 5).  Bit-identical
                              to PEVIT_W_BF16 run on the de-quantised weights.  KAdaptation, LoRA and the frozen tower.  */
+    PEVIT_W_FP8_ACT = 3,  /* opt-in, NOT bit-compatible with the bf16 path: PEVIT_W_FP8_E4M3 weights, and in the FORWARD pass the
+                             A operands of the four frozen products of a block (LayerNorm outputs, attention output, gelu(h))
+                             are e4m3 codes too (unscaled: activations are O(1); saturating at +-448), written by their
+                             producers, so that these products run fp8 x fp8 on CDNA4's MX-scaled matrix instruction
+                             (v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales: twice the bf16 MFMA rate, half the
+                             operand bytes).  The backward pass is that of PEVIT_W_FP8_E4M3 (bf16 activations, saved in
+                             bf16).  Deviation from the bf16-on-de-quantised run: profiles/r03_fp8_act.md.                */
     PEVIT_W_F32_VERIFY = 2 /* f32-class VERIFICATION mode, not a production format: weights and every activation kept in
                              f32, the matrix-core contractions run as plain f32 kernels (csrc/verify.hip) inside the same
                              launch sequences, layouts and index arithmetic.  Used by the parity tests to assert the stated
@@ -164,6 +171,15 @@ int pevit_op_gemm_fp8(void* stream, int epilogue, const void* A_bf16, int lda, c
                       const float* bscale, const float* oscale, int M, int N, int K, const float* bias,
                       const float* resid, int ldr, float* out_f32, int ldo, void* out_bf16, int ldob, void* out2_bf16,
                       int ldob2, const void* aux_bf16, int ldaux, size_t head_stride, int E, int H, int tokens);
+/* fp8 x fp8 (PEVIT_W_FP8_ACT): A = UNSCALED saturating e4m3 codes [M][lda] (pevit_op_cast_fp8), B / bscale as above; the
+ * matrix-core instruction is v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales.  Epilogues 0, 1, 2, 4; out2_fp8: the
+ * EPI_BIAS_GELU activation output is written as e4m3 codes (ldob2 in codes). */
+int pevit_op_gemm_f8a(void* stream, int epilogue, const void* A_codes, int lda, const void* B_codes, int ldb, int b_rows,
+                      const float* bscale, int M, int N, int K, const float* bias, const float* resid, int ldr,
+                      float* out_f32, int ldo, void* out_bf16, int ldob, void* out2, int ldob2, int out2_fp8,
+                      size_t head_stride, int E, int H, int tokens);
+/* src (rows x cols f32, cols % 128 == 0) -> e4m3 codes without a scale (|x| > 448 saturates), k-permuted per 128 */
+int pevit_op_cast_fp8(void* stream, const float* src, void* codes, int rows, int cols);
 /* W (rows x cols f32, cols % 128 == 0) -> per-row power-of-two scales 2^ceil(log2(amax/448)), e4m3 codes [rows][cols]
  * and (codes_t != NULL, rows % 128 == 0) the same codes transposed [cols][rows]; both k-permuted per 128 */
 int pevit_op_quant_fp8(void* stream, const float* W, int rows, int cols, void* codes, float* scales, void* codes_t);

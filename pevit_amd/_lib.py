@@ -21,7 +21,7 @@ class PevitDims(C.Structure):
                 ("num_classes", C.c_int32), ("weight_format", C.c_int32)]
 
 
-WEIGHT_FORMATS = {"bf16": 0, "fp8": 1, "f32-verify": 2}
+WEIGHT_FORMATS = {"bf16": 0, "fp8": 1, "f32-verify": 2, "fp8-act": 3}
 
 
 METHOD_IDS = {"kadaptation": 0, "lora": 1, "adapter": 2, "compacter": 3, "none": 4}
@@ -60,6 +60,9 @@ SIGNATURES = {
                               P, c_int, P, c_int, P, c_int, c_size_t, c_int, c_int, c_int]),
     "pevit_op_gemm_fp8": (c_int, [P, c_int, P, c_int, P, c_int, c_int, P, P, c_int, c_int, c_int, P, P, c_int, P, c_int,
                                   P, c_int, P, c_int, P, c_int, c_size_t, c_int, c_int, c_int]),
+    "pevit_op_gemm_f8a": (c_int, [P, c_int, P, c_int, P, c_int, c_int, P, c_int, c_int, c_int, P, P, c_int, P, c_int, P, c_int,
+                                  P, c_int, c_int, c_size_t, c_int, c_int, c_int]),
+    "pevit_op_cast_fp8": (c_int, [P, P, P, c_int, c_int]),
     "pevit_op_quant_fp8": (c_int, [P, P, c_int, c_int, P, P, P]),
     "pevit_op_dequant_fp8": (c_int, [P, P, P, c_int, c_int, P]),
     "pevit_op_ln_fwd": (c_int, [P, P, P, P, c_int, c_int, P, P, P, P]),

@@ -184,19 +184,44 @@ __global__ __launch_bounds__(64 * LNA_WAVES) void ln_bwd_affine_kernel(const flo
     for (int i = 0; i < LNA_MAXV; ++i) {
         ag[i] = make_float4(0.f, 0.f, 0.f, 0.f); ab[i] = make_float4(0.f, 0.f, 0.f, 0.f); ar[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    // a wave walks its LNA_ROWS / LNA_WAVES rows with the NEXT row's operands already requested: processed one after the other
+    // each row paid a full HBM round trip before its reductions could start (27.8 us for 88 MB in step; with the next row in
+    // flight the kernel is bound by the bytes)
+    float4 nd[LNA_MAXV], nx[LNA_MAXV], nr[LNA_MAXV];
+    auto request = [&](int row) {
+        const size_t base = (size_t)row * E;
+#pragma unroll
+        for (int i = 0; i < LNA_MAXV; ++i) {
+            const int c = lane * 4 + i * 256;
+            nd[i] = nx[i] = nr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < E) {
+                nd[i] = *reinterpret_cast<const float4*>(dy + base + c);
+                nx[i] = *reinterpret_cast<const float4*>(x + base + c);
+                if (dres) nr[i] = *reinterpret_cast<const float4*>(dres + base + c);
+            }
+        }
+    };
+    {
+        const int row0 = blockIdx.x * LNA_ROWS + wid;
+        if (row0 < rows) request(row0);
+    }
     for (int rr = wid; rr < LNA_ROWS; rr += LNA_WAVES) {
         const int row = blockIdx.x * LNA_ROWS + rr;
         if (row >= rows) break;
         const float mean = mean_in[row], rstd = rstd_in[row];
         const size_t base = (size_t)row * E;
+        float4 cd[LNA_MAXV], cx[LNA_MAXV], cr[LNA_MAXV];
+#pragma unroll
+        for (int i = 0; i < LNA_MAXV; ++i) { cd[i] = nd[i]; cx[i] = nx[i]; cr[i] = nr[i]; }
+        if (rr + LNA_WAVES < LNA_ROWS && row + LNA_WAVES < rows) request(row + LNA_WAVES);
         float4 gd[LNA_MAXV], xh[LNA_MAXV];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < LNA_MAXV; ++i) {
             const int c = lane * 4 + i * 256;
             if (c < E) {
-                const float4 d = *reinterpret_cast<const float4*>(dy + base + c);
-                const float4 xv = *reinterpret_cast<const float4*>(x + base + c);
+                const float4 d = cd[i];
+                const float4 xv = cx[i];
                 const float4 g = *reinterpret_cast<const float4*>(gamma + c);
                 xh[i] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
                 ag[i].x += d.x * xh[i].x; ag[i].y += d.y * xh[i].y; ag[i].z += d.z * xh[i].z; ag[i].w += d.w * xh[i].w;
@@ -215,7 +240,7 @@ __global__ __launch_bounds__(64 * LNA_WAVES) void ln_bwd_affine_kernel(const flo
                 o.x = rstd * (gd[i].x - m1 - xh[i].x * m2); o.y = rstd * (gd[i].y - m1 - xh[i].y * m2);
                 o.z = rstd * (gd[i].z - m1 - xh[i].z * m2); o.w = rstd * (gd[i].w - m1 - xh[i].w * m2);
                 if (dres) {
-                    const float4 r = *reinterpret_cast<const float4*>(dres + base + c);
+                    const float4 r = cr[i];
                     o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
                     ar[i].x += r.x; ar[i].y += r.y; ar[i].z += r.z; ar[i].w += r.w;
                 }

@@ -77,7 +77,7 @@ __device__ __forceinline__ void store16(bf16* dst, const f32x4 o[4], float scale
 template <int KT32, int NW>
 __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
                                                        const bf16* __restrict__ v, bf16* __restrict__ out, int ldo,
-                                                       float* __restrict__ lse, int H, int N) {
+                                                       float* __restrict__ lse, int H, int N, unsigned char* __restrict__ out8) {
     constexpr int NPAD = 32 * KT32, LDK = ATT_LDR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* Ks = reinterpret_cast<bf16*>(smem);                 // [NPAD][LDK] row-major, padded rows
@@ -148,6 +148,15 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const bf16* __restric
         }
         if (xq < N) {
             store16(out + ((size_t)b * N + xq) * ldo + h * 64 + 16 * g, o, 1.0f / l);
+            if (out8) {      // e4m3 copy (k-permuted) for the fp8 x fp8 out-projection
+                const float inv = 1.0f / l;
+                float lo8[8], hi8[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { lo8[r] = o[0][r] * inv; lo8[4 + r] = o[1][r] * inv; hi8[r] = o[2][r] * inv; hi8[4 + r] = o[3][r] * inv; }
+                unsigned char* rb = out8 + ((size_t)b * N + xq) * ldo;
+                store8_fp8(rb, h * 64 + 16 * g, lo8);
+                store8_fp8(rb, h * 64 + 16 * g + 8, hi8);
+            }
             if (g == 0) lse[(size_t)bh * N + xq] = m + __logf(l);
         }
     }
@@ -354,7 +363,7 @@ __global__ __launch_bounds__(64 * NW, (ALL4 ? ATT_BWD_MINW : 1)) void attn_bwd_k
 
 template <int KT32, int NW>
 int launch_fwd(const bf16* q, const bf16* k, const bf16* v, bf16* out, int ldo, float* lse, int B, int H, int N,
-               hipStream_t s) {
+               hipStream_t s, unsigned char* out8) {
     constexpr int NPAD = 32 * KT32;
     const int bytes = 2 * NPAD * ATT_LDR * 2;
     static bool attr = false;
@@ -365,7 +374,7 @@ int launch_fwd(const bf16* q, const bf16* k, const bf16* v, bf16* out, int ldo, 
         }
         attr = true;
     }
-    hipLaunchKernelGGL((attn_fwd_kernel<KT32, NW>), dim3(B * H), dim3(64 * NW), bytes, s, q, k, v, out, ldo, lse, H, N);
+    hipLaunchKernelGGL((attn_fwd_kernel<KT32, NW>), dim3(B * H), dim3(64 * NW), bytes, s, q, k, v, out, ldo, lse, H, N, out8);
     LAUNCH_OK("attn_fwd_kernel");
     return 0;
 }
@@ -407,12 +416,12 @@ int launch_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* out, int
 #endif
 
 int pevit_launch_attn_fwd(const bf16* q, const bf16* k, const bf16* v, bf16* out, int ldo, float* lse, int B, int H,
-                          int N, hipStream_t s) {
+                          int N, hipStream_t s, unsigned char* out8) {
     if (N < 1 || N > 288) { pevit_set_error("attn_fwd: tokens per image N=%d outside [1,288]", N); return -1; }
     if (ldo % 8) { pevit_set_error("attn_fwd: ldo must be a multiple of 8"); return -1; }
-    if (N <= 64) return launch_fwd<2, 4>(q, k, v, out, ldo, lse, B, H, N, s);
-    if (N <= 224) return launch_fwd<7, ATT_NW_MID_F>(q, k, v, out, ldo, lse, B, H, N, s);
-    return launch_fwd<9, ATT_NW_BIG_F>(q, k, v, out, ldo, lse, B, H, N, s);
+    if (N <= 64) return launch_fwd<2, 4>(q, k, v, out, ldo, lse, B, H, N, s, out8);
+    if (N <= 224) return launch_fwd<7, ATT_NW_MID_F>(q, k, v, out, ldo, lse, B, H, N, s, out8);
+    return launch_fwd<9, ATT_NW_BIG_F>(q, k, v, out, ldo, lse, B, H, N, s, out8);
 }
 
 int pevit_launch_attn_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* out, int ldo, const bf16* dout,

@@ -60,6 +60,8 @@ struct pevit_ctx {
     int E, L, H, N, P, R, D, C, G2, Kpatch;
     int NQ, NQpad;            // 3E+64 and its multiple-of-128 padding
     bool fp8 = false;         // frozen block weights as e4m3 codes + per-channel scales (fp8.hip)
+    bool fp8act = false;      // ... and fp8 A operands in the forward frozen products (PEVIT_W_FP8_ACT)
+    size_t w_a8 = 0, w_attn8 = 0;   // e4m3 copies of the LayerNorm output / the attention output (fp8act)
     bool f32 = false;         // f32-class verification mode: every bf16-declared buffer holds f32 (verify.hip)
     size_t es = 2;            // bytes per element of those buffers
     float ascale;             // 160 (model.py:564) or alpha/r (lora_model.py:491)
@@ -144,7 +146,11 @@ void layout_workspace(pevit_ctx* c, int B, LayerSaved* sav, size_t* total, pevit
     const int chunks = pevit_lowrank_chunks((int)T);
     o = cv.take(T * E * 4);                 if (fill) fill->w_xfinal = o;
     o = cv.take(T * E * es);                 if (fill) fill->w_xn2 = o;
-    o = cv.take(T * 4 * E * es);             if (fill) fill->w_g = o;
+    o = cv.take(T * 4 * E * es);             if (fill) fill->w_g = o;       // (fp8act: holds gelu(h) as e4m3 codes, half of it used)
+    if (c->fp8act) {
+        o = cv.take(T * E);                  if (fill) fill->w_a8 = o;
+        o = cv.take(T * E);                  if (fill) fill->w_attn8 = o;
+    }
     o = cv.take(T * (size_t)c->NQ * es);     if (fill) fill->w_dqkv = o;
     o = cv.take(T * 64 * 4);                if (fill) fill->w_u32 = o;
     o = cv.take(T * E * es);                 if (fill) fill->w_dO = o;
@@ -214,10 +220,11 @@ extern "C" int pevit_ctx_create(const pevit_dims* dims, pevit_ctx** out) {
     if (d.method == PEVIT_LORA && (d.lora_rank < 1 || d.lora_rank > 32)) {
         pevit_set_error("ctx_create: LoRA rank %d outside [1,32]", d.lora_rank); return -1;
     }
-    if (d.weight_format != PEVIT_W_BF16 && d.weight_format != PEVIT_W_FP8_E4M3 && d.weight_format != PEVIT_W_F32_VERIFY) {
+    if (d.weight_format != PEVIT_W_BF16 && d.weight_format != PEVIT_W_FP8_E4M3 && d.weight_format != PEVIT_W_F32_VERIFY &&
+        d.weight_format != PEVIT_W_FP8_ACT) {
         pevit_set_error("ctx_create: unknown weight_format %d", d.weight_format); return -1;
     }
-    if (d.weight_format == PEVIT_W_FP8_E4M3 && (d.method == PEVIT_ADAPTER || d.method == PEVIT_COMPACTER)) {
+    if ((d.weight_format == PEVIT_W_FP8_E4M3 || d.weight_format == PEVIT_W_FP8_ACT) && (d.method == PEVIT_ADAPTER || d.method == PEVIT_COMPACTER)) {
         pevit_set_error("ctx_create: fp8 weights are built for the attention-site methods (KAdaptation, LoRA) and the frozen tower"); return -1;
     }
     if (d.out_dim <= 0 || d.out_dim % 8 != 0 || d.num_classes <= 0) {
@@ -232,7 +239,8 @@ extern "C" int pevit_ctx_create(const pevit_dims* dims, pevit_ctx** out) {
     c->Kpatch = (int)align_up((size_t)3 * d.patch * d.patch, 64);
     c->NQ = 3 * c->E + 64; c->NQpad = (int)align_up((size_t)c->NQ, 128);
     c->ascale = d.method == PEVIT_LORA ? 128.0f / (float)d.lora_rank : 160.0f;
-    c->fp8 = d.weight_format == PEVIT_W_FP8_E4M3;
+    c->fp8act = d.weight_format == PEVIT_W_FP8_ACT;
+    c->fp8 = d.weight_format == PEVIT_W_FP8_E4M3 || c->fp8act;
     c->f32 = d.weight_format == PEVIT_W_F32_VERIFY;
     c->es = c->f32 ? 4 : 2;
     c->sk_slots = c->f32 ? 0 : pevit_gemm_sk_slots();
@@ -546,8 +554,10 @@ int blocks_forward(pevit_ctx* c, hipStream_t s, int B, bool cls_only) {
         bf16* qkv = at<bf16>(W, v.qkv);
         const size_t plane = (size_t)T * E;
         // x = x + attn(ln_1(x))                                         model.py:973
+        unsigned char* a8 = c->fp8act ? at<unsigned char>(W, c->w_a8) : nullptr;
+        unsigned char* attn8 = c->fp8act ? at<unsigned char>(W, c->w_attn8) : nullptr;
         CHECK(pevit_launch_ln_fwd(x_in, at<float>(A, b.ln1w), at<float>(A, b.ln1b), T, E, at<bf16>(W, v.xn1), nullptr,
-                                  at<float>(W, v.mean1), at<float>(W, v.rstd1), s, 0, c->f32));
+                                  at<float>(W, v.mean1), at<float>(W, v.rstd1), s, 0, c->f32, a8));
         if (!c->fp8) {
             GemmParams p = gp(at<bf16>(W, v.xn1), E, at<bf16>(A, b.wqkv), E, c->NQpad, T, site ? c->NQ : 3 * E, E);
             p.bias = at<float>(A, b.bqkv); p.outb = qkv; p.head_stride = plane; p.outf = at<float>(W, v.t); p.ldo = 64;
@@ -556,6 +566,7 @@ int blocks_forward(pevit_ctx* c, hipStream_t s, int B, bool cls_only) {
         } else {
             // fp8 codes for the 3E frozen rows; the 64 trainable adapter rows stay bf16 and get their own small product
             GemmParams p = gpw(c, at<bf16>(W, v.xn1), E, b.wqkv, E, 3 * E, T, 3 * E, E, b.sqkv);
+            if (a8) { p.A = reinterpret_cast<const bf16*>(a8); p.a_fp8 = 1; }
             p.bias = at<float>(A, b.bqkv); p.outb = qkv; p.head_stride = plane; p.E = E; p.H = H; p.Ntok = N;
             CHECK(gemm(c, EPI_QKV_HEADS, p, s));
             if (site) {
@@ -575,7 +586,7 @@ int blocks_forward(pevit_ctx* c, hipStream_t s, int B, bool cls_only) {
                                             at<float>(W, v.attn_out), E, at<float>(W, v.lse), B, H, N, s));
         else
             CHECK(pevit_launch_attn_fwd(qkv, qkv + plane, qkv + 2 * plane, at<bf16>(W, v.attn_out), E, at<float>(W, v.lse), B,
-                                        H, N, s));
+                                        H, N, s, attn8));
         // rows of the tail of this block: all T, or (last block, cls_only) the B class-token rows, which
         // sit N*E elements apart in every [T][E] buffer
         const bool cls = cls_only && l == c->L - 1;
@@ -583,26 +594,30 @@ int blocks_forward(pevit_ctx* c, hipStream_t s, int B, bool cls_only) {
         const int rs = cls ? N * E : E;            // row stride of [T][E] buffers
         {
             GemmParams p = gpw(c, at<bf16>(W, v.attn_out), rs, b.wo, E, E, R, E, E, b.so);
+            if (attn8) { p.A = reinterpret_cast<const bf16*>(attn8); p.a_fp8 = 1; }
             p.bias = at<float>(A, b.bo); p.resid = x_in; p.ldr = rs; p.outf = x_mid; p.ldo = rs;
             CHECK(gemm(c, EPI_BIAS_RESID_F32, p, s));
         }
         // x = x + mlp(ln_2(x))                                          model.py:974
         CHECK(pevit_launch_ln_fwd(x_mid, at<float>(A, b.ln2w), at<float>(A, b.ln2b), R, E, at<bf16>(W, c->w_xn2), nullptr,
-                                  at<float>(W, v.mean2), at<float>(W, v.rstd2), s, (size_t)rs, c->f32));
+                                  at<float>(W, v.mean2), at<float>(W, v.rstd2), s, (size_t)rs, c->f32, a8));
         {
             GemmParams p = gpw(c, at<bf16>(W, c->w_xn2), E, b.wfc, E, 4 * E, R, 4 * E, E, b.sfc);
+            if (a8) { p.A = reinterpret_cast<const bf16*>(a8); p.a_fp8 = 1; p.out2_fp8 = 1; }     // gelu(h) leaves as e4m3 codes
             p.bias = at<float>(A, b.bfc); p.outb = at<bf16>(W, v.h); p.ldob = 4 * E; p.outb2 = at<bf16>(W, c->w_g);
             p.ldob2 = 4 * E;
             CHECK(gemm(c, EPI_BIAS_GELU, p, s));
         }
         if (cls) {
             GemmParams p = gpw(c, at<bf16>(W, c->w_g), 4 * E, b.wpr, 4 * E, E, R, E, 4 * E, b.spr);
+            if (a8) p.a_fp8 = 1;
             p.bias = at<float>(A, b.bpr); p.resid = x_mid; p.ldr = rs; p.outf = x_out; p.ldo = rs;
             CHECK(gemm(c, EPI_BIAS_RESID_F32, p, s));
             continue;
         }
         if (!post_mlp(c)) {
             GemmParams p = gpw(c, at<bf16>(W, c->w_g), 4 * E, b.wpr, 4 * E, E, T, E, 4 * E, b.spr);
+            if (a8) p.a_fp8 = 1;
             p.bias = at<float>(A, b.bpr); p.resid = x_mid; p.ldr = E; p.outf = x_out; p.ldo = E;
             CHECK(gemm(c, EPI_BIAS_RESID_F32, p, s));
         } else {
@@ -1102,6 +1117,20 @@ extern "C" int pevit_op_gemm_fp8(void* stream, int epi, const void* A, int lda, 
     p.outb2 = (bf16*)outb2; p.ldob2 = ldob2; p.aux = (const bf16*)aux; p.ldaux = ldaux; p.head_stride = head_stride;
     p.E = E; p.H = H; p.Ntok = tokens;
     return pevit_launch_gemm(epi, p, g_default_tune, (hipStream_t)stream);
+}
+// fp8 x fp8 form (PEVIT_W_FP8_ACT): A = unscaled e4m3 codes as written by pevit_op_cast_fp8
+extern "C" int pevit_op_gemm_f8a(void* stream, int epi, const void* Acodes, int lda, const void* Bcodes, int ldb, int b_rows,
+                                 const float* bscale, int M, int N, int K, const float* bias, const float* resid, int ldr,
+                                 float* outf, int ldo, void* outb, int ldob, void* outb2, int ldob2, int out2_fp8,
+                                 size_t head_stride, int E, int H, int tokens) {
+    GemmParams p = gp((const bf16*)Acodes, lda, (const bf16*)Bcodes, ldb, b_rows, M, N, K);
+    p.b_fp8 = 1; p.a_fp8 = 1; p.bscale = bscale; p.out2_fp8 = out2_fp8;
+    p.bias = bias; p.resid = resid; p.ldr = ldr; p.outf = outf; p.ldo = ldo; p.outb = (bf16*)outb; p.ldob = ldob;
+    p.outb2 = (bf16*)outb2; p.ldob2 = ldob2; p.head_stride = head_stride; p.E = E; p.H = H; p.Ntok = tokens;
+    return pevit_launch_gemm(epi, p, g_default_tune, (hipStream_t)stream);
+}
+extern "C" int pevit_op_cast_fp8(void* stream, const float* src, void* codes, int rows, int cols) {
+    return pevit_launch_cast_fp8(src, (unsigned char*)codes, (size_t)rows, cols, (hipStream_t)stream);
 }
 extern "C" int pevit_op_quant_fp8(void* stream, const float* W, int rows, int cols, void* codes, float* scales,
                                   void* codes_t) {

@@ -115,5 +115,25 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + idx;
 }
 
+// fp8 (OCP e4m3) operands of the MX matrix instruction are stored k-permuted inside every group of 128 channels, so that the 32
+// codes one MFMA lane needs of a 64-wide k-step are contiguous: [k-step of 64][lane half][16-group][8] (fp8.hip, gemm.hip)
+__host__ __device__ __forceinline__ int fp8_kperm(int k) {
+    const int grp = k & ~127, kk = k & 127;
+    const int par = kk >> 6, ks = (kk >> 4) & 3, half = (kk >> 3) & 1, j = kk & 7;
+    return grp + par * 64 + half * 32 + ks * 8 + j;
+}
+// 8 consecutive channels k0..k0+7 (k0 % 8 == 0) -> 8 contiguous e4m3 codes at fp8_kperm(k0); values beyond +-448 saturate
+__device__ __forceinline__ void store8_fp8(unsigned char* row_base, int k0, const float v[8]) {
+    float c[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) c[i] = fminf(fmaxf(v[i], -448.0f), 448.0f);
+    int lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(c[0], c[1], lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(c[2], c[3], lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(c[4], c[5], hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(c[6], c[7], hi, true);
+    *reinterpret_cast<int2*>(row_base + fp8_kperm(k0)) = make_int2(lo, hi);
+}
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

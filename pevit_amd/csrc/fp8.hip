@@ -16,13 +16,6 @@
 
 namespace {
 
-// position of input channel k inside its 128-group: [k-tile parity][lane half][k-step][8]
-__host__ __device__ __forceinline__ int fp8_kperm(int k) {
-    const int grp = k & ~127, kk = k & 127;
-    const int par = kk >> 6, ks = (kk >> 4) & 3, half = (kk >> 3) & 1, j = kk & 7;
-    return grp + par * 64 + half * 32 + ks * 8 + j;
-}
-
 __device__ __forceinline__ float pow2_scale(float amax) {
     if (!(amax > 0.f)) return 1.0f;
     int e;
@@ -114,6 +107,28 @@ int pevit_launch_quant_transpose_fp8(const float* W, int rows, int cols, const f
     hipLaunchKernelGGL(quant_transpose_kernel, dim3(ceil_div(cols, 32), ceil_div(rows, 32)), dim3(256), 0, s, W, rows, cols, scale,
                        outT, ldo, scaled_rows, pre);
     LAUNCH_OK("quant_transpose_kernel");
+    return 0;
+}
+
+// unscaled, saturating e4m3 codes of an activation matrix [rows][cols], k-permuted per 128 like the weights (the layout the
+// fp8 x fp8 products read their A operand in; in the step the producers write it themselves)
+__global__ void cast_fp8_kernel(const float* __restrict__ src, unsigned char* __restrict__ dst, size_t rows, int cols) {
+    const size_t n8 = rows * (size_t)cols / 8;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / (cols / 8);
+        const int c = (int)(i - r * (cols / 8)) * 8;
+        const float4 a = *reinterpret_cast<const float4*>(src + r * cols + c), b = *reinterpret_cast<const float4*>(src + r * cols + c + 4);
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        store8_fp8(dst + r * cols, c, v);
+    }
+}
+int pevit_launch_cast_fp8(const float* src, unsigned char* dst, size_t rows, int cols, hipStream_t s) {
+    if (cols % 128) { pevit_set_error("cast_fp8: width %d must be a multiple of 128", cols); return -1; }
+    if (rows == 0) return 0;
+    const size_t n8 = rows * (size_t)cols / 8;
+    const int blocks = (int)((n8 + 255) / 256);
+    hipLaunchKernelGGL(cast_fp8_kernel, dim3(blocks > 4096 ? 4096 : blocks), dim3(256), 0, s, src, dst, rows, cols);
+    LAUNCH_OK("cast_fp8_kernel");
     return 0;
 }
 

@@ -99,6 +99,7 @@ __device__ __forceinline__ bf16x8 fp8x8_to_bf16(int lo, int hi) {
 }
 
 typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(8))) int i32x8;
 
 // Persistent form: gridDim.x workgroups walk the tiles (tile = blockIdx.x, += gridDim.x; gridDim.x
 // is a multiple of 8 so a workgroup's tiles stay on one XCD range).  The first k-tile of the NEXT
@@ -428,15 +429,20 @@ __device__ __forceinline__ void buffer_lds16(const void* base, int bytes, char* 
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_ptr)lds_wave_base, 16, voff, soff, 0, 0);
 }
 
-template <int EPI, int WGM, int WGN, int WM, int WN, int KSP>
+// OPS: 0 = bf16 x bf16; 1 = bf16 x fp8 weights converted to bf16 (bit-identical to 0 on the de-quantised weights);
+// 2 = fp8 x fp8 on the MX-scaled matrix instruction (v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales: twice the
+// bf16 rate, half the operand bytes): A holds e4m3 codes too, written k-permuted like the weights by its producer; a
+// k-tile is then 128 codes = two 64-wide MFMA k-steps in the same 128-byte LDS rows.
+template <int EPI, int WGM, int WGN, int WM, int WN, int KSP, int OPS>
 __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmParams p, int ntiles) {
     constexpr int NW = 8;
+    constexpr bool BF8 = OPS == 1, F8A = OPS == 2;
     static_assert(WGM * WGN == NW && (WN == 1 || WN == 2), "eight waves; one or two fragment columns per wave");
-    constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32, BK = 64;
+    constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32, BK = F8A ? 128 : 64, KSTEP = F8A ? 64 : 16;
     constexpr int ROWB = 128, CH = 8, RPP = 8;
     constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE_BYTES = A_BYTES + B_BYTES;
     constexpr int PA_T = BM / RPP, NPT = (BM + BN) / RPP, NP = (NPT + NW - 1) / NW;   // A pieces, pieces per k-tile, per wave
-    constexpr int KS = BK / 16, NPH = KS / KSP;          // MFMA k-steps per k-tile, phases per k-tile
+    constexpr int KS = BK / KSTEP, NPH = KS / KSP;       // MFMA k-steps per k-tile, phases per k-tile
     constexpr int ISSUE_PH = NPH > 1 ? NPH - 1 : 1;     // phases whose LOAD section carries LDS-DMA requests
     static_assert(BM % RPP == 0 && BN % RPP == 0 && NPH * KSP == KS, "tile geometry");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -445,7 +451,9 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmParams p, int ntiles)
     const int grp = wid >> 2, wm = wid / WGN, wn = wid % WGN;      // stagger groups: waves 0-3 / 4-7, whatever the wave grid
 
     // (rows - 1) * pitch + K elements are readable; the launcher has checked that both fit 31 bits
-    const int a_bytes = ((p.M - 1) * p.lda + p.K) * 2, b_bytes = ((p.Nb - 1) * p.ldb + p.K) * 2;
+    // fp8 B (BF8): rows of 128 codes = TWO k-tiles, requested with the even k-tile into B stage (kt >> 1) & 1 (as in gemm_kernel);
+    // the conversion to bf16 sits in the LOAD section, i.e. beside the partner wave's MFMA section
+    const int a_bytes = ((p.M - 1) * p.lda + p.K) * (F8A ? 1 : 2), b_bytes = ((p.Nb - 1) * p.ldb + p.K) * (BF8 || F8A ? 1 : 2);
     // 1 KiB pieces (8 rows x 128 bytes) of a k-tile: [0, PA_T) = A, then B; wave w requests the pieces w, w + 8, ... (a tile
     // whose piece count is no multiple of 8 -- 160x256: 52 -- leaves the last round to the first waves)
     int voff[NP];
@@ -460,7 +468,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmParams p, int ntiles)
             int r = (is_a ? m0 : n0) + row;
             const int lim = is_a ? p.M : p.Nb;
             r = r < lim ? r : lim - 1;
-            voff[i] = r * ((is_a ? p.lda : p.ldb) * 2) + chunk * 16;
+            voff[i] = r * (is_a ? p.lda * (F8A ? 1 : 2) : p.ldb * (BF8 || F8A ? 1 : 2)) + chunk * 16;
         }
     };
     auto issue_piece = [&](int kt, int i) {
@@ -469,7 +477,8 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmParams p, int ntiles)
         if ((NPT % NW) && q >= NPT) return;
         char* dst = smem + (kt & 1) * STAGE_BYTES + q * 1024;
         if (q < PA_T) buffer_lds16(p.A, a_bytes, dst, voff[i], kt * 128);
-        else buffer_lds16(p.B, b_bytes, dst, voff[i], kt * 128);
+        else if constexpr (!BF8) buffer_lds16(p.B, b_bytes, dst, voff[i], kt * 128);
+        else if (!(kt & 1)) buffer_lds16(p.B, b_bytes, smem + ((kt >> 1) & 1) * STAGE_BYTES + q * 1024, voff[i], (kt >> 1) * 128);
 #endif
     };
     const int frow = lane & 31, fswz = (frow >> 1) & (CH - 1), fhalf = lane >> 5;
@@ -506,17 +515,55 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmParams p, int ntiles)
         for (int kt = 0; kt < nk; ++kt) {
             const char* st = smem + (kt & 1) * STAGE_BYTES;
             const bool more = kt + 1 < nk;
+            i32x4 braw[WN][2];                                    // fp8: this lane's 32 codes of the k-tile per fragment column
 #pragma unroll
             for (int ph = 0; ph < NPH; ++ph) {
                 // ---- LOAD
-                bf16x8 af[KSP][WM], bfr[KSP][WN];
+                typedef typename std::conditional<F8A, i32x8, bf16x8>::type frag_t;
+                frag_t af[KSP][WM], bfr[KSP][WN];
 #if GEMM8_ABLATE != 8
+                if constexpr (F8A) {
+                    // lane (row, half): the 32 codes of k-step ks = chunks 4*ks + 2*half + {0, 1} of its row (k-permuted storage)
+#pragma unroll
+                    for (int s = 0; s < KSP; ++s) {
+                        const int c0 = (ph * KSP + s) * 4 + fhalf * 2;
+                        const int o0 = (c0 ^ fswz) << 4, o1 = ((c0 + 1) ^ fswz) << 4;
+#pragma unroll
+                        for (int j = 0; j < WN; ++j) {
+                            const i32x4 lo = *reinterpret_cast<const i32x4*>(st + b_base + j * 32 * ROWB + o0);
+                            const i32x4 hi = *reinterpret_cast<const i32x4*>(st + b_base + j * 32 * ROWB + o1);
+                            bfr[s][j] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        }
+#pragma unroll
+                        for (int i = 0; i < WM; ++i) {
+                            const i32x4 lo = *reinterpret_cast<const i32x4*>(st + a_base + i * 32 * ROWB + o0);
+                            const i32x4 hi = *reinterpret_cast<const i32x4*>(st + a_base + i * 32 * ROWB + o1);
+                            af[s][i] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        }
+                    }
+                } else {
+                if constexpr (BF8) {
+                    if (ph == 0) {
+                        const char* sb = smem + ((kt >> 1) & 1) * STAGE_BYTES;
+                        const int c0 = (kt & 1) * 4 + fhalf * 2;
+#pragma unroll
+                        for (int j = 0; j < WN; ++j) {
+                            braw[j][0] = *reinterpret_cast<const i32x4*>(sb + b_base + j * 32 * ROWB + ((c0 ^ fswz) << 4));
+                            braw[j][1] = *reinterpret_cast<const i32x4*>(sb + b_base + j * 32 * ROWB + (((c0 + 1) ^ fswz) << 4));
+                        }
+                    }
+                }
 #pragma unroll
                 for (int s = 0; s < KSP; ++s) {
+                    const int ks = ph * KSP + s;
 #pragma unroll
-                    for (int j = 0; j < WN; ++j) bfr[s][j] = *reinterpret_cast<const bf16x8*>(st + b_base + j * 32 * ROWB + coff[ph * KSP + s]);
+                    for (int j = 0; j < WN; ++j) {
+                        if constexpr (BF8) bfr[s][j] = fp8x8_to_bf16(braw[j][ks >> 1][(ks & 1) * 2], braw[j][ks >> 1][(ks & 1) * 2 + 1]);
+                        else bfr[s][j] = *reinterpret_cast<const bf16x8*>(st + b_base + j * 32 * ROWB + coff[ks]);
+                    }
 #pragma unroll
                     for (int i = 0; i < WM; ++i) af[s][i] = *reinterpret_cast<const bf16x8*>(st + a_base + i * 32 * ROWB + coff[ph * KSP + s]);
+                }
                 }
 #endif
                 __builtin_amdgcn_sched_barrier(0);
@@ -537,7 +584,10 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmParams p, int ntiles)
                     for (int i = 0; i < WM; ++i)
 #pragma unroll
                         for (int j = 0; j < WN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][i], bfr[s][j], acc[i][j], 0, 0, 0);
+                        {
+                            if constexpr (F8A) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[s][i], bfr[s][j], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+                            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][i], bfr[s][j], acc[i][j], 0, 0, 0);
+                        }
                 __builtin_amdgcn_s_setprio(0);
 #endif
                 __builtin_amdgcn_sched_barrier(0);
@@ -595,8 +645,16 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmParams p, int ntiles)
             // of their 256-column tile), or a measurement run without stores
         } else if (epi_has_pre<EPI> && inside) {
             if constexpr (epi_has_pre<EPI>) {
-                float cc[8];
+                float cc[8], bsc[8];
                 epi_load_cols<EPI>(p, gc, cc);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bsc[e] = 1.0f;
+                if constexpr (BF8 || F8A) {
+                    if (p.bscale) {
+                        const float4 b0 = *reinterpret_cast<const float4*>(p.bscale + gc), b1 = *reinterpret_cast<const float4*>(p.bscale + gc + 4);
+                        bsc[0] = b0.x; bsc[1] = b0.y; bsc[2] = b0.z; bsc[3] = b0.w; bsc[4] = b1.x; bsc[5] = b1.y; bsc[6] = b1.z; bsc[7] = b1.w;
+                    }
+                }
                 bf16x8 aux_nxt[NPASS];
                 auto load_aux = [&](int i) {
                     if constexpr (epi_reads_aux<EPI>) {
@@ -623,6 +681,10 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmParams p, int ntiles)
                     for (int ps = 0; ps < NPASS; ++ps) {
                         float v[8];
                         from_lds(ps, v);
+                        if constexpr (BF8 || F8A) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] *= bsc[e];
+                        }
                         epilogue_store_pre<EPI, bf16>(p, gr0 + i * 32 + ps * RPASS + erow, gc, v, cc, h[ps]);
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -640,7 +702,10 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmParams p, int ntiles)
                     const int row = gr0 + i * 32 + ps * RPASS + erow;
                     float v[8];
                     from_lds(ps, v);
-                    if (row < p.M && gc < p.N) epilogue_store<EPI, bf16>(p, row, gc, v);
+                    if (row < p.M && gc < p.N) {
+                        if constexpr (BF8 || F8A) { if (p.bscale) mul8(v, p.bscale + gc); }
+                        epilogue_store<EPI, bf16>(p, row, gc, v);
+                    }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1269,10 +1334,10 @@ int use_ksplit(const GemmParams& p, const GemmTune& t, int cfg) {
 }
 
 // the staggered 8-wave kernel: 256x256 (configuration 4) and 320x256 (5), bf16 B, operands addressable with 31-bit byte offsets
-template <int EPI, int WGM, int WGN, int WM, int WN, int KSP>
+template <int EPI, int WGM, int WGN, int WM, int WN, int KSP, int OPS>
 int launch_big8(const GemmParams& p, const GemmTune& t, hipStream_t stream) {
     constexpr int bm = WGM * WM * 32, bn = WGN * WN * 32, lds = 2 * (bm + bn) * 128;
-    auto kern = gemm8_kernel<EPI, WGM, WGN, WM, WN, KSP>;
+    auto kern = gemm8_kernel<EPI, WGM, WGN, WM, WN, KSP, OPS>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
@@ -1292,20 +1357,18 @@ int launch_big8(const GemmParams& p, const GemmTune& t, hipStream_t stream) {
 }
 bool big8_ok(const GemmParams& p, const GemmTune& t) {
     if (!t.stagger || (t.ablate & 12)) return false;
-    const long long a = ((long long)p.M * p.lda + p.K) * 2, b = ((long long)p.Nb * p.ldb + p.K) * 2;
+    const long long a = ((long long)p.M * p.lda + p.K) * 2, b = ((long long)p.Nb * p.ldb + p.K) * (p.b_fp8 ? 1 : 2);
     return a < (1LL << 31) && b < (1LL << 31);
 }
 
 template <int EPI, bool BF8>
 int launch_epi(const GemmParams& p, const GemmTune& t, hipStream_t stream) {
-    const bool stag = !BF8 && big8_ok(p, t);
+    const bool stag = big8_ok(p, t);
     const int cfg = pick_config(p, t, stag);
-    if constexpr (!BF8) {
-        if (stag) {
-            if (cfg == 5) return launch_big8<EPI, 2, 4, 5, 2, 1>(p, t, stream);
-            if (cfg == 4) return launch_big8<EPI, 2, 4, 4, 2, 1>(p, t, stream);
-            if (cfg == CFG_160x256) return launch_big8<EPI, 1, 8, 5, 1, 1>(p, t, stream);
-        }
+    if (stag) {
+        if (cfg == 5) return launch_big8<EPI, 2, 4, 5, 2, 1, BF8 ? 1 : 0>(p, t, stream);
+        if (cfg == 4) return launch_big8<EPI, 2, 4, 4, 2, 1, BF8 ? 1 : 0>(p, t, stream);
+        if (cfg == CFG_160x256) return launch_big8<EPI, 1, 8, 5, 1, 1, BF8 ? 1 : 0>(p, t, stream);
     }
     if constexpr (!BF8 && (EPI == EPI_BIAS_RESID_F32 || EPI == EPI_F32 || EPI == EPI_BF16 || EPI == EPI_BIAS_RESID_KEEP || EPI == EPI_PATCH_EMBED)) {
         const int kwm = use_ksplit(p, t, cfg);
@@ -1327,6 +1390,16 @@ int launch_epi(const GemmParams& p, const GemmTune& t, hipStream_t stream) {
     }
 }
 
+// fp8 x fp8 (GemmParams::a_fp8): always on the staggered kernel; the 8-wave tile whose rounds x bytes-per-k-tile is smallest
+template <int EPI>
+int launch_f8a(const GemmParams& p, const GemmTune& t, hipStream_t stream) {
+    const long long a = (long long)p.M * p.lda + p.K, b = (long long)p.Nb * p.ldb + p.K;
+    if (a >= (1LL << 31) || b >= (1LL << 31)) { pevit_set_error("gemm (fp8 x fp8): operands beyond 2 GiB"); return -1; }
+    // 160x256 on 1 x 8 waves only: a fragment of the 64-deep instruction is 8 registers per lane, and with two fragment columns
+    // per wave (320x256 / 256x256: 160 / 128 accumulator registers + 56 / 48 of fragments) hipcc spills 166 / 26 registers
+    return launch_big8<EPI, 1, 8, 5, 1, 1, 2>(p, t, stream);
+}
+
 }  // namespace
 
 int pevit_gemm_sk_slots() { return min(2 * num_cus(), PEVIT_SK_MAX_SLOTS) & ~7; }
@@ -1337,7 +1410,19 @@ int pevit_launch_gemm(int epi, const GemmParams& p_in, const GemmTune& t, hipStr
     if (p.K % 64 != 0 || p.K <= 0) { pevit_set_error("gemm: K=%d must be a positive multiple of 64", p.K); return -1; }
     if (p.N % 8 != 0) { pevit_set_error("gemm: N=%d must be a multiple of 8", p.N); return -1; }
     if (p.M <= 0 || p.N <= 0) { pevit_set_error("gemm: empty problem M=%d N=%d", p.M, p.N); return -1; }
-    if ((p.lda % 8) || (p.ldb % (p.b_fp8 ? 16 : 8))) { pevit_set_error("gemm: lda/ldb must be multiples of 8 (16 for fp8 B)"); return -1; }
+    if ((!p.a_fp8 && (p.lda % 8)) || (p.ldb % (p.b_fp8 ? 16 : 8))) { pevit_set_error("gemm: lda/ldb must be multiples of 8 (16 for fp8 B)"); return -1; }
+    if (p.a_fp8) {
+        if (!p.b_fp8 || p.K % 128 != 0 || (p.lda % 16)) { pevit_set_error("gemm: fp8 A needs fp8 B, K %% 128 == 0 and lda %% 16 == 0"); return -1; }
+        // the forward frozen products of the block (opt-in weight format "fp8-act")
+        switch (epi) {
+            case EPI_QKV_HEADS: return launch_f8a<EPI_QKV_HEADS>(p, t, stream);
+            case EPI_BIAS_RESID_F32: return launch_f8a<EPI_BIAS_RESID_F32>(p, t, stream);
+            case EPI_BIAS_GELU: return launch_f8a<EPI_BIAS_GELU>(p, t, stream);
+            case EPI_F32: return launch_f8a<EPI_F32>(p, t, stream);
+        }
+        pevit_set_error("gemm: epilogue %d has no fp8 x fp8 form", epi);
+        return -1;
+    }
     if (p.b_fp8) {
         if (p.K % 128 != 0) { pevit_set_error("gemm: fp8 B needs K=%d to be a multiple of 128", p.K); return -1; }
         // the frozen-weight products of the block and their dX forms

@@ -123,7 +123,8 @@ __device__ __forceinline__ void epilogue_store_pre(const GemmParams& p, int row,
         } else {
             store8s<ST>(p.outb, (size_t)row * p.ldob + col, v);
         }
-        store8s<ST>(p.outb2, (size_t)row * p.ldob2 + col, g);
+        if (p.out2_fp8) store8_fp8(reinterpret_cast<unsigned char*>(p.outb2) + (size_t)row * p.ldob2, col, g);   // consumer: fp8 x fp8 c_proj
+        else store8s<ST>(p.outb2, (size_t)row * p.ldob2 + col, g);
     } else {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {

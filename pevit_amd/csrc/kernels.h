@@ -22,6 +22,8 @@ struct GemmParams {
     const bf16* A; int lda;
     const void* B; int ldb; int Nb;   // Nb = readable rows of B (>= N); ldb in elements (bf16, or fp8 codes)
     int b_fp8;                        // B holds e4m3 codes, k-permuted per 128 (fp8_kperm), K % 128 == 0
+    int a_fp8;                        // A holds e4m3 codes as well (lda in codes): fp8 x fp8 on the MX matrix instruction (needs b_fp8)
+    int out2_fp8;                     // EPI_BIAS_GELU: the activation output (outb2, ldob2 in codes) is written as k-permuted e4m3 codes
     const float* bscale;              // fp8 B: per-output-channel (power-of-two) scale, applied to the accumulator
     const float* oscale;              // EPI_DGELU_BF16 only: per-column factor folded into the bf16 output (or null)
     int M, N, K;
@@ -71,7 +73,7 @@ int pevit_launch_gemm(int epi, const GemmParams& p, const GemmTune& t, hipStream
 // y = LN(x) * gamma + beta over the last dim (eps 1e-5, f32 statistics: model.py:154-160)
 int pevit_launch_ln_fwd(const float* x, const float* gamma, const float* beta, int rows, int E,
                         bf16* y_bf16, float* y_f32, float* mean, float* rstd, hipStream_t s,
-                        size_t xstride = 0, int f32 = 0);
+                        size_t xstride = 0, int f32 = 0, unsigned char* y_fp8 = nullptr);   // y_fp8: k-permuted e4m3 copy [rows][E]
 // dx_out = dres + LN-backward(dy)   (gamma/beta frozen: no parameter grads).  dy is f32, or (dy_stored) in the activation
 // storage type -- bf16 in production -- when it is the output of a dX GEMM
 int pevit_launch_ln_bwd(const void* dy, const float* x, const float* mean, const float* rstd,
@@ -81,7 +83,7 @@ int pevit_launch_ln_bwd(const void* dy, const float* x, const float* mean, const
 // ---- attention.hip ---------------------------------------------------------------
 // q,k,v: (B*H, N, 64) bf16 (q pre-scaled by 1/8, deltas already added); out: rows (b*N+n), cols h*64+d
 int pevit_launch_attn_fwd(const bf16* q, const bf16* k, const bf16* v, bf16* out, int ldo,
-                          float* lse, int B, int H, int N, hipStream_t s);
+                          float* lse, int B, int H, int N, hipStream_t s, unsigned char* out_fp8 = nullptr);   // + e4m3 copy, row pitch ldo codes
 // dqkv: row layout [T][ld]: cols [0,E) dq, [E,2E) dk, [2E,3E) dv
 int pevit_launch_attn_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* out, int ldo,
                           const bf16* dout, int lddo, const float* lse, bf16* dqkv, int ld,
@@ -144,6 +146,7 @@ int pevit_launch_quant_rows_fp8(const float* W, int rows, int cols, unsigned cha
 int pevit_launch_quant_transpose_fp8(const float* W, int rows, int cols, const float* scale, unsigned char* outT, int ldo,
                                      int scaled_rows, float pre, hipStream_t s);
 int pevit_launch_cast_bf16_cols(const float* src, bf16* dst, size_t rows, int cols, const float* colscale, hipStream_t s);
+int pevit_launch_cast_fp8(const float* src, unsigned char* dst, size_t rows, int cols, hipStream_t s);
 int pevit_launch_dequant_rows_fp8(const unsigned char* codes, int ldc, const float* scale, int rows, int cols, float* out,
                                   hipStream_t s);
 

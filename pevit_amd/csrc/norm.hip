@@ -14,7 +14,8 @@ template <typename ST>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, int rows, int E, size_t xstride,
                                                      bf16* __restrict__ yb, float* __restrict__ yf,
-                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                     unsigned char* __restrict__ y8) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -57,6 +58,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
             o.w = (v[i].w - mean) * rstd * g.w + b.w;
             if (yb) st_store4<ST>(yb, (size_t)row * E + c, o.x, o.y, o.z, o.w);
             if (yf) *reinterpret_cast<float4*>(yf + (size_t)row * E + c) = o;
+            if (y8) {       // e4m3 copy for the fp8 x fp8 products: 4 consecutive channels stay contiguous under fp8_kperm
+                int w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(o.x, -448.f), 448.f), fminf(fmaxf(o.y, -448.f), 448.f), 0, false);
+                w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(o.z, -448.f), 448.f), fminf(fmaxf(o.w, -448.f), 448.f), w, true);
+                *reinterpret_cast<int*>(y8 + (size_t)row * E + fp8_kperm(c)) = w;
+            }
         }
     }
 }
@@ -129,14 +135,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
 }  // namespace
 
 int pevit_launch_ln_fwd(const float* x, const float* gamma, const float* beta, int rows, int E, bf16* y_bf16,
-                        float* y_f32, float* mean, float* rstd, hipStream_t s, size_t xstride, int f32) {
+                        float* y_f32, float* mean, float* rstd, hipStream_t s, size_t xstride, int f32, unsigned char* y_fp8) {
     if (xstride == 0) xstride = (size_t)E;
     if (E % 4 != 0 || E > 256 * MAXV) { pevit_set_error("ln_fwd: unsupported width %d", E); return -1; }
+    if (y_fp8 && E % 128 != 0) { pevit_set_error("ln_fwd: the fp8 copy needs a width that is a multiple of 128"); return -1; }
     if (rows <= 0) return 0;
     if (f32) hipLaunchKernelGGL(ln_fwd_kernel<float>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, x, gamma, beta, rows, E, xstride,
-                                y_bf16, y_f32, mean, rstd);
+                                y_bf16, y_f32, mean, rstd, y_fp8);
     else hipLaunchKernelGGL(ln_fwd_kernel<bf16>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, x, gamma, beta, rows, E, xstride,
-                            y_bf16, y_f32, mean, rstd);
+                            y_bf16, y_f32, mean, rstd, y_fp8);
     LAUNCH_OK("ln_fwd_kernel");
     return 0;
 }

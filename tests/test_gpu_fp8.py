@@ -266,3 +266,67 @@ def test_config5_vit_l14_fp8_per_gpu_shard_bs32():
         e8.param_views()["layers.0.bias"].zero_()
     losses = [float(e8.train_step(images, labels, lr=0.05, momentum=0.9, weight_decay=0.0)[1]) for _ in range(6)]
     assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < 0.7 * losses[0], losses
+
+
+# ---- opt-in "fp8-act": fp8 x fp8 on the MX-scaled matrix instruction -------------------------------------------------
+def _unperm(codes_u8, cols):
+    from pevit_amd import fp8
+    return codes_u8[:, fp8.kperm(cols).to(codes_u8.device)]
+
+
+@pytest.mark.parametrize("M,N,K", [(6400, 3072, 768), (700, 640, 256), (3200, 768, 3072), (257, 384, 128), (8224, 1024, 1024)])
+def test_gemm_fp8_x_fp8_matches_the_product_of_the_dequantised_operands(lib, M, N, K):
+    """A = saturating unscaled e4m3 codes of an O(1) activation, B = weight codes + channel scales: the kernel's f32 result must
+    equal dequant(A) @ dequant(B)^T (products of two e4m3 values are exact in f32; only the summation differs), for the
+    three tile shapes the launcher picks and the three epilogues of the forward path."""
+    from pevit_amd import fp8
+    A = rnd(M, K, seed=1) * 1.5
+    W = rnd(N, K, seed=2, scale=0.05) * torch.logspace(-1, 1, N, device="cuda")[:, None]
+    bias = rnd(N, seed=5, scale=0.1)
+    resid = rnd(M, N, seed=6)
+    codes, scales, _ = quant(lib, W)
+    acodes = torch.zeros((M, K), dtype=torch.uint8, device="cuda")
+    ok(lib, lib.pevit_op_cast_fp8(S(), P(A), P(acodes), M, K))
+    torch.cuda.synchronize()
+    Ad = _unperm(acodes, K).view(torch.float8_e4m3fn).float()
+    assert torch.equal(Ad, A.clamp(-448, 448).to(torch.float8_e4m3fn).float())          # RNE, natural order after un-permuting
+    Wd = fp8.dequantize_rows(*fp8.quantize_rows(W.cpu())).cuda()
+    ref = Ad @ Wd.T
+    out = torch.full((M, N), float("nan"), device="cuda")
+    ok(lib, lib.pevit_op_gemm_f8a(S(), EPI["BIAS_RESID"], P(acodes), K, P(codes), K, codes.shape[0], P(scales), M, N, K, P(bias),
+                                  P(resid), N, P(out), N, None, 0, None, 0, 0, 0, 0, 0, 0))
+    torch.cuda.synchronize()
+    assert max_rel(out.cpu(), (ref + bias + resid).cpu()) < 2e-4
+    h = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
+    g8 = torch.zeros((M, N), dtype=torch.uint8, device="cuda")
+    if N % 128 == 0:
+        ok(lib, lib.pevit_op_gemm_f8a(S(), EPI["BIAS_GELU"], P(acodes), K, P(codes), K, codes.shape[0], P(scales), M, N, K, P(bias),
+                                      None, 0, None, 0, P(h), N, P(g8), N, 1, 0, 0, 0, 0))
+        torch.cuda.synchronize()
+        href = (ref + bias).to(torch.bfloat16)
+        assert max_rel(h.float().cpu(), href.float().cpu()) < 1e-2
+        gref = (h.float() * torch.sigmoid(1.702 * h.float())).clamp(-448, 448).to(torch.float8_e4m3fn).float()
+        got = _unperm(g8, N).view(torch.float8_e4m3fn).float()
+        # one e4m3 rounding of the kernel's own h: identical up to 1-ulp sigmoid differences that flip a rounding
+        assert float((got != gref).float().mean()) < 2e-3
+        assert max_rel(got.cpu(), gref.cpu()) < 7e-2
+
+
+def test_fp8_act_step_runs_and_stays_close_to_fp8_weights():
+    """Whole step of the opt-in format on a 2-block ViT-B/32-width tower at B = 32: finite, and within e4m3 activation noise of
+    the fp8-weights engine (forward only differs; the measured full-depth deviations are in profiles/r03_fp8_act.md)."""
+    from pevit_amd.engine import HipEngine
+    from pevit_amd.synth import synth_batch
+    from test_gpu_emulation import _case
+    arch, sd = _case("ViT-B/32-2L", "kadaptation", 4)
+    images, labels = synth_batch(32, arch.resolution, 10, seed_img=3, seed_lbl=4)
+    outs = []
+    for wf in ("fp8", "fp8-act"):
+        eng = HipEngine(arch, "kadaptation", 10, 32, weight_format=wf)
+        eng.load_state_dict(sd)
+        logits, loss = eng.forward_backward(images.cuda(), labels.cuda())
+        torch.cuda.synchronize()
+        assert torch.isfinite(logits).all() and torch.isfinite(eng.grads).all()
+        outs.append((logits.clone().cpu(), float(loss), eng.grads.clone().cpu()))
+    assert max_rel(outs[1][0], outs[0][0]) < 0.25
+    assert abs(outs[1][1] - outs[0][1]) < 0.1

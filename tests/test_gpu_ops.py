@@ -332,3 +332,31 @@ def test_lowrank_u_and_grads(lib, Bt, N, E):
     for i in range(4):
         assert max_rel(G[i].cpu(), ref[i].cpu()) < 2e-4, i
     assert max_rel(dbp.sum(0).sum(0).cpu(), (dDq + dDv).sum(0).cpu()) < 2e-4
+
+
+def test_gemm_streamk_with_the_chip_shared(lib):
+    """Stream-K's hand-off assumes its workgroups become resident; under data parallelism the engine switches stream-K off
+    (engine.forward_backward_dp), and the fused SGD kernel skips its update if a hand-off ever timed out.  Here the kernel
+    itself is run while vendor GEMMs on a second stream occupy the CUs (the situation of an overlapped all-reduce): every
+    launch must still produce the bit-identical result without raising the error word -- producers publish the tail of a
+    tile before they start anything else, so a consumer only ever waits for work that is already running or done."""
+    M, N, K = 2500, 768, 3072
+    A = rnd(M, K, seed=1, dtype=torch.bfloat16)
+    B = rnd(768, K, seed=2, scale=0.05, dtype=torch.bfloat16)
+    bias = rnd(N, seed=5, scale=0.1)
+    resid = rnd(M, N, seed=6)
+    ref = torch.full((M, N), float("nan"), device="cuda")
+    gemm(lib, EPI["BIAS_RESID"], A, B, M, N, K, bias=bias, resid=resid, outf=ref, b_rows=768)
+    assert lib.pevit_streamk_error(None, S()) == 0
+    side = torch.cuda.Stream()
+    big = torch.randn(8192, 8192, device="cuda", dtype=torch.bfloat16)
+    for it in range(6):
+        with torch.cuda.stream(side):
+            for _ in range(4):
+                big @ big                                   # ~1 ms each on all 256 CUs
+        out = torch.full((M, N), float("nan"), device="cuda")
+        for _ in range(5):
+            gemm(lib, EPI["BIAS_RESID"], A, B, M, N, K, bias=bias, resid=resid, outf=out, b_rows=768)
+            assert torch.equal(out, ref)
+    side.synchronize()
+    assert lib.pevit_streamk_error(None, S()) == 0
