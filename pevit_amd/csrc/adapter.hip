@@ -16,6 +16,7 @@
 //   * the chain rule from the dense panels back to the reference's parameter tensors.
 #include "common.h"
 #include "kernels.h"
+#include "gemm_epilogue.h"
 
 namespace {
 
@@ -398,6 +399,121 @@ __global__ __launch_bounds__(256) void chain_compacter_kernel(const float* __res
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Bottleneck pair in ONE launch:  S = fn(X W1^T [+ b1])  (T x 64, K = E),  out = S W2^T [+ b2 + resid]  (T x E, K = 64).
+//   forward  (adapter_model.py:270-272 / compacter_model.py:437-443): X = z = LN_a(h), W1 = down, fn = ReLU | gelu_new,
+//            S = act (saved; Compacter also saves the bf16 pre-activation), W2 = up, resid = x_mid + h  -> block output (f32)
+//   backward: X = d out (bf16), W1 = up^T, fn = multiply by act'(saved), S = d pre (saved for the weight gradients),
+//            W2 = down^T -> d z (f32)
+// As two GEMM launches these were N = 64 and K = 64 products on 64x64 tiles (100 workgroups, ~1 % MFMA utilisation,
+// 12.6 + 10.3 us forward, 10.9 + 8.6 us backward per layer in step); here a workgroup owns 32 token rows: phase 1 on four
+// waves = 2 column fragments x 2 halves of K (fragment-shaped global loads: X is read once, W1 comes from L2), the halves
+// meet through LDS, S goes to LDS (and HBM); phase 2: every wave multiplies S by six 32-row panels of W2.
+// Same rounding points as the two-launch form (S rounded to bf16 once, f32 accumulation).
+enum { BN_FWD_RELU = 0, BN_FWD_GELUNEW = 1, BN_BWD_RELU = 2, BN_BWD_GELUNEW = 3 };
+constexpr int BNK_ROWS = 32, BNK_LDS = 72;      // token rows per workgroup; row stride (elements) of S in LDS
+
+template <int MODE>
+__global__ __launch_bounds__(256) void bottleneck_pair_kernel(const bf16* __restrict__ X, int ldx, const bf16* __restrict__ W1,
+                                                              const float* __restrict__ b1, const bf16* __restrict__ aux,
+                                                              bf16* __restrict__ S_out, bf16* __restrict__ S_pre,
+                                                              const bf16* __restrict__ W2, const float* __restrict__ b2,
+                                                              const float* __restrict__ resid, float* __restrict__ out, int T, int E) {
+    __shared__ __attribute__((aligned(16))) float red[2][16][64];
+    __shared__ __attribute__((aligned(16))) bf16 Ss[BNK_ROWS * BNK_LDS];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int r0 = blockIdx.x * BNK_ROWS;
+    const int frow = lane & 31, fhalf = lane >> 5;
+    // ---- phase 1: wave = (column fragment nf, K half kh)
+    {
+        const int nf = wid & 1, kh = wid >> 1;
+        const int row = min(r0 + frow, T - 1);
+        const bf16* xa = X + (size_t)row * ldx + kh * (E / 2) + 8 * fhalf;
+        const bf16* wb = W1 + (size_t)(nf * 32 + frow) * E + kh * (E / 2) + 8 * fhalf;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const int steps = E / 32;                       // 16-deep k-steps per half
+#pragma unroll 8
+        for (int ks = 0; ks < steps; ++ks)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_bf16x8(xa + 16 * ks), load_bf16x8(wb + 16 * ks), acc, 0, 0, 0);
+        if (kh == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[nf][r][lane] = acc[r];
+        }
+        __syncthreads();
+        if (kh == 0) {
+            const int col = nf * 32 + frow;
+            const float bias = (MODE == BN_FWD_RELU || MODE == BN_FWD_GELUNEW) ? b1[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lr = (r & 3) + 8 * (r >> 2) + 4 * fhalf, grow = r0 + lr;
+                float v = acc[r] + red[nf][r][lane] + bias;
+                bf16 sv;
+                if constexpr (MODE == BN_FWD_RELU) {
+                    sv = f2bf(fmaxf(v, 0.f));
+                } else if constexpr (MODE == BN_FWD_GELUNEW) {
+                    const bf16 pre = f2bf(v);
+                    if (grow < T) S_pre[(size_t)grow * 64 + col] = pre;
+                    sv = f2bf(gelu_new_f(bf2f(pre)));
+                } else {
+                    const float a = grow < T ? bf2f(aux[(size_t)grow * 64 + col]) : 0.f;
+                    if constexpr (MODE == BN_BWD_RELU) sv = f2bf(a > 0.f ? v : 0.f);
+                    else sv = f2bf(v * gelu_new_grad_f(a));
+                }
+                Ss[lr * BNK_LDS + col] = sv;
+                if (grow < T) S_out[(size_t)grow * 64 + col] = sv;
+            }
+        }
+        __syncthreads();
+    }
+    // ---- phase 2: out[32 x E] = S[32 x 64] W2^T, wave w takes the 32-column panels w, w + 4, ... in batches of FB: all
+    // loads of a batch (W2 fragments, residual values) are issued before its first store -- a load after a store makes hipcc
+    // wait with vmcnt(0), i.e. for the store (the first version of this kernel ran 54 us that way)
+    constexpr int FB = 4;
+    bf16x8 sa[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) sa[ks] = *reinterpret_cast<const bf16x8*>(Ss + frow * BNK_LDS + 16 * ks + 8 * fhalf);
+    const int nfr = E / 32;
+    for (int f0 = wid; f0 < nfr; f0 += 4 * FB) {
+        f32x16 acc[FB];
+        float rv[FB][16], bias[FB];
+        bf16x8 wf[FB][4];
+#pragma unroll
+        for (int i = 0; i < FB; ++i) {
+            const int f = min(f0 + 4 * i, nfr - 1), col = f * 32 + frow;
+            const bf16* wb = W2 + (size_t)col * 64 + 8 * fhalf;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) wf[i][ks] = load_bf16x8(wb + 16 * ks);
+            bias[i] = b2 ? b2[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int grow = min(r0 + (r & 3) + 8 * (r >> 2) + 4 * fhalf, T - 1);
+                rv[i][r] = resid ? resid[(size_t)grow * E + col] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < FB; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[ks], wf[i][ks], acc[i], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < FB; ++i) {
+            const int f = f0 + 4 * i, col = f * 32 + frow;
+            if (f < nfr) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int grow = r0 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+                    if (grow < T) out[(size_t)grow * E + col] = acc[i][r] + bias[i] + rv[i][r];
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 int pevit_tn_chunks(int T) { return ceil_div(T, TG_ROWS); }
@@ -473,5 +589,21 @@ int pevit_launch_chain_compacter(const float* Gd, const float* Gu, const float* 
     hipLaunchKernelGGL(chain_compacter_kernel, dim3(4, layers, 4), dim3(256), 0, s, Gd, Gu, rule, params, grads, E, g_layer,
                        param_layer, off_dWl, off_dWr, off_uWl, off_uWr);
     LAUNCH_OK("chain_compacter_kernel");
+    return 0;
+}
+
+int pevit_launch_bottleneck_pair(int mode, const bf16* X, int ldx, const bf16* W1, const float* b1, const bf16* aux, bf16* S_out,
+                                 bf16* S_pre, const bf16* W2, const float* b2, const float* resid, float* out, int T, int E,
+                                 hipStream_t s) {
+    if (E % 64 != 0 || T <= 0) { pevit_set_error("bottleneck_pair: bad shape T=%d E=%d", T, E); return -1; }
+    const dim3 grid(ceil_div(T, BNK_ROWS)), block(256);
+    switch (mode) {
+        case BN_FWD_RELU: hipLaunchKernelGGL(bottleneck_pair_kernel<BN_FWD_RELU>, grid, block, 0, s, X, ldx, W1, b1, aux, S_out, S_pre, W2, b2, resid, out, T, E); break;
+        case BN_FWD_GELUNEW: hipLaunchKernelGGL(bottleneck_pair_kernel<BN_FWD_GELUNEW>, grid, block, 0, s, X, ldx, W1, b1, aux, S_out, S_pre, W2, b2, resid, out, T, E); break;
+        case BN_BWD_RELU: hipLaunchKernelGGL(bottleneck_pair_kernel<BN_BWD_RELU>, grid, block, 0, s, X, ldx, W1, b1, aux, S_out, S_pre, W2, b2, resid, out, T, E); break;
+        case BN_BWD_GELUNEW: hipLaunchKernelGGL(bottleneck_pair_kernel<BN_BWD_GELUNEW>, grid, block, 0, s, X, ldx, W1, b1, aux, S_out, S_pre, W2, b2, resid, out, T, E); break;
+        default: pevit_set_error("bottleneck_pair: unknown mode %d", mode); return -1;
+    }
+    LAUNCH_OK("bottleneck_pair_kernel");
     return 0;
 }

@@ -106,6 +106,8 @@ struct pevit_ctx {
     // A/B-measurement knobs (pevit_tune): per context, so that contexts stay independent of each other
     GemmTune tune;
     int dx_stored = 1;        // dX GEMMs hand the LN-input gradient to LayerNorm backward in the activation storage type (bf16)
+    int fused_bn = 0;         // post-MLP adapters: down -> activation -> up (and its backward) as one launch each (adapter.hip
+                              // bottleneck_pair_kernel): 24.4 + 22.1 us against 22.9 + 19.5 us for the four GEMM launches -- opt-in
     int side_stream = 0;      // adapter-gradient contractions on a second stream: +0.5 % step throughput, but it slows the GEMMs
                               // it overlaps by 4 %, which blurs the per-kernel roofline measurement: off by default
 };
@@ -632,21 +634,28 @@ int blocks_forward(pevit_ctx* c, hipStream_t s, int B, bool cls_only) {
             }
             CHECK(pevit_launch_ln_fwd(at<float>(W, v.hf32), lp + c->o_nw, lp + c->o_nb, T, E, at<bf16>(W, v.z), nullptr,
                                       at<float>(W, v.mean_a), at<float>(W, v.rstd_a), s, 0, c->f32));
+            if (c->fused_bn && !c->f32) {
+                // down -> activation -> up (+ bias + x_mid + h) in one launch (adapter.hip bottleneck_pair_kernel)
+                CHECK(pevit_launch_bottleneck_pair(c->d.method == PEVIT_ADAPTER ? 0 : 1, at<bf16>(W, v.z), E, at<bf16>(A, b.wd), lp + c->o_db,
+                                                   nullptr, at<bf16>(W, v.act), at<bf16>(W, v.apre), at<bf16>(A, b.wu), lp + c->o_ub, ytmp,
+                                                   x_out, T, E, s));
+            } else {
             {
-                GemmParams p = gp(at<bf16>(W, v.z), E, at<bf16>(A, b.wd), E, 64, T, 64, E);
-                p.bias = lp + c->o_db;
-                if (c->d.method == PEVIT_ADAPTER) {
-                    p.outb = at<bf16>(W, v.act); p.ldob = 64;
-                    CHECK(gemm(c, EPI_BIAS_RELU_BF16, p, s));
-                } else {
-                    p.outb = at<bf16>(W, v.apre); p.ldob = 64; p.outb2 = at<bf16>(W, v.act); p.ldob2 = 64;
-                    CHECK(gemm(c, EPI_BIAS_GELUNEW, p, s));
+                    GemmParams p = gp(at<bf16>(W, v.z), E, at<bf16>(A, b.wd), E, 64, T, 64, E);
+                    p.bias = lp + c->o_db;
+                    if (c->d.method == PEVIT_ADAPTER) {
+                        p.outb = at<bf16>(W, v.act); p.ldob = 64;
+                        CHECK(gemm(c, EPI_BIAS_RELU_BF16, p, s));
+                    } else {
+                        p.outb = at<bf16>(W, v.apre); p.ldob = 64; p.outb2 = at<bf16>(W, v.act); p.ldob2 = 64;
+                        CHECK(gemm(c, EPI_BIAS_GELUNEW, p, s));
+                    }
                 }
-            }
-            {
-                GemmParams p = gp(at<bf16>(W, v.act), 64, at<bf16>(A, b.wu), 64, E, T, E, 64);
-                p.bias = lp + c->o_ub; p.resid = ytmp; p.ldr = E; p.outf = x_out; p.ldo = E;
-                CHECK(gemm(c, EPI_BIAS_RESID_F32, p, s));
+                {
+                    GemmParams p = gp(at<bf16>(W, v.act), 64, at<bf16>(A, b.wu), 64, E, T, E, 64);
+                    p.bias = lp + c->o_ub; p.resid = ytmp; p.ldr = E; p.outf = x_out; p.ldo = E;
+                    CHECK(gemm(c, EPI_BIAS_RESID_F32, p, s));
+                }
             }
         }
     }
@@ -695,11 +704,23 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0, bool cls_
             else
                 CHECK(pevit_launch_tn_gemm64(dyb, E, at<bf16>(W, v.act), 64, at<float>(W, c->w_tnU + (size_t)l * c->tn_layer),
                                              nullptr, nullptr, T, E, s));
+            if (c->fused_bn && !c->f32) {
+                // d pre = (dx_out W_up) * act'(saved) ; d z = d pre W_down, one launch
+                CHECK(pevit_launch_bottleneck_pair(c->d.method == PEVIT_ADAPTER ? 2 : 3, dyb, E, at<bf16>(A, b.wuT), nullptr,
+                                                   c->d.method == PEVIT_ADAPTER ? at<bf16>(W, v.act) : at<bf16>(W, v.apre), dpre, nullptr,
+                                                   at<bf16>(A, b.wdT), nullptr, nullptr, dxn, T, E, s));
+            } else {
             {   // d act = dx_out W_up ; d pre = d act * act'(pre)
                 GemmParams p = gp(dyb, E, at<bf16>(A, b.wuT), E, 64, T, 64, E);
                 p.outb = dpre; p.ldob = 64; p.ldaux = 64;
                 if (c->d.method == PEVIT_ADAPTER) { p.aux = at<bf16>(W, v.act); CHECK(gemm(c, EPI_DRELU_BF16, p, s)); }
                 else { p.aux = at<bf16>(W, v.apre); CHECK(gemm(c, EPI_DGELUNEW_BF16, p, s)); }
+            }
+            {   // d z = d pre W_down
+                GemmParams p = gp(dpre, 64, at<bf16>(A, b.wdT), 64, E, T, E, 64);
+                p.outf = dxn; p.ldo = E;
+                CHECK(gemm(c, EPI_F32, p, s));
+            }
             }
             // d W_down[j][e] = sum_r d pre[r][j] z[r][e] ; d b_down = colsum(d pre)
             if (c->f32)
@@ -708,11 +729,6 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0, bool cls_
             else
                 CHECK(pevit_launch_tn_gemm64(at<bf16>(W, v.z), E, dpre, 64, at<float>(W, c->w_tnD + (size_t)l * c->tn_layer), nullptr,
                                              at<float>(W, c->w_csy + (size_t)l * c->csy_layer), T, E, s));
-            {   // d z = d pre W_down
-                GemmParams p = gp(dpre, 64, at<bf16>(A, b.wdT), 64, E, T, E, 64);
-                p.outf = dxn; p.ldo = E;
-                CHECK(gemm(c, EPI_F32, p, s));
-            }
             // d h = dx_out + LN_a-backward(d z) ; partial sums for d gamma_a, d beta_a
             CHECK(pevit_launch_ln_bwd_affine(dxn, at<float>(W, v.hf32), at<float>(W, v.mean_a), at<float>(W, v.rstd_a), lp + c->o_nw,
                                              dxa, at<float>(W, c->w_dht), at<bf16>(W, c->w_dhb),
@@ -1236,6 +1252,7 @@ extern "C" int pevit_tune(pevit_ctx* c, const char* key, int value) {
     if (key && !strcmp(key, "gemm_cfg_shortk")) { t.cfg_shortk = value; return 0; }
     if (key && !strcmp(key, "gemm_big_bias")) { t.big_bias = value; return 0; }
     if (key && c && !strcmp(key, "side_stream")) { c->side_stream = value; return 0; }
+    if (key && c && !strcmp(key, "fused_bottleneck")) { c->fused_bn = value; return 0; }
     if (key && !strcmp(key, "gemm_streamk")) { t.streamk = value; return 0; }
     if (key && !strcmp(key, "gemm_sk_share")) { t.sk_share = value; return 0; }
     if (key && !strcmp(key, "gemm_sk_band")) { t.sk_band = value; return 0; }

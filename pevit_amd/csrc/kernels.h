@@ -183,6 +183,11 @@ int pevit_launch_prep_compacter(const float* rule, const float* dWl, const float
 // G[e][j] = sum_r X[r][e] Y[r][j] (per-chunk partials [chunk][E][64]); optional column sums of X / Y
 int pevit_launch_tn_gemm64(const bf16* X, int ldx, const bf16* Y, int ldy, float* partial, float* csx, float* csy, int T, int E,
                            hipStream_t s);
+// S = fn(X W1^T [+ b1]) (T x 64, saved) ; out = S W2^T [+ b2 + resid] (f32) in one launch.  mode: 0 forward ReLU, 1 forward
+// gelu_new (S_pre = bf16 pre-activation), 2 / 3 backward (fn = multiply by the activation derivative at the saved aux)
+int pevit_launch_bottleneck_pair(int mode, const bf16* X, int ldx, const bf16* W1, const float* b1, const bf16* aux, bf16* S_out,
+                                 bf16* S_pre, const bf16* W2, const float* b2, const float* resid, float* out, int T, int E,
+                                 hipStream_t s);
 int pevit_launch_ln_bwd_affine(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                                const float* dres, float* dx, bf16* dx_bf16, float* partial, int rows, int E, hipStream_t s, int f32 = 0);
 int pevit_launch_colsum_reduce(const float* partial, int chunks, int n, float* out, int layers, size_t partial_layer,

@@ -6,7 +6,7 @@
 set -x
 export TMPDIR=/tmp
 R=$PWD
-TAG=${1:-r02}
+TAG=${1:-r03}
 O=$R/gpurun_out/pmc_$TAG
 rm -rf $O; mkdir -p $O/fetch $O/write $O/ktrace $O/mfma
 cd /tmp
@@ -17,6 +17,7 @@ timeout 600 rocprofv3 --kernel-trace --stats -d $O/ktrace -o k -- python $R/benc
 cd $R
 F=$(find $O/fetch -name "*.db" | head -1); W=$(find $O/write -name "*.db" | head -1); K=$(find $O/ktrace -name "*.db" | head -1); M=$(find $O/mfma -name "*.db" | head -1)
 python scripts/pmc_traffic.py $F $W "ViT-B/32|kadaptation|bs128" profiles/hbm_traffic.json > $O/traffic.txt 2>&1
+cp profiles/hbm_traffic.json $R/gpurun_out/hbm_traffic.json     # profiles/ does not travel back from the GPU box: copy it from gpurun_out/
 python scripts/prof_summary.py $K 45 > $O/kernel_stats.md 2>&1
 python scripts/pmc_mfma.py $M > $O/mfma_util.md 2>&1
 python bench.py > $O/bench_line.json 2>$O/bench_err.log
