@@ -42,7 +42,7 @@ def train_gflop_per_image(E, L, P, R, D, C, rank, attention_site=True):
 
 
 PEAK_TFLOPS_BF16 = 2500.0     # dense MFMA bf16, MI355X_MICROARCH.md
-CPU_BASELINE_THREADS = 32     # best of the sweep 8/16/32/64/128 on the GPU box's host (profiles/r03_cpu_thread_sweep.md)
+CPU_BASELINE_THREADS = 16     # best of the sweep 8/16/32/64/128 on the GPU box's host (profiles/r03_cpu_thread_sweep.md)
 EPI_NAMES = {0: "qkv(+t) -> head layout", 1: "bias+residual f32", 2: "bias+QuickGELU", 3: "dQuickGELU", 4: "f32", 5: "bf16",
              6: "bias bf16", 7: "patch embed", 8: "bias+ReLU", 9: "bias+residual (keep h)", 10: "bias+gelu_new",
              11: "dReLU", 12: "dgelu_new"}

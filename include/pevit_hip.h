@@ -109,7 +109,9 @@ int pevit_bind(pevit_ctx* ctx, void* arena, size_t arena_bytes, void* workspace,
 int pevit_set_params(pevit_ctx* ctx, float* params, float* grads, float* momentum,
                      const unsigned char* grad_mask);
 
-/* frozen weights: device f32 pointers in the OpenAI state-dict layout */
+/* frozen weights: device f32 pointers in the OpenAI state-dict layout.  With fp8 weights pevit_load_block uses
+ * the bound workspace as packing scratch: call it after pevit_bind, on the stream the context trains on, and not between a
+ * forward and its backward (the saved activations are invalidated: the next backward without a new forward fails). */
 int pevit_load_block(pevit_ctx* ctx, void* stream, int layer, const float* in_proj_weight,
                      const float* in_proj_bias, const float* out_proj_weight, const float* out_proj_bias,
                      const float* ln_1_weight, const float* ln_1_bias, const float* c_fc_weight,

@@ -412,7 +412,11 @@ extern "C" int pevit_load_block(pevit_ctx* c, void* stream, int l, const float* 
         // QKV backward (bf16): the transposed copy holds the DE-QUANTISED weights, exactly representable in bf16
         HIP_OK(hipMemsetAsync(A + b.wqkvT, 0, E * (size_t)c->NQ * 2, s));
         const size_t skip = align_up((size_t)(PEVIT_SK_MAX_SLOTS + 1) * 4, 256);    // the stream-K flags stay zero
-        float* tmp = at<float>(c->ws, skip);    // 3E*E floats of the (not yet used) workspace
+        // 3E*E floats of the bound workspace serve as packing scratch: whatever activations a previous forward saved there
+        // are overwritten, so a backward through them is refused from here on (saved_batch = 0), and the load must be
+        // issued on the stream the engine trains on (include/pevit_hip.h: one stream per context)
+        float* tmp = at<float>(c->ws, skip);
+        c->saved_batch = 0; c->saved_kind = 0;
         if (skip + (size_t)3 * E * E * 4 > c->ws_bytes_for_max) { pevit_set_error("load_block: workspace too small for the fp8 packing scratch"); return -1; }
         CHECK(pevit_launch_dequant_rows_fp8(at<u8>(A, b.wqkv), e, at<float>(A, b.sqkv), 3 * e, e, tmp, s));
         CHECK(pevit_launch_transpose_bf16(tmp, 3 * e, e, at<bf16>(A, b.wqkvT), c->NQ, 0, 1.0f, s));

@@ -195,12 +195,15 @@ class ClassifierBase(nn.Module):
             self.channel_bn = nn.Identity()
 
         visual = self.backbone.visual
-        wf = str(config.MODEL.get("WEIGHT_FORMAT", "bf16")) if hasattr(config.MODEL, "get") else "bf16"
-        if wf != "bf16":
-            visual.weight_format = wf
+        # MODEL.WEIGHT_FORMAT, when the config has the key, is authoritative (an explicit "bf16" is not overridden by the
+        # PEVIT_WEIGHT_FORMAT environment default the tower was constructed with); a change of format drops a stale engine
+        wf = config.MODEL.get("WEIGHT_FORMAT", None) if hasattr(config.MODEL, "get") else None
+        if wf is not None:
+            visual.weight_format = str(wf)
         visual._num_classes = output_dim
         visual._max_batch = max(int(config.TRAIN.BATCH_SIZE_PER_GPU), int(config.TEST.BATCH_SIZE_PER_GPU))
-        if visual._engine is not None and visual._engine.num_classes != output_dim:
+        if visual._engine is not None and (visual._engine.num_classes != output_dim or
+                                           visual._engine.weight_format != visual.weight_format):
             visual._engine = None
         self._bound = None
 

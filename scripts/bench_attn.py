@@ -21,10 +21,4 @@ dqkv = torch.zeros(B * N, ld, dtype=torch.bfloat16, device="cuda")
 fwd = lambda: lib.pevit_op_attn_fwd(S(), P(q), P(k), P(v), P(out), E, P(lse), B, H, N)
 bwd = lambda: lib.pevit_op_attn_bwd(S(), P(q), P(k), P(v), P(out), E, P(do), E, P(lse), P(dqkv), ld, B, H, N)
 print(f"attn fwd {timeit(fwd):.1f} us")
-for ph in (1, 2, 3):
-    lib.pevit_tune(b"attn_bwd_phase", ph)
-    print(f"attn bwd phase<={ph}: {timeit(bwd):.1f} us")
-for ph in (5, 6, 7):
-    lib.pevit_tune(b"attn_bwd_phase", ph)
-    print(f"attn bwd without row-major LDS copies, phase<={ph & 3}: {timeit(bwd):.1f} us")
-lib.pevit_tune(b"attn_bwd_phase", 3)
+print(f"attn bwd {timeit(bwd):.1f} us")

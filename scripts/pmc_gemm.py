@@ -6,7 +6,7 @@ lib = _lib.load()
 P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
 S = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
 def run(M, N, K, cfg, iters):
-    lib.pevit_tune(b"gemm_config", cfg)
+    lib.pevit_tune(None, b"gemm_config", cfg)
     A = torch.randn(M, K, device="cuda").bfloat16(); B = (torch.randn((N + 127) // 128 * 128, K, device="cuda") * 0.05).bfloat16()
     out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
     for _ in range(iters):

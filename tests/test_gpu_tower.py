@@ -513,3 +513,27 @@ def test_single_sample_batches_fail_like_batchnorm():
     logits, loss = eng.forward_backward(img, lab, bn_training=False)
     torch.cuda.synchronize()
     assert logits.shape == (1, meta["classes"]) and torch.isfinite(logits).all() and torch.isfinite(loss).all()
+
+
+def test_bf16_ln_input_gradient_hand_over_costs_what_it_is_said_to():
+    """The dX GEMMs hand the LayerNorm-input gradient to LayerNorm backward in bf16 (`dx_stored=1`, the production default:
+    one more rounding on the gradient path, half the bytes on both sides of an HBM-bound kernel).  Its price is pinned here:
+    same step, same inputs, `dx_stored` 1 vs 0 (f32 hand-over) -- logits identical (forward untouched), every gradient tensor
+    within 1.5e-2 relative L2 (measured <= 6e-3 on the 2-block B = 128 tower), so a precision regression of the production
+    path cannot hide behind the calibrated gates of the fixture tests."""
+    from pevit_amd.engine import HipEngine
+    from pevit_amd.synth import synth_batch
+    arch, sd = _full_size_case("ViT-B/32-2L", "kadaptation", 4)
+    B, C = 128, 100
+    images, labels = synth_batch(B, arch.resolution, C, seed_img=3, seed_lbl=4)
+    outs = []
+    for stored in (1, 0):
+        eng = HipEngine(arch, "kadaptation", C, B)
+        eng.load_state_dict(sd)
+        assert eng.tune("dx_stored", stored) == 0
+        logits, loss = eng.forward_backward(images.cuda(), labels.cuda())
+        torch.cuda.synchronize()
+        outs.append((logits.clone().cpu(), {k: v.clone().cpu() for k, v in eng.grad_views().items()}))
+    assert torch.equal(outs[0][0], outs[1][0])
+    worst = max((rel_err(outs[0][1][k], outs[1][1][k]), k) for k in outs[1][1] if float(outs[1][1][k].abs().max()) > 0)
+    assert worst[0] < 1.5e-2, worst
