@@ -128,6 +128,13 @@ int pevit_transformer_forward(pevit_ctx* ctx, void* stream, const float* x_nbe, 
                               int save_for_backward);
 int pevit_transformer_backward(pevit_ctx* ctx, void* stream, const float* dy_nbe, float* dx_nbe_or_null,
                                int batch);
+/* blocks [l_lo, l_hi) only -- ResidualAttentionBlock.forward (model.py:972-975) for l_hi = l_lo + 1, MultiheadAttention.forward
+ * (model.py:837) being the attention half of it; pevit_transformer_* = the range [0, layers).  Every block keeps its own saved
+ * activations: the blocks may be walked one call at a time and differentiated in reverse order (a walk starts at block 0). */
+int pevit_blocks_forward(pevit_ctx* ctx, void* stream, const float* x_nbe, float* y_nbe, int batch, int save_for_backward,
+                         int l_lo, int l_hi);
+int pevit_blocks_backward(pevit_ctx* ctx, void* stream, const float* dy_nbe, float* dx_nbe_or_null, int batch, int l_lo,
+                          int l_hi);
 int pevit_visual_forward(pevit_ctx* ctx, void* stream, const float* images, float* feat, int batch,
                          int save_for_backward);
 int pevit_visual_backward(pevit_ctx* ctx, void* stream, const float* dfeat, int batch);

@@ -45,6 +45,8 @@ SIGNATURES = {
     "pevit_load_phm_rule": (c_int, [P, P, P]),
     "pevit_transformer_forward": (c_int, [P, P, P, P, c_int, c_int]),
     "pevit_transformer_backward": (c_int, [P, P, P, P, c_int]),
+    "pevit_blocks_forward": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int]),
+    "pevit_blocks_backward": (c_int, [P, P, P, P, c_int, c_int, c_int]),
     "pevit_visual_forward": (c_int, [P, P, P, P, c_int, c_int]),
     "pevit_visual_backward": (c_int, [P, P, P, c_int]),
     "pevit_visual_backward_part": (c_int, [P, P, P, c_int, c_int, c_int]),

@@ -545,13 +545,14 @@ GemmParams gpw(const pevit_ctx* c, const bf16* A, int lda, size_t w_off, int ldb
 // cls_only: the caller consumes only the class token of the last block (VisionTransformer.forward,
 // model.py:1046) -- everything of the last block that sits after the attention core is then
 // evaluated on the B class-token rows only (identical results, ~6 % fewer FLOPs per step).
-int blocks_forward(pevit_ctx* c, hipStream_t s, int B, bool cls_only) {
+int blocks_forward(pevit_ctx* c, hipStream_t s, int B, bool cls_only, int l_lo = 0, int l_hi = -1) {
+    if (l_hi < 0) l_hi = c->L;
     const int E = c->E, T = B * c->N, H = c->H, N = c->N;
     cls_only = cls_only && !post_mlp(c);
     char* W = c->ws; char* A = c->arena;
     const bool site = attention_site(c);
     if (site || post_mlp(c)) CHECK(prep_adapters(c, s));
-    for (int l = 0; l < c->L; ++l) {
+    for (int l = l_lo; l < l_hi; ++l) {
         const BlockArena& b = c->blk[l];
         const LayerSaved& v = c->sav[l];
         float* x_in = at<float>(W, v.x_in);
@@ -855,22 +856,38 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0, bool cls_
 
 }  // namespace
 
-extern "C" int pevit_transformer_forward(pevit_ctx* c, void* stream, const float* x_nbe, float* y_nbe, int B,
-                                         int save_for_backward) {
-    CHECK(check_ready(c, B, "transformer_forward"));
+// Blocks [l_lo, l_hi) of the tower on (N,B,E) activations: ResidualAttentionBlock.forward (model.py:972-975) for one block,
+// Transformer.forward (model.py:1013) for all of them.  Every block keeps its own saved activations, so the blocks can be
+// walked one call at a time (reference-side code that iterates visual.transformer.resblocks) and differentiated in reverse.
+extern "C" int pevit_blocks_forward(pevit_ctx* c, void* stream, const float* x_nbe, float* y_nbe, int B, int save_for_backward,
+                                    int l_lo, int l_hi) {
+    CHECK(check_ready(c, B, "blocks_forward"));
+    if (l_lo < 0 || l_hi > c->L || l_lo >= l_hi) { pevit_set_error("blocks_forward: bad block range [%d, %d)", l_lo, l_hi); return -1; }
     hipStream_t s = (hipStream_t)stream;
     size_t total; layout_workspace(c, B, c->sav, &total, c);
-    CHECK(pevit_launch_permute_rows(x_nbe, at<float>(c->ws, c->sav[0].x_in), c->N, B, c->E, 1, s));
-    CHECK(blocks_forward(c, s, B, false));
-    CHECK(pevit_launch_permute_rows(at<float>(c->ws, c->w_xfinal), y_nbe, c->N, B, c->E, 0, s));
+    // a walk over the blocks starts at block 0: the per-layer scratch of the shared KAdaptation rule gradients starts clean, so
+    // that a backward through SOME blocks only never adds another step's contribution (rule_sum adds all L layers)
+    if (l_lo == 0 && c->d.method == PEVIT_KADAPTATION) HIP_OK(hipMemsetAsync(c->ws + c->w_rule, 0, (size_t)c->L * 4096 * 4, s));
+    CHECK(pevit_launch_permute_rows(x_nbe, at<float>(c->ws, c->sav[l_lo].x_in), c->N, B, c->E, 1, s));
+    CHECK(blocks_forward(c, s, B, false, l_lo, l_hi));
+    const size_t out = l_hi < c->L ? c->sav[l_hi].x_in : c->w_xfinal;
+    CHECK(pevit_launch_permute_rows(at<float>(c->ws, out), y_nbe, c->N, B, c->E, 0, s));
     c->saved_batch = save_for_backward ? B : 0; c->saved_kind = 1;
     return 0;
 }
 
-extern "C" int pevit_transformer_backward(pevit_ctx* c, void* stream, const float* dy_nbe, float* dx_nbe, int B) {
-    CHECK(check_ready(c, B, "transformer_backward"));
+extern "C" int pevit_transformer_forward(pevit_ctx* c, void* stream, const float* x_nbe, float* y_nbe, int B,
+                                         int save_for_backward) {
+    return pevit_blocks_forward(c, stream, x_nbe, y_nbe, B, save_for_backward, 0, c ? c->L : 0);
+}
+
+// dy (gradient of the output of block l_hi-1) -> dx (gradient of the input of block l_lo, may be NULL); the adapter gradients of
+// exactly these blocks are accumulated into the flat gradient buffer
+extern "C" int pevit_blocks_backward(pevit_ctx* c, void* stream, const float* dy_nbe, float* dx_nbe, int B, int l_lo, int l_hi) {
+    CHECK(check_ready(c, B, "blocks_backward"));
+    if (l_lo < 0 || l_hi > c->L || l_lo >= l_hi) { pevit_set_error("blocks_backward: bad block range [%d, %d)", l_lo, l_hi); return -1; }
     if (c->saved_batch != B || c->saved_kind != 1) {
-        pevit_set_error("transformer_backward: the saved activations are not those of a transformer_forward with batch %d "
+        pevit_set_error("blocks_backward: the saved activations are not those of a blocks/transformer forward with batch %d "
                         "(saved: batch %d, %s)", B, c->saved_batch, c->saved_kind == 2 ? "visual_forward" : "none");
         return -1;
     }
@@ -879,12 +896,16 @@ extern "C" int pevit_transformer_backward(pevit_ctx* c, void* stream, const floa
     CHECK(pevit_launch_permute_rows(dy_nbe, at<float>(c->ws, c->w_dxa), c->N, B, c->E, 1, s));
     if (c->fp8)
         CHECK(pevit_launch_cast_bf16_cols(at<float>(c->ws, c->w_dxa), at<bf16>(c->ws, c->w_dyb), (size_t)B * c->N, c->E,
-                                          at<float>(c->arena, c->blk[c->L - 1].spr), s));
+                                          at<float>(c->arena, c->blk[l_hi - 1].spr), s));
     else
         CHECK(pevit_launch_cast_bf16(at<float>(c->ws, c->w_dxa), at<bf16>(c->ws, c->w_dyb), n, 1.0f, s, c->f32));
-    CHECK(blocks_backward(c, s, B, dx_nbe != nullptr, false, c->L, 0));
+    CHECK(blocks_backward(c, s, B, dx_nbe != nullptr, false, l_hi, l_lo));
     if (dx_nbe) CHECK(pevit_launch_permute_rows(at<float>(c->ws, c->w_dxa), dx_nbe, c->N, B, c->E, 0, s));
     return 0;
+}
+
+extern "C" int pevit_transformer_backward(pevit_ctx* c, void* stream, const float* dy_nbe, float* dx_nbe, int B) {
+    return pevit_blocks_backward(c, stream, dy_nbe, dx_nbe, B, 0, c ? c->L : 0);
 }
 
 extern "C" int pevit_zero_grads(pevit_ctx* c, void* stream) {

@@ -116,6 +116,7 @@ class HipEngine:
             raise _lib.PevitError(f"host/engine parameter layout mismatch: {total} vs {self.n_tower}")
         self._steps = 0
         self.forward_generation = 0      # bumped by EVERY forward: each one overwrites the single activation workspace
+        self.block_generation = {}       # per block: bumped by every forward THROUGH that block (blocks keep their own activations)
         self._logits = torch.empty((max_batch, num_classes), dtype=torch.float32, device=self.device)
         self._loss = torch.zeros(1, dtype=torch.float32, device=self.device)
 
@@ -225,11 +226,34 @@ class HipEngine:
             raise _lib.PevitError(f"transformer_forward expects ({self.arch.tokens}, B, {self.arch.width}) on {self.device}, "
                                   f"got {tuple(x_nbe.shape)} on {x_nbe.device}")
         self.forward_generation += 1
+        for l in range(self.arch.layers):
+            self.block_generation[l] = self.block_generation.get(l, 0) + 1
         x = x_nbe.contiguous().float()
         y = torch.empty_like(x)
         _lib.check(self.lib.pevit_transformer_forward(self._ctx, _lib.stream_ptr(), _lib.ptr(x), _lib.ptr(y), B, int(save)),
                    "pevit_transformer_forward")
         return y
+
+    def blocks_forward(self, x_nbe: torch.Tensor, l_lo: int, l_hi: int, save: bool = True) -> torch.Tensor:
+        """Blocks [l_lo, l_hi) on (N,B,E) activations (the reference's ResidualAttentionBlock.forward for one block)."""
+        N, B, E = x_nbe.shape
+        if (N, E) != (self.arch.tokens, self.arch.width) or x_nbe.device != self.device:
+            raise _lib.PevitError(f"blocks_forward expects ({self.arch.tokens}, B, {self.arch.width}) on {self.device}")
+        for l in range(l_lo, l_hi):
+            self.block_generation[l] = self.block_generation.get(l, 0) + 1
+        x = x_nbe.contiguous().float()
+        y = torch.empty_like(x)
+        _lib.check(self.lib.pevit_blocks_forward(self._ctx, _lib.stream_ptr(), _lib.ptr(x), _lib.ptr(y), B, int(save), l_lo, l_hi),
+                   "pevit_blocks_forward")
+        return y
+
+    def blocks_backward(self, dy_nbe: torch.Tensor, l_lo: int, l_hi: int, need_dx: bool = True):
+        N, B, E = dy_nbe.shape
+        dy = dy_nbe.contiguous().float()
+        dx = torch.empty_like(dy) if need_dx else None
+        _lib.check(self.lib.pevit_blocks_backward(self._ctx, _lib.stream_ptr(), _lib.ptr(dy), _lib.ptr(dx), B, l_lo, l_hi),
+                   "pevit_blocks_backward")
+        return dx
 
     def transformer_backward(self, dy_nbe: torch.Tensor, need_dx: bool = True):
         N, B, E = dy_nbe.shape
@@ -244,6 +268,8 @@ class HipEngine:
         img = images.contiguous().float()
         self._check_batch(img)
         self.forward_generation += 1
+        for l in range(self.arch.layers):
+            self.block_generation[l] = self.block_generation.get(l, 0) + 1
         feat = torch.empty((B, self.arch.embed_dim), dtype=torch.float32, device=self.device)
         _lib.check(self.lib.pevit_visual_forward(self._ctx, _lib.stream_ptr(), _lib.ptr(img), _lib.ptr(feat), B, int(save)),
                    "pevit_visual_forward")

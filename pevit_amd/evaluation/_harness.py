@@ -90,6 +90,10 @@ class _BackboneCache:
         self._items = {k: v for k, v in self._items.items() if k == key or v[0]() is not None}   # drop other idle models
         self._items[key] = (weakref.ref(owner), model)
 
+    def evict(self, model):
+        """A backbone whose frozen tensors were changed (head merge) must never be handed to another Classifier."""
+        self._items = {k: v for k, v in self._items.items() if v[1] is not model}
+
     def clear(self):
         self._items.clear()
 
@@ -175,9 +179,17 @@ class ClassifierBase(nn.Module):
             w.data = zeroshot_weights.T.to(w.dtype).to(w.device).contiguous()
             self.layers[0].bias.data.fill_(0.0)
 
-        if config.TRAIN.MERGE_ENCODER_AND_HEAD_PROJ:
-            raise RuntimeError("TRAIN.MERGE_ENCODER_AND_HEAD_PROJ folds visual.proj into the head; the HIP tower "
-                               "always applies visual.proj -- leave this option off")
+        if config.TRAIN.MERGE_ENCODER_AND_HEAD_PROJ and getattr(self.backbone.visual, "proj", None) is not None:
+            # kadaptation_clip.py:146-158: visual.proj leaves the tower and is multiplied into the head; BatchNorm then runs
+            # over the tower's width.  (The reference's scripts pass False; here the tower keeps an identity projection.)
+            head_proj, head_bias = self.layers[0].weight.data, self.layers[0].bias.data
+            _BACKBONES.evict(self.backbone)                                                # its proj is about to change
+            encoder_proj = self.backbone.visual.merge_proj_into_head()                     # (E, D)
+            encoder_ic = encoder_proj.shape[0]
+            self.channel_bn = nn.BatchNorm1d(encoder_ic, affine=False).to(dev)
+            self.layers = nn.Sequential(nn.Linear(encoder_ic, output_dim)).to(dev)
+            self.layers[0].weight.data = head_proj @ encoder_proj.T.to(head_proj.dtype).to(head_proj.device)
+            self.layers[0].bias.data = head_bias
 
         self.logit_scale = nn.Parameter(torch.ones([], device=dev))
         self.logit_scale.requires_grad = config.TRAIN.TRAINABLE_LOGIT_SCALE

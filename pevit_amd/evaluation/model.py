@@ -168,6 +168,61 @@ class _TransformerFn(torch.autograd.Function):
         return (dx, None, None, *grads)
 
 
+class _BlockFn(torch.autograd.Function):
+    """ResidualAttentionBlock.forward (model.py:972-975) of block ``index`` on the engine (pevit_blocks_forward / _backward)."""
+
+    @staticmethod
+    def forward(ctx, x, visual, index, save, *params):
+        eng = visual._engine
+        y = eng.blocks_forward(x, index, index + 1, save=save)
+        ctx.visual, ctx.index, ctx.generation, ctx.need_dx = visual, index, eng.block_generation[index], x.requires_grad
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        eng = ctx.visual._engine
+        if eng.block_generation.get(ctx.index) != ctx.generation:
+            raise _lib.PevitError(f"backward through block {ctx.index} whose activations the engine no longer holds: another forward "
+                                  "through this block ran in between")
+        eng.grads[:eng.n_tower].zero_()
+        dx = eng.blocks_backward(dy, ctx.index, ctx.index + 1, need_dx=ctx.need_dx)
+        views = eng.param_views(eng.grads.clone())
+        mask = ctx.visual._has_grad
+        grads = [views["visual." + n] if mask[n] else None for n in ctx.visual._trainable_names]
+        return (dx, None, None, None, *grads)
+
+
+class _Block(_Params):
+    """visual.transformer.resblocks[i]: parameters under the reference's names, callable like the reference's
+    ResidualAttentionBlock (reference-side code that walks ``resblocks`` keeps working; the whole-tower call is one engine op)."""
+
+    def forward(self, x):
+        visual = self._owner()
+        eng = visual.engine()
+        eng.ensure_batch(x.shape[1])
+        params = visual._trainable_params()
+        save = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+        return _BlockFn.apply(x.contiguous().float(), visual, self._index, save, *params)
+
+
+class _Resblocks(_Params):
+    """The reference's nn.Sequential of blocks: indexable, iterable, callable (applies the blocks in order)."""
+
+    def __getitem__(self, i):
+        return self._modules[str(i)]
+
+    def __len__(self):
+        return len(self._modules)
+
+    def __iter__(self):
+        return iter(self._modules.values())
+
+    def forward(self, x):
+        for blk in self:
+            x = blk(x)
+        return x
+
+
 class _Transformer(_Params):
     """visual.transformer: owner of the shared phm_rule* factors and of resblocks (model.py:978-1014), callable like the
     reference's module.  ``kdropout`` mirrors MultiheadAttention.kdropout = Dropout(0.5) (model.py:516,582): the reference
@@ -235,7 +290,7 @@ class VisionTransformer(nn.Module):
         for n, (s, tr) in shapes.items():              # shared rules live on the Transformer (model.py:987-999)
             if n.startswith("transformer.phm_rule"):
                 self.transformer.add(n[len("transformer."):], torch.zeros(s), tr)
-        self.transformer.add_module("resblocks", _Params())
+        self.transformer.add_module("resblocks", _Resblocks())
         frozen_shapes = {"attn.in_proj_weight": (3 * E, E), "attn.in_proj_bias": (3 * E,), "attn.out_proj.weight": (E, E),
                          "attn.out_proj.bias": (E,), "ln_1.weight": (E,), "ln_1.bias": (E,), "mlp.c_fc.weight": (4 * E, E),
                          "mlp.c_fc.bias": (4 * E,), "mlp.c_proj.weight": (E, 4 * E), "mlp.c_proj.bias": (E,),
@@ -243,7 +298,9 @@ class VisionTransformer(nn.Module):
         for i in range(L):
             pre = f"transformer.resblocks.{i}."
             mine = [n[len(pre):] for n in shapes if n.startswith(pre)]
-            blk = _Params()
+            blk = _Block()
+            object.__setattr__(blk, "_owner", weakref.ref(self))
+            object.__setattr__(blk, "_index", i)
             for n in _block_order(method, mine):
                 if n in frozen_shapes:
                     blk.add(n, torch.zeros(frozen_shapes[n]))
@@ -312,6 +369,23 @@ class VisionTransformer(nn.Module):
             off += k
         self._engine = eng
         return eng
+
+    def merge_proj_into_head(self):
+        """TRAIN.MERGE_ENCODER_AND_HEAD_PROJ (kadaptation_clip.py:146-158): the reference sets ``visual.proj = None`` and
+        multiplies it into the head.  The engine always applies a projection, so here ``proj`` becomes the E x E identity (the
+        tower then returns the ln_post'd class token, rounded to bf16 once) and the output width becomes E; returns the old
+        (E, D) matrix for the caller to fold into its head.  Any existing engine is dropped."""
+        import dataclasses
+        old = self.proj.data.detach().clone()
+        E = old.shape[0]
+        self.proj = nn.Parameter(torch.eye(E, dtype=old.dtype, device=old.device), requires_grad=False)
+        self.arch = dataclasses.replace(self.arch, embed_dim=E)
+        self.output_dim = E
+        fp = getattr(self, "_frozen_fingerprint", None)
+        if fp is not None:
+            self._frozen_fingerprint = (fp, "proj-merged")
+        self._engine = None
+        return old
 
     def _trainable_params(self):
         """The trainable Parameter objects in flat-buffer order (their identity survives device moves and

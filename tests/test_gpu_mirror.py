@@ -337,3 +337,47 @@ def test_fp8_weight_format_through_the_reference_api(ckpt):
         mod.train_one(OneBatch(t["images"], t["labels"], 2), clf, crit, opt, 0, cfg)
         losses[fmt] = torch.cat([p.detach().flatten().cpu() for n, p in clf.named_parameters() if p.requires_grad and n != "logit_scale"])
     assert torch.equal(losses["fp8"], losses["bf16"])
+
+
+@pytest.mark.parametrize("method", ["kadaptation", "lora", "adapter", "compacter"])
+def test_walking_resblocks_equals_the_transformer_call(method, ckpt):
+    """Reference-side code that iterates ``visual.transformer.resblocks`` (the nn.Sequential of model.py:1011-1014): every block
+    is callable (ResidualAttentionBlock.forward, model.py:972-975, one pevit_blocks_forward call each, own saved activations) and
+    the walk -- forward AND backward through autograd -- reproduces the single-call seam bit for bit."""
+    from oracle import ref_cpu
+    from pevit_amd.evaluation.model import build_peft_model
+    from pevit_amd.synth import randomize_adapters
+    sd = load_tiny_sd()
+    model = build_peft_model(dict(sd), method).cuda()
+    named = [(n, p) for n, p in model.visual.named_parameters() if ref_cpu.is_trainable(method, "visual." + n)]
+    model.visual.engine()
+    randomize_adapters([(n, p) for n, p in named], seed=4)
+    for _, p in named:
+        p.requires_grad_(True)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(10, 5, 128, generator=g); dy = torch.randn(10, 5, 128, generator=g)
+
+    def run(walk):
+        for _, p in named:
+            p.grad = None
+        xg = x.cuda().requires_grad_(True)
+        if walk:
+            y = xg
+            assert len(model.visual.transformer.resblocks) == 2
+            for blk in model.visual.transformer.resblocks:
+                y = blk(y)
+        else:
+            y = model.visual.transformer(xg)
+        y.backward(dy.cuda())
+        torch.cuda.synchronize()
+        return y.detach().clone(), xg.grad.clone(), {n: (p.grad.clone() if p.grad is not None else None) for n, p in named}
+    y0, dx0, g0 = run(False)
+    y1, dx1, g1 = run(True)
+    assert torch.equal(y0, y1) and torch.equal(dx0, dx1)
+    for n in g0:
+        if g0[n] is None:
+            assert g1[n] is None or float(g1[n].abs().max()) == 0.0, n
+        else:
+            assert torch.equal(g0[n], g1[n]), n
+    # the Sequential itself is callable too
+    assert torch.equal(model.visual.transformer.resblocks(x.cuda()), y0)
