@@ -927,6 +927,68 @@ __global__ __launch_bounds__(256, 2) void gemm_streamk_kernel(GemmParams p, int 
     }
 }
 
+// The end of a k-split tile, shared by gemm_ksplit_kernel and gemm_kphase_kernel: the two groups' partial sums meet through
+// LDS (every wave is past its last k-tile and has no request in flight): fragment f = i * WN + j is FINISHED by group f % 2,
+// which receives the other group's partial at hand[((gw * NF + f) * 16 + r) * 64 + lane] and runs that fragment's epilogue.
+// SCRATCH_OFF: byte offset of the 4 KiB-per-wave epilogue scratch, behind the hand-off area.
+template <int EPI, int WM, int WN, int NWG, int NOWN, int SCRATCH_OFF>
+__device__ __forceinline__ void ksplit_finish(const GemmParams& p, char* smem, f32x16 (&acc)[WM][WN], float4 (&rpre)[NOWN][2][2],
+                                              float (&bpre)[WN][8], int m0, int n0, int grp, int gw, int wm, int wn, int wid, int lane) {
+    constexpr bool PRE = (EPI == EPI_BIAS_RESID_F32 || EPI == EPI_BIAS_RESID_KEEP);
+    constexpr int NF = WM * WN;
+    float* hand = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+            if (((i * WN + j) & 1) != grp) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) hand[((gw * NF + i * WN + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+            }
+    __syncthreads();
+    static_assert(SCRATCH_OFF >= NWG * NF * 16 * 64 * 4, "epilogue scratch must not overlap the hand-off area");
+    // 4 KiB of epilogue scratch per wave behind the hand-off area (launch_ksplit sizes the LDS for it)
+    float* cw = reinterpret_cast<float*>(smem + SCRATCH_OFF + wid * 4096);
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            if (((i * WN + j) & 1) != grp) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                cw[row * 32 + (lane & 31)] = acc[i][j][r] + hand[((gw * NF + i * WN + j) * 16 + r) * 64 + lane];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                const int lr = pass * 16 + (lane >> 2);
+                const int lc = (lane & 3) * 8;
+                const int row = m0 + wm * WM * 32 + i * 32 + lr;
+                const int col = n0 + wn * WN * 32 + j * 32 + lc;
+                const float4 x0 = *reinterpret_cast<const float4*>(cw + lr * 32 + lc);
+                const float4 x1 = *reinterpret_cast<const float4*>(cw + lr * 32 + lc + 4);
+                if (row < p.M && col < p.N) {
+                    float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                    if constexpr (PRE) {          // epilogue_store<EPI_BIAS_RESID_*> with the residual and the bias already in registers
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += bpre[j][e];
+                        if constexpr (EPI == EPI_BIAS_RESID_KEEP) store8f(p.outf2 + (size_t)row * p.ldo2 + col, v);
+                        const float4 r0 = rpre[(i * WN + j) >> 1][pass][0], r1 = rpre[(i * WN + j) >> 1][pass][1];
+                        v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
+                        v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+                        store8f(p.outf + (size_t)row * p.ldo + col, v);
+                    } else {
+                        epilogue_store<EPI, bf16>(p, row, col, v);
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // One-tile-per-CU form for the N = E products: a 160x128 tile gives M = 6400, N = 768 exactly 240 tiles for 256 CUs (the
 // vendor library picks the same shape class for these problems: MT128x160 / MT160x128, profiles/r02_vendor_gemm_shapes.md),
@@ -1072,60 +1134,164 @@ __global__ __launch_bounds__(2 * WGM * WGN * 64, 1) void gemm_ksplit_kernel(Gemm
     }
     if (STAG && !grp) __builtin_amdgcn_s_barrier();
     __syncthreads();
-    // ---- the two partial sums meet through LDS: fragment f = i * WN + j is FINISHED by group f % 2, which receives the other
-    // group's partial at hand[((gw * NF + f) * 16 + r) * 64 + lane] and runs that fragment's epilogue -- both groups store
-    constexpr int NF = WM * WN;
-    float* hand = reinterpret_cast<float*>(smem);
+    ksplit_finish<EPI, WM, WN, NWG, NOWN, 3 * STAGE_BYTES>(p, smem, acc, rpre, bpre, m0, n0, grp, gw, wm, wn, wid, lane);
+    __syncthreads();                                       // the LDS scratch is free before the next tile's first k-tile lands in it
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same tile (32*WM x 128, two groups of 1 x 4 waves, each wave a column of WM fragments) with the PHASED schedule of
+// gemm8_kernel (round 3).  gemm_ksplit_kernel gives each group whole k-tiles and lets hipcc schedule the k-tile: a wave requests
+// its 9 pieces (~100 cycles of issue each), then reads and multiplies fragment by fragment behind lgkmcnt(0) waits, then waits
+// for its requests with vmcnt(0): an iteration is ~3,900 cycles for 1,280 cycles of MFMAs per SIMD (matrix pipe 19-21 % busy by
+// the counters, profiles/r03_mfma_utilisation.md), and at most one k-tile per group is in flight.  Here
+//   * the groups split every k-tile: group g multiplies its k-steps 2g, 2g+1 (both groups read the same LDS stage);
+//   * a wave's k-tile is ONE phase: LOAD (all 2*(WM+1) fragments, its share of the k-tile S-1 ahead by LDS-DMA, lgkmcnt(0))
+//     -> barrier -> MFMA (2*WM back to back at raised priority) -> barrier, group 1 one barrier behind group 0, so that on
+//     every SIMD one wave multiplies while its partner reads and requests;
+//   * S = 4 stages of one k-tile: requests are issued three k-tiles (six barrier intervals) before their data is read, and the
+//     wait for them is an exact vmcnt(pieces of the two younger k-tiles) -- never a drain.
+// Hazards, by barrier interval (group 0: LOAD(kt) in interval 2kt, MFMA(kt) in 2kt+1; group 1: one later):
+//   * WAR: stage (kt-1) % S is requested again from interval 2kt on; its last readers (group 1, LOAD(kt-1), interval 2kt-1)
+//     waited for their ds_reads before the barrier that ends that interval;
+//   * RAW: k-tile kt+1 is first read in interval 2kt+2; every wave waits for ITS pieces of k-tile kt+1 before the barrier that
+//     ends interval 2kt+1 (group 0: after MFMA(kt); group 1: at the end of LOAD(kt)), having issued up to k-tile kt+S-1.
+// Same MFMA order per accumulator and the same final sum (even-steps partial + odd-steps partial differs from the alternate-
+// k-tile split of gemm_ksplit_kernel: results agree to f32 rounding, not bit for bit; tests/test_gpu_ops.py).
+template <int EPI, int WM>
+__global__ __launch_bounds__(512, 2) void gemm_kphase_kernel(GemmParams p, int ntiles) {
+    constexpr int NW = 8, NWG = 4, WN = 1, S = 4;
+    constexpr int BM = WM * 32, BN = 128, BK = 64, KS = 4;
+    constexpr int ROWB = 128, CH = 8, RPP = 8;
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int PA_T = BM / RPP, NPT = (BM + BN) / RPP, NP = (NPT + NW - 1) / NW, NFULL = NPT % NW ? NPT % NW : NW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = wid >> 2, gw = wid & 3, wm = 0, wn = gw;
+    const bool big = wid < NFULL;                           // this wave requests NP pieces per k-tile (the others NP - 1)
+    const int a_bytes = ((p.M - 1) * p.lda + p.K) * 2, b_bytes = ((p.Nb - 1) * p.ldb + p.K) * 2;
+    const int frow = lane & 31, fswz = (frow >> 1) & (CH - 1), fhalf = lane >> 5;
+    const int a_base = frow * ROWB, b_base = A_BYTES + (wn * 32 + frow) * ROWB;
+    int coff[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) coff[s] = ((((grp * 2 + s) * 2 + fhalf) ^ fswz) << 4);
+    const int nk = p.K / BK;
+    // outstanding requests this wave may leave when it needs k-tile t: its pieces of the k-tiles issued after t (at most S - 2)
+    auto wait_tile = [&](int t) {
+        const int last = min(t + S - 2, nk - 1);            // youngest k-tile issued so far
+        const int after = last - t;
+        if (after >= 2) { if (big) wait_vmcnt<2 * NP>(); else wait_vmcnt<2 * NP - 2>(); }
+        else if (after == 1) { if (big) wait_vmcnt<NP>(); else wait_vmcnt<NP - 1>(); }
+        else wait_vmcnt<0>();
+    };
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int m0, n0;
+    tile_origin<BM, BN>(p, tile, m0, n0);
+    int voff[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int q = i * NW + wid;                           // wave-uniform
+        const bool is_a = q < PA_T;
+        const int rb = is_a ? q : q - PA_T;
+        const int row = rb * RPP + lane / CH;
+        const int chunk = (lane % CH) ^ ((row >> 1) & (CH - 1));
+        int r = (is_a ? m0 : n0) + row;
+        const int lim = is_a ? p.M : p.Nb;
+        r = r < lim ? r : lim - 1;
+        voff[i] = r * (is_a ? p.lda : p.ldb) * 2 + chunk * 16;
+    }
+    auto issue_tile = [&](int kt) {
+        char* st = smem + (kt & (S - 1)) * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int q = i * NW + wid;
+            const bool is_a = q < PA_T;                     // wave-uniform: a scalar select of the descriptor, no branch
+            if (i < NP - 1 || NFULL == NW || big)           // only the last round can be short
+                buffer_lds16(is_a ? (const void*)p.A : (const void*)p.B, is_a ? a_bytes : b_bytes, st + q * 1024, voff[i], kt * 128);
+        }
+    };
+    f32x16 acc[WM][WN];
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int j = 0; j < WN; ++j)
-            if (((i * WN + j) & 1) != grp) {
+        for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.0f;
+    // residual epilogues: the bias of this lane's 8 columns and the residual values of the fragments this wave's group will
+    // finish are requested FIRST (older than every operand request: the exact vmcnt waits below then cover them), so that the
+    // epilogue -- which every CU reaches at the same moment with one tile per CU -- only has its stores left
+    constexpr bool PRE = (EPI == EPI_BIAS_RESID_F32 || EPI == EPI_BIAS_RESID_KEEP);
+    constexpr int NOWN = PRE ? (WM * WN + 1) / 2 : 1;
+    float4 rpre[NOWN][2][2];
+    float bpre[WN][8];
+    if constexpr (PRE) {
+        // clamped addresses instead of bounds branches (a value loaded inside a branch makes hipcc drain with vmcnt(0) at the
+        // join); rows / columns outside the matrix are never stored
+        const int col = min(n0 + wn * 32 + (lane & 3) * 8, p.N - 8);
+        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + col), b1 = *reinterpret_cast<const float4*>(p.bias + col + 4);
+        bpre[0][0] = b0.x; bpre[0][1] = b0.y; bpre[0][2] = b0.z; bpre[0][3] = b0.w;
+        bpre[0][4] = b1.x; bpre[0][5] = b1.y; bpre[0][6] = b1.z; bpre[0][7] = b1.w;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) hand[((gw * NF + i * WN + j) * 16 + r) * 64 + lane] = acc[i][j][r];
-            }
-    __syncthreads();
-    static_assert(3 * STAGE_BYTES >= NWG * NF * 16 * 64 * 4, "epilogue scratch must not overlap the hand-off area");
-    // 4 KiB of epilogue scratch per wave behind the hand-off area (launch_ksplit sizes the LDS for it)
-    float* cw = reinterpret_cast<float*>(smem + 3 * STAGE_BYTES + wid * 4096);
-#pragma unroll
-    for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            if (((i * WN + j) & 1) != grp) continue;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                cw[row * 32 + (lane & 31)] = acc[i][j][r] + hand[((gw * NF + i * WN + j) * 16 + r) * 64 + lane];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int k = 0; k < NOWN; ++k) {
+            const int i = min(2 * k + grp, WM - 1);           // the k-th fragment this group finishes (a harmless repeat past the end)
 #pragma unroll
             for (int pass = 0; pass < 2; ++pass) {
-                const int lr = pass * 16 + (lane >> 2);
-                const int lc = (lane & 3) * 8;
-                const int row = m0 + wm * WM * 32 + i * 32 + lr;
-                const int col = n0 + wn * WN * 32 + j * 32 + lc;
-                const float4 x0 = *reinterpret_cast<const float4*>(cw + lr * 32 + lc);
-                const float4 x1 = *reinterpret_cast<const float4*>(cw + lr * 32 + lc + 4);
-                if (row < p.M && col < p.N) {
-                    float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-                    if constexpr (PRE) {          // epilogue_store<EPI_BIAS_RESID_*> with the residual and the bias already in registers
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += bpre[j][e];
-                        if constexpr (EPI == EPI_BIAS_RESID_KEEP) store8f(p.outf2 + (size_t)row * p.ldo2 + col, v);
-                        const float4 r0 = rpre[(i * WN + j) >> 1][pass][0], r1 = rpre[(i * WN + j) >> 1][pass][1];
-                        v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
-                        v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
-                        store8f(p.outf + (size_t)row * p.ldo + col, v);
-                    } else {
-                        epilogue_store<EPI, bf16>(p, row, col, v);
-                    }
-                }
+                const int row = min(m0 + i * 32 + pass * 16 + (lane >> 2), p.M - 1);
+                const float* src = p.resid + (size_t)row * p.ldr + col;
+                rpre[k][pass][0] = *reinterpret_cast<const float4*>(src);
+                rpre[k][pass][1] = *reinterpret_cast<const float4*>(src + 4);
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < S - 1; ++t)
+        if (t < nk) issue_tile(t);
+    wait_tile(0);
+    __builtin_amdgcn_s_barrier();
+    if (grp) __builtin_amdgcn_s_barrier();                      // group 1 runs one barrier behind
+    // one k-tile of this wave; STEADY: a k-tile is requested and two younger ones stay in flight (kt + S - 1 < nk)
+    auto ktile = [&](int kt, auto steady) {
+        constexpr bool STEADY = decltype(steady)::value;
+        const char* st = smem + (kt & (S - 1)) * STAGE_BYTES;
+        // ---- LOAD
+        bf16x8 af[2][WM], bfr[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bfr[s] = *reinterpret_cast<const bf16x8*>(st + b_base + coff[s]);
+#pragma unroll
+            for (int i = 0; i < WM; ++i) af[s][i] = *reinterpret_cast<const bf16x8*>(st + a_base + i * 32 * ROWB + coff[s]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (STEADY || kt + S - 1 < nk) issue_tile(kt + S - 1);
+        if (grp) {
+            if constexpr (STEADY) { if (big) wait_vmcnt<2 * NP>(); else wait_vmcnt<2 * NP - 2>(); }
+            else if (kt + 1 < nk) wait_tile(kt + 1);
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);                     // lgkmcnt(0): this wave's reads are in registers
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- MFMA
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < WM; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][i], bfr[s], acc[i][0], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!grp) {
+            if constexpr (STEADY) { if (big) wait_vmcnt<2 * NP>(); else wait_vmcnt<2 * NP - 2>(); }
+            else if (kt + 1 < nk) wait_tile(kt + 1);
+        }
+        __builtin_amdgcn_s_barrier();
+    };
+    int kt = 0;
+    for (; kt + S - 1 < nk; ++kt) ktile(kt, std::true_type{});
+    for (; kt < nk; ++kt) ktile(kt, std::false_type{});
+    if (!grp) __builtin_amdgcn_s_barrier();
+    wait_vmcnt<0>();
+    __syncthreads();
+    constexpr int SCRATCH = 3 * STAGE_BYTES > NWG * WM * 4096 ? 3 * STAGE_BYTES : NWG * WM * 4096;
+    ksplit_finish<EPI, WM, WN, NWG, NOWN, SCRATCH>(p, smem, acc, rpre, bpre, m0, n0, grp, gw, wm, wn, wid, lane);
     __syncthreads();                                       // the LDS scratch is free before the next tile's first k-tile lands in it
   }
 }
@@ -1161,6 +1327,31 @@ int launch_ksplit(const GemmParams& p, const GemmTune& t, hipStream_t stream) {
     pb.band = xcd_band(tiles, ceil_div(p.N, bn), grid, t);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(2 * WGM * WGN * 64), lds, stream, pb, tiles);
     LAUNCH_OK("gemm (k-split)");
+    return 0;
+}
+
+template <int EPI, int WM>
+int launch_kphase(const GemmParams& p, const GemmTune& t, hipStream_t stream) {
+    constexpr int bm = WM * 32, bn = 128, stage = (bm + bn) * 128;
+    constexpr int scratch = 3 * stage > 4 * WM * 4096 ? 3 * stage : 4 * WM * 4096;
+    constexpr int lds = 4 * stage > scratch + 8 * 4096 ? 4 * stage : scratch + 8 * 4096;
+    auto kern = gemm_kphase_kernel<EPI, WM>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+            pevit_set_error("hipFuncSetAttribute(phased k-split gemm epi %d) failed", EPI);
+            return -1;
+        }
+        attr_set = true;
+    }
+    const long long a = ((long long)p.M * p.lda + p.K) * 2, b = ((long long)p.Nb * p.ldb + p.K) * 2;
+    if (a >= (1LL << 31) || b >= (1LL << 31)) return launch_ksplit<EPI, 1, 4, WM, 1, true>(p, t, stream);   // 31-bit buffer offsets
+    const int tiles = ceil_div(p.M, bm) * ceil_div(p.N, bn);
+    const int grid = min(tiles, num_cus() & ~7);
+    GemmParams pb = p;
+    pb.band = xcd_band(tiles, ceil_div(p.N, bn), grid, t);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, pb, tiles);
+    LAUNCH_OK("gemm (phased k-split)");
     return 0;
 }
 
@@ -1372,6 +1563,8 @@ int launch_epi(const GemmParams& p, const GemmTune& t, hipStream_t stream) {
     }
     if constexpr (!BF8 && (EPI == EPI_BIAS_RESID_F32 || EPI == EPI_F32 || EPI == EPI_BF16 || EPI == EPI_BIAS_RESID_KEEP || EPI == EPI_PATCH_EMBED)) {
         const int kwm = use_ksplit(p, t, cfg);
+        if (kwm == 5 && t.ksplit_stagger == 2) return launch_kphase<EPI, 5>(p, t, stream);
+        if (kwm == 3 && t.ksplit_stagger == 2) return launch_kphase<EPI, 3>(p, t, stream);
         if (kwm == 5) return t.ksplit_stagger ? launch_ksplit<EPI, 1, 4, 5, 1, true>(p, t, stream) : launch_ksplit<EPI, 1, 4, 5, 1, false>(p, t, stream);
         if (kwm == 3) return launch_ksplit<EPI, 1, 4, 3, 1, true>(p, t, stream);
         const SkPlan plan = streamk_plan(p, t, cfg);

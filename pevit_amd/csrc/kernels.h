@@ -57,7 +57,7 @@ struct GemmTune {
     int sk_share = 0, sk_band = 0;   // measurement (gemm_streamk = 2): k-iterations per stream-K workgroup, m-tiles per band
     int ksplit = 1;       // N = E long-K products with ~one 160x128 tile per CU: 8-wave tile, two wave groups on alternate k-tiles
     int ksplit_small = 1;     // ... also as a 96x128 tile where that fills the chip and 160x128 does not (M = 3200)
-    int ksplit_stagger = 1;   // ... its two wave groups half an iteration apart (two barriers per pair of k-tiles)
+    int ksplit_stagger = 2;   // ... 1: its two wave groups half an iteration apart (alternate k-tiles); 2: phased kernel (groups split each k-tile, 4 stages)
     int ksplit_mink = 512;    // ... from this K on
     int band = -1;        // >= 0 forces GemmParams::band of the one-round 8-wave launches (measurement); -1 = XCD-aligned
     int stagger = 1;      // 8-wave tiles (bf16 B): the staggered two-group kernel (gemm8_kernel) instead of gemm_kernel
