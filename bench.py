@@ -284,7 +284,7 @@ def main():
                                                                  if args.weights == "fp8" else ""),
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "train_gflop_per_image": gflop, "final_loss": final_loss},
-            "roofline": {"bound": "mfma", "kernel": "gemm_kernel<...> + gemm_ksplit_kernel<...> + gemm_streamk_kernel<...> (pevit_amd/csrc/gemm.hip: all epilogues / tile shapes)",
+            "roofline": {"bound": "mfma", "kernel": "gemm8_kernel<...> + gemm_kphase_kernel<...> + gemm_kernel<...> + gemm_streamk_kernel<...> (pevit_amd/csrc/gemm.hip: all epilogues / tile shapes)",
                          "achieved": gemm_tflops, "peak": PEAK_TFLOPS_BF16, "unit": "TFLOP/s",
                          "frac": gemm_tflops / PEAK_TFLOPS_BF16, "traffic": traffic, "traffic_unit": "bytes/launch",
                          "peak_attainable_measured": {"value": attainable, "unit": "TFLOP/s",

@@ -65,6 +65,7 @@ SIGNATURES = {
     "pevit_op_gemm_f8a": (c_int, [P, c_int, P, c_int, P, c_int, c_int, P, c_int, c_int, c_int, P, P, c_int, P, c_int, P, c_int,
                                   P, c_int, c_int, c_size_t, c_int, c_int, c_int]),
     "pevit_op_cast_fp8": (c_int, [P, P, P, c_int, c_int]),
+    "pevit_debug_last_gemm_path": (c_int, []),
     "pevit_op_quant_fp8": (c_int, [P, P, c_int, c_int, P, P, P]),
     "pevit_op_dequant_fp8": (c_int, [P, P, P, c_int, c_int, P]),
     "pevit_op_ln_fwd": (c_int, [P, P, P, P, c_int, c_int, P, P, P, P]),

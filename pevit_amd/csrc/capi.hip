@@ -1285,9 +1285,12 @@ extern "C" int pevit_tune(pevit_ctx* c, const char* key, int value) {
     if (key && !strcmp(key, "gemm_ksplit_small")) { t.ksplit_small = value; return 0; }
     if (key && !strcmp(key, "gemm_ksplit_stagger")) { t.ksplit_stagger = value; return 0; }
     if (key && !strcmp(key, "gemm_ksplit_mink")) { t.ksplit_mink = value; return 0; }
+    if (key && !strcmp(key, "gemm_kphase_nl")) { t.kphase_nl = value; return 0; }
     if (key && !strcmp(key, "gemm_band")) { t.band = value; return 0; }
     if (key && !strcmp(key, "gemm_stagger")) { t.stagger = value; return 0; }
     if (key && c && !strcmp(key, "dx_stored")) { c->dx_stored = value; return 0; }
     pevit_set_error("tune: unknown key %s", key ? key : "(null)");
     return -1;
 }
+
+extern "C" int pevit_debug_last_gemm_path(void) { return pevit_gemm_last_path(); }

@@ -40,6 +40,7 @@
 #include "gemm_epilogue.h"
 
 namespace {
+int g_last_path = 0;   // which kernel family the last pevit_launch_gemm took (pevit_debug_last_gemm_path; tests)
 
 // measurement bits of GemmParams::dbg; -DGEMM_NO_DBG compiles them out
 #ifdef GEMM_NO_DBG
@@ -1158,13 +1159,14 @@ __global__ __launch_bounds__(2 * WGM * WGN * 64, 1) void gemm_ksplit_kernel(Gemm
 //     ends interval 2kt+1 (group 0: after MFMA(kt); group 1: at the end of LOAD(kt)), having issued up to k-tile kt+S-1.
 // Same MFMA order per accumulator and the same final sum (even-steps partial + odd-steps partial differs from the alternate-
 // k-tile split of gemm_ksplit_kernel: results agree to f32 rounding, not bit for bit; tests/test_gpu_ops.py).
-template <int EPI, int WM>
+template <int EPI, int WM, int NLREQ>
 __global__ __launch_bounds__(512, 2) void gemm_kphase_kernel(GemmParams p, int ntiles) {
     constexpr int NW = 8, NWG = 4, WN = 1, S = 4;
     constexpr int BM = WM * 32, BN = 128, BK = 64, KS = 4;
     constexpr int ROWB = 128, CH = 8, RPP = 8;
     constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE_BYTES = A_BYTES + B_BYTES;
     constexpr int PA_T = BM / RPP, NPT = (BM + BN) / RPP, NP = (NPT + NW - 1) / NW, NFULL = NPT % NW ? NPT % NW : NW;
+    constexpr int NL = NLREQ < NP ? NLREQ : NP;            // pieces requested in the LOAD section; the others between the MFMAs
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1178,13 +1180,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kphase_kernel(GemmParams p, int n
     for (int s = 0; s < 2; ++s) coff[s] = ((((grp * 2 + s) * 2 + fhalf) ^ fswz) << 4);
     const int nk = p.K / BK;
     // outstanding requests this wave may leave when it needs k-tile t: its pieces of the k-tiles issued after t (at most S - 2)
-    auto wait_tile = [&](int t) {
-        const int last = min(t + S - 2, nk - 1);            // youngest k-tile issued so far
-        const int after = last - t;
-        if (after >= 2) { if (big) wait_vmcnt<2 * NP>(); else wait_vmcnt<2 * NP - 2>(); }
-        else if (after == 1) { if (big) wait_vmcnt<NP>(); else wait_vmcnt<NP - 1>(); }
-        else wait_vmcnt<0>();
-    };
+    // tail / first k-tile: everything this wave has requested so far (drains; at most S - 1 times per tile)
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     int m0, n0;
     tile_origin<BM, BN>(p, tile, m0, n0);
@@ -1201,15 +1197,16 @@ __global__ __launch_bounds__(512, 2) void gemm_kphase_kernel(GemmParams p, int n
         r = r < lim ? r : lim - 1;
         voff[i] = r * (is_a ? p.lda : p.ldb) * 2 + chunk * 16;
     }
-    auto issue_tile = [&](int kt) {
+    auto issue_piece = [&](int kt, int i) {
         char* st = smem + (kt & (S - 1)) * STAGE_BYTES;
+        const int q = i * NW + wid;
+        const bool is_a = q < PA_T;                         // wave-uniform: a scalar select of the descriptor, no branch
+        if (i < NP - 1 || NFULL == NW || big)               // only the last round can be short
+            buffer_lds16(is_a ? (const void*)p.A : (const void*)p.B, is_a ? a_bytes : b_bytes, st + q * 1024, voff[i], kt * 128);
+    };
+    auto issue_tile = [&](int kt) {
 #pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            const int q = i * NW + wid;
-            const bool is_a = q < PA_T;                     // wave-uniform: a scalar select of the descriptor, no branch
-            if (i < NP - 1 || NFULL == NW || big)           // only the last round can be short
-                buffer_lds16(is_a ? (const void*)p.A : (const void*)p.B, is_a ? a_bytes : b_bytes, st + q * 1024, voff[i], kt * 128);
-        }
+        for (int i = 0; i < NP; ++i) issue_piece(kt, i);
     };
     f32x16 acc[WM][WN];
 #pragma unroll
@@ -1246,13 +1243,23 @@ __global__ __launch_bounds__(512, 2) void gemm_kphase_kernel(GemmParams p, int n
 #pragma unroll
     for (int t = 0; t < S - 1; ++t)
         if (t < nk) issue_tile(t);
-    wait_tile(0);
+    if (nk >= S - 1) { if (big) wait_vmcnt<2 * NP>(); else wait_vmcnt<2 * NP - 2>(); }     // k-tile 0 has landed; 1 and 2 may fly
+    else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     if (grp) __builtin_amdgcn_s_barrier();                      // group 1 runs one barrier behind
-    // one k-tile of this wave; STEADY: a k-tile is requested and two younger ones stay in flight (kt + S - 1 < nk)
+    // one k-tile of this wave; STEADY: a k-tile is requested and two younger ones stay in flight (kt + S - 1 < nk).
+    // Request order of a wave: L(0) M(0) L(1) M(1) ... (L(k): NL pieces of k-tile k + S - 1 in LOAD(k), M(k): the rest between
+    // the MFMAs of k).  Group 0 waits for k-tile kt + 1 (= L, M of kt - 2) after MFMA(kt): 2 k-tiles' pieces are younger;
+    // group 1 at the end of LOAD(kt): one k-tile's pieces + NL are younger.  Outside the steady state the waits drain.
+    // past the last request (kt + S - 1 >= nk): k-tile kt + 1 with only k-tile kt + 2 (all of it requested long ago) younger
+    auto tail_wait = [&](int kt) {
+        if (kt + 2 < nk) { if (big) wait_vmcnt<NP>(); else wait_vmcnt<NP - 1>(); }
+        else if (kt + 1 < nk) wait_vmcnt<0>();
+    };
     auto ktile = [&](int kt, auto steady) {
         constexpr bool STEADY = decltype(steady)::value;
         const char* st = smem + (kt & (S - 1)) * STAGE_BYTES;
+        const bool req = STEADY || kt + S - 1 < nk;
         // ---- LOAD
         bf16x8 af[2][WM], bfr[2];
 #pragma unroll
@@ -1262,10 +1269,13 @@ __global__ __launch_bounds__(512, 2) void gemm_kphase_kernel(GemmParams p, int n
             for (int i = 0; i < WM; ++i) af[s][i] = *reinterpret_cast<const bf16x8*>(st + a_base + i * 32 * ROWB + coff[s]);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (STEADY || kt + S - 1 < nk) issue_tile(kt + S - 1);
+        if (req) {
+#pragma unroll
+            for (int i = 0; i < NL; ++i) issue_piece(kt + S - 1, i);
+        }
         if (grp) {
-            if constexpr (STEADY) { if (big) wait_vmcnt<2 * NP>(); else wait_vmcnt<2 * NP - 2>(); }
-            else if (kt + 1 < nk) wait_tile(kt + 1);
+            if constexpr (STEADY) { if (big) wait_vmcnt<NP + NL>(); else wait_vmcnt<NP - 1 + (NL < NP ? NL : NP - 1)>(); }
+            else tail_wait(kt);
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);                     // lgkmcnt(0): this wave's reads are in registers
         __builtin_amdgcn_s_barrier();
@@ -1275,12 +1285,17 @@ __global__ __launch_bounds__(512, 2) void gemm_kphase_kernel(GemmParams p, int n
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int i = 0; i < WM; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][i], bfr[s], acc[i][0], 0, 0, 0);
+            for (int i = 0; i < WM; ++i) {
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][i], bfr[s], acc[i][0], 0, 0, 0);
+                // one request behind every second MFMA
+                const int m = s * WM + i;
+                if ((m & 1) && NL + (m >> 1) < NP && req) issue_piece(kt + S - 1, NL + (m >> 1));
+            }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         if (!grp) {
             if constexpr (STEADY) { if (big) wait_vmcnt<2 * NP>(); else wait_vmcnt<2 * NP - 2>(); }
-            else if (kt + 1 < nk) wait_tile(kt + 1);
+            else tail_wait(kt);
         }
         __builtin_amdgcn_s_barrier();
     };
@@ -1327,15 +1342,16 @@ int launch_ksplit(const GemmParams& p, const GemmTune& t, hipStream_t stream) {
     pb.band = xcd_band(tiles, ceil_div(p.N, bn), grid, t);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(2 * WGM * WGN * 64), lds, stream, pb, tiles);
     LAUNCH_OK("gemm (k-split)");
+    g_last_path = 3;
     return 0;
 }
 
-template <int EPI, int WM>
+template <int EPI, int WM, int NL>
 int launch_kphase(const GemmParams& p, const GemmTune& t, hipStream_t stream) {
     constexpr int bm = WM * 32, bn = 128, stage = (bm + bn) * 128;
     constexpr int scratch = 3 * stage > 4 * WM * 4096 ? 3 * stage : 4 * WM * 4096;
     constexpr int lds = 4 * stage > scratch + 8 * 4096 ? 4 * stage : scratch + 8 * 4096;
-    auto kern = gemm_kphase_kernel<EPI, WM>;
+    auto kern = gemm_kphase_kernel<EPI, WM, NL>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
@@ -1352,6 +1368,7 @@ int launch_kphase(const GemmParams& p, const GemmTune& t, hipStream_t stream) {
     pb.band = xcd_band(tiles, ceil_div(p.N, bn), grid, t);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, pb, tiles);
     LAUNCH_OK("gemm (phased k-split)");
+    g_last_path = 4;
     return 0;
 }
 
@@ -1405,6 +1422,7 @@ int launch_cfg(const GemmParams& p, const GemmTune& t, hipStream_t stream) {
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(nw * 64), lds, stream, p, tiles);
     LAUNCH_OK("gemm");
+    g_last_path = 1;
     return 0;
 }
 
@@ -1504,6 +1522,7 @@ int launch_streamk(const GemmParams& p_in, SkPlan plan, hipStream_t stream) {
     const int grid = (int)(((long)tiles * (p.K / 64) + share - 1) / share + 7) & ~7;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p, tiles);
     LAUNCH_OK("gemm (stream-K)");
+    g_last_path = 5;
     return 0;
 }
 
@@ -1544,6 +1563,7 @@ int launch_big8(const GemmParams& p, const GemmTune& t, hipStream_t stream) {
     pb.band = xcd_band(tiles, ceil_div(p.N, bn), grid, t);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, pb, tiles);
     LAUNCH_OK("gemm (staggered 8-wave)");
+    g_last_path = 2;
     return 0;
 }
 bool big8_ok(const GemmParams& p, const GemmTune& t) {
@@ -1563,8 +1583,12 @@ int launch_epi(const GemmParams& p, const GemmTune& t, hipStream_t stream) {
     }
     if constexpr (!BF8 && (EPI == EPI_BIAS_RESID_F32 || EPI == EPI_F32 || EPI == EPI_BF16 || EPI == EPI_BIAS_RESID_KEEP || EPI == EPI_PATCH_EMBED)) {
         const int kwm = use_ksplit(p, t, cfg);
-        if (kwm == 5 && t.ksplit_stagger == 2) return launch_kphase<EPI, 5>(p, t, stream);
-        if (kwm == 3 && t.ksplit_stagger == 2) return launch_kphase<EPI, 3>(p, t, stream);
+        if (kwm && t.ksplit_stagger == 2) {
+            // requests between the MFMAs (kphase_nl = 2: two in LOAD, the rest behind every second MFMA) win 3 % back to back and
+            // lose 0.9 % in the step (28.14 k vs 27.89 k images/s, two pairs; profiles/r03_gemm_experiments.md section 8)
+            if (kwm == 5) return t.kphase_nl <= 2 ? launch_kphase<EPI, 5, 2>(p, t, stream) : launch_kphase<EPI, 5, 8>(p, t, stream);
+            return t.kphase_nl <= 2 ? launch_kphase<EPI, 3, 2>(p, t, stream) : launch_kphase<EPI, 3, 8>(p, t, stream);
+        }
         if (kwm == 5) return t.ksplit_stagger ? launch_ksplit<EPI, 1, 4, 5, 1, true>(p, t, stream) : launch_ksplit<EPI, 1, 4, 5, 1, false>(p, t, stream);
         if (kwm == 3) return launch_ksplit<EPI, 1, 4, 3, 1, true>(p, t, stream);
         const SkPlan plan = streamk_plan(p, t, cfg);
@@ -1596,6 +1620,7 @@ int launch_f8a(const GemmParams& p, const GemmTune& t, hipStream_t stream) {
 }  // namespace
 
 int pevit_gemm_sk_slots() { return min(2 * num_cus(), PEVIT_SK_MAX_SLOTS) & ~7; }
+int pevit_gemm_last_path() { return g_last_path; }
 
 int pevit_launch_gemm(int epi, const GemmParams& p_in, const GemmTune& t, hipStream_t stream) {
     GemmParams p = p_in;

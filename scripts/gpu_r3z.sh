@@ -1,0 +1,11 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
+mkdir -p gpurun_out
+J='import sys,json; d=json.loads(sys.stdin.readline()); r=d["roofline"]; print(sys.argv[1], round(d["value"],1), round(d["ms_per_step"],3), "gemm TF/s", round(r["achieved"],1), "gemm ms", round(r.get("gemm_ms_per_step",0),3))'
+echo "== phased tests"; timeout 1500 python -m pytest tests/test_gpu_ops.py -x -q -m gpu -k "phased" 2>&1 | tail -4
+echo "== other archs: ksplit 1 vs 2 (phased kernel on several rounds)"
+for a in "ViT-L/14 32" "ViT-B/16 64"; do set -- $a; for k in 1 2; do timeout 600 python bench.py --arch $1 --batch $2 --steps 30 --warmup 5 --no-cpu-baseline --tune gemm_ksplit=$k 2>/dev/null | python -c "$J" "$1 b$2 ksplit=$k"; done; done
+echo "== methods"
+for m in kadaptation lora adapter compacter; do timeout 600 python bench.py --method $m --steps 50 --warmup 10 --no-cpu-baseline 2>/dev/null | python -c "$J" "$m"; done
+echo "== pmc passes"; bash scripts/run_pmc_passes.sh r03 2>&1 | tail -40 | cut -c1-1500
+echo "== batch 64 line"; timeout 300 python bench.py --batch 64 --no-cpu-baseline 2>/dev/null | tee gpurun_out/r3_bench_b64.json | cut -c1-300

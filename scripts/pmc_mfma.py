@@ -22,7 +22,7 @@ for k, d in sorted(per.items(), key=lambda kv: -kv[1].get("SQ_VALU_MFMA_BUSY_CYC
         continue
     n, busy = d["SQ_VALU_MFMA_BUSY_CYCLES"]; _, act = d["GRBM_GUI_ACTIVE"]
     tot_busy += busy; tot_act += act
-    if any(x in k for x in ("gemm_kernel<", "gemm_streamk_kernel<", "gemm_ksplit_kernel<")):
+    if any(x in k for x in ("gemm_kernel<", "gemm8_kernel<", "gemm_streamk_kernel<", "gemm_ksplit_kernel<", "gemm_kphase_kernel<")):
         fam_busy += busy; fam_act += act
     if busy <= 0:
         continue

@@ -40,7 +40,7 @@ def family(stats, needles):
     return n, tot
 
 
-GEMM_FAMILY = ("gemm_kernel<", "gemm8_kernel<", "gemm_streamk_kernel<", "gemm_ksplit_kernel<")   # every kernel of pevit_amd/csrc/gemm.hip
+GEMM_FAMILY = ("gemm_kernel<", "gemm8_kernel<", "gemm_streamk_kernel<", "gemm_ksplit_kernel<", "gemm_kphase_kernel<")   # every kernel of pevit_amd/csrc/gemm.hip
 
 
 def main():
@@ -70,7 +70,7 @@ def main():
                  "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr},
         "calibration": {"kernel": "cast_f32_to_bf16 over 2^28 elements (1 GiB read, 0.5 GiB written)",
                         "read_factor_true_over_counter": read_factor, "write_factor_true_over_counter": write_factor},
-        "how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, KiB), summed over every gemm_kernel / gemm8_kernel / gemm_ksplit_kernel / gemm_streamk_kernel "
+        "how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, KiB), summed over every gemm_kernel / gemm8_kernel / gemm_ksplit_kernel / gemm_kphase_kernel / gemm_streamk_kernel "
                "dispatch of `bench.py --steps 3 --warmup 1`, / dispatches, x the true/counter factor measured in the same pass "
                "on a 1 GiB streaming cast (read %.3f, write %.3f)" % (read_factor, write_factor),
     }

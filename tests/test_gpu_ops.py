@@ -360,3 +360,40 @@ def test_gemm_streamk_with_the_chip_shared(lib):
             assert torch.equal(out, ref)
     side.synchronize()
     assert lib.pevit_streamk_error(None, S()) == 0
+
+
+@pytest.mark.parametrize("M,N,K", [(6400, 768, 64), (6400, 768, 128), (6400, 768, 192), (6400, 768, 256), (6400, 768, 320),
+                                   (6333, 760, 832), (3200, 768, 3072), (3111, 768, 2368), (12800, 768, 768), (5000, 1024, 512)])
+@pytest.mark.parametrize("nl", [8, 2])
+def test_gemm_phased_ksplit_tile(lib, M, N, K, nl):
+    """The phased k-split kernel (two wave groups take the two halves of every k-tile; 4 LDS stages, exact vmcnt waits) at its
+    edges: 1, 2, 3 k-tiles (no steady state: prologue and tail only), 4 and 5 (one and two steady iterations), an odd number of
+    k-tiles, ragged M and N, the 96x128 form (M = 3200: 204 tiles), several tiles per workgroup (gemm_ksplit=2: M = 12800 gives
+    480 tiles; 5000x1024 gives 256 with a partial last m-tile), and with the requests placed between the MFMAs (nl = 2).
+    Every epilogue the step runs on it, against the torch product of the same bf16 operands."""
+    A = rnd(M, K, seed=1, dtype=torch.bfloat16)
+    B = rnd(N, K, seed=2, scale=0.05, dtype=torch.bfloat16)
+    bias = rnd(N, seed=5, scale=0.1)
+    resid = rnd(M, N, seed=6)
+    ref = A.float() @ B.float().T
+    # gemm_big=0: keep the 8-wave tiles away from M = 12800 (the heuristic would take 320x256 there)
+    for key, val in ((b"gemm_ksplit", 2), (b"gemm_ksplit_mink", 64), (b"gemm_ksplit_stagger", 2), (b"gemm_kphase_nl", nl), (b"gemm_big", 0)):
+        assert lib.pevit_tune(None, key, val) == 0
+    try:
+        o1 = torch.full((M, N), float("nan"), device="cuda")
+        gemm(lib, EPI["BIAS_RESID"], A, B, M, N, K, bias=bias, resid=resid, outf=o1)
+        assert lib.pevit_debug_last_gemm_path() == 4, "the heuristic did not take the phased k-split kernel for this shape"
+        o2 = torch.full((M, N), float("nan"), device="cuda")
+        gemm(lib, EPI["F32"], A, B, M, N, K, outf=o2)
+        o3 = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
+        gemm(lib, EPI["BF16"], A, B, M, N, K, outb=o3)
+        # in place on the residual stream, as the block runs it (x += proj(...))
+        x = resid.clone()
+        gemm(lib, EPI["BIAS_RESID"], A, B, M, N, K, bias=bias, resid=x, outf=x)
+    finally:
+        for key, val in ((b"gemm_ksplit", 1), (b"gemm_ksplit_mink", 512), (b"gemm_kphase_nl", 8), (b"gemm_big", 1)):
+            lib.pevit_tune(None, key, val)
+    assert max_rel(o1.cpu(), (ref + bias + resid).cpu()) < 2e-4
+    assert max_rel(o2.cpu(), ref.cpu()) < 2e-4
+    assert max_rel(o3.float().cpu(), ref.cpu()) < 1e-2
+    assert torch.equal(x, o1)
