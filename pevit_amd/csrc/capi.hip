@@ -1289,6 +1289,7 @@ extern "C" int pevit_tune(pevit_ctx* c, const char* key, int value) {
     if (key && !strcmp(key, "gemm_band")) { t.band = value; return 0; }
     if (key && !strcmp(key, "gemm_stagger")) { t.stagger = value; return 0; }
     if (key && c && !strcmp(key, "dx_stored")) { c->dx_stored = value; return 0; }
+    if (key && !strcmp(key, "lowrank_xcd")) { pevit_lowrank_set_xcd(value); return 0; }
     pevit_set_error("tune: unknown key %s", key ? key : "(null)");
     return -1;
 }

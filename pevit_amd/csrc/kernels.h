@@ -66,6 +66,7 @@ struct GemmTune {
 };
 constexpr int PEVIT_SK_SLAB_FLOATS = 128 * 128;   // one partial tile per residency slot
 constexpr int PEVIT_SK_MAX_SLOTS = 1024;
+void pevit_lowrank_set_xcd(int v);                  // lowrank_grad: XCD-contiguous workgroup order (measurement knob, default on)
 int pevit_gemm_last_path();                        // 1 plain tile, 2 staggered 8-wave, 3 k-split (alternate k-tiles), 4 phased k-split, 5 stream-K
 int pevit_gemm_sk_slots();                         // residency slots of the stream-K kernel on this device (2 per CU, multiple of 8)
 

@@ -310,14 +310,17 @@ __global__ __launch_bounds__(256, 2) void lowrank_grad_kernel(const bf16* __rest
                                                               const bf16* __restrict__ dqkv, int ld,
                                                               const float* __restrict__ t, float* __restrict__ partial,
                                                               float* __restrict__ dbias_partial, int B, int H, int N,
-                                                              int E) {
+                                                              int E, int remap) {
     __shared__ __attribute__((aligned(16))) bf16 Xs[LG_ROWS * LG_LD];
     __shared__ __attribute__((aligned(16))) bf16 Ys[LG_ROWS * LG_LD];
     __shared__ float cs[4][64];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, c16 = lane & 15;
     const int groups = E / 64 / LG_ES;
     const int per_chunk = groups * 3;
-    const int chunk = blockIdx.x / per_chunk, rem = blockIdx.x - chunk * per_chunk;
+    // the `groups` workgroups of a (chunk, kind) read the same Y rows (64 KB of u / 32 KB of t): consecutive LOGICAL ids on one
+    // XCD (workgroup b runs on XCD b % 8), so that its L2 fetches them once instead of up to six L2s once each
+    const int bid = remap ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int chunk = bid / per_chunk, rem = bid - chunk * per_chunk;
     const int kind = rem / groups, eg = rem - kind * groups;
     const int T = B * N;
     const int r0 = chunk * LG_ROWS;
@@ -525,7 +528,10 @@ __global__ void chain_lora_kernel(const float* __restrict__ G, float ascale, int
     g_a2v[(size_t)e * r + j] += ascale * G[3 * plane + (size_t)e * 32 + j];
 }
 
+int g_lowrank_xcd = 1;
 }  // namespace
+
+void pevit_lowrank_set_xcd(int v) { g_lowrank_xcd = v; }
 
 int pevit_launch_prep_kadapt(const float* rule1_l, const float* rule1_r, const float* rule2_l, const float* rule2_r,
                              const float* q_left, const float* q_right, AdapterPanels pan, int E, float ascale,
@@ -581,7 +587,7 @@ int pevit_launch_lowrank_grad(const bf16* xn, int ldx, const float* u32, const b
     if (chunks != ceil_div(T, LG_ROWS)) { pevit_set_error("lowrank_grad: chunks mismatch"); return -1; }
     if (E % (64 * LG_ES)) { pevit_set_error("lowrank_grad: width %d must be a multiple of %d", E, 64 * LG_ES); return -1; }
     hipLaunchKernelGGL(lowrank_grad_kernel, dim3(chunks * (E / 64 / LG_ES) * 3), dim3(256), 0, s, xn, ldx, u32, dqkv, ld, t,
-                       partial, dbias_partial, B, H, N, E);
+                       partial, dbias_partial, B, H, N, E, g_lowrank_xcd);
     LAUNCH_OK("lowrank_grad_kernel");
     return 0;
 }
