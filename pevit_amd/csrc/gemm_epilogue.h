@@ -33,9 +33,18 @@ __device__ __forceinline__ void mul8(float v[8], const float* src) {
     v[0] *= b0.x; v[1] *= b0.y; v[2] *= b0.z; v[3] *= b0.w;
     v[4] *= b1.x; v[5] *= b1.y; v[6] *= b1.z; v[7] *= b1.w;
 }
+#ifndef PEVIT_NT_STORES
+#define PEVIT_NT_STORES 0      // measurement builds (scripts/build_variants.sh): 1 = bf16 epilogue stores non-temporal, 2 = f32 ones
+#endif
 __device__ __forceinline__ void store8f(float* dst, const float v[8]) {
+#if PEVIT_NT_STORES & 2
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store(f32x4v{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4v*>(dst));
+    __builtin_nontemporal_store(f32x4v{v[4], v[5], v[6], v[7]}, reinterpret_cast<f32x4v*>(dst + 4));
+#else
     *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
     *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+#endif
 }
 // activation storage: bf16 (production) or f32 (the f32-class verification mode, PEVIT_W_F32_VERIFY); pointers are
 // declared bf16* throughout and reinterpreted here, element offsets are in elements of ST
@@ -44,7 +53,11 @@ template <typename ST> __device__ __forceinline__ void store8s(bf16* base, size_
         bf16x8 o;
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[i] = f2bf(v[i]);
+#if PEVIT_NT_STORES & 1
+        __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(base + off));
+#else
         store_bf16x8(base + off, o);
+#endif
     } else {
         store8f(reinterpret_cast<float*>(base) + off, v);
     }
