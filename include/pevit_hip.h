@@ -190,7 +190,7 @@ int pevit_op_gemm_f8a(void* stream, int epilogue, const void* A_codes, int lda, 
 /* src (rows x cols f32, cols % 128 == 0) -> e4m3 codes without a scale (|x| > 448 saturates), k-permuted per 128 */
 int pevit_op_cast_fp8(void* stream, const float* src, void* codes, int rows, int cols);
 /* Which kernel family the last pevit_op_gemm / in-step product of this process was launched on (tests, measurements):
- * 1 plain tile, 2 staggered 8-wave tile, 3 k-split tile (alternate k-tiles), 4 phased k-split tile, 5 stream-K. */
+ * 1 plain tile, 2 staggered 8-wave tile, 3 k-split tile (alternate k-tiles), 4 phased k-split tile, 5 stream-K, 6 few-row split-K. */
 int pevit_debug_last_gemm_path(void);
 /* W (rows x cols f32, cols % 128 == 0) -> per-row power-of-two scales 2^ceil(log2(amax/448)), e4m3 codes [rows][cols]
  * and (codes_t != NULL, rows % 128 == 0) the same codes transposed [cols][rows]; both k-permuted per 128 */

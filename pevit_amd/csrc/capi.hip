@@ -1286,6 +1286,10 @@ extern "C" int pevit_tune(pevit_ctx* c, const char* key, int value) {
     if (key && !strcmp(key, "gemm_ksplit_stagger")) { t.ksplit_stagger = value; return 0; }
     if (key && !strcmp(key, "gemm_ksplit_mink")) { t.ksplit_mink = value; return 0; }
     if (key && !strcmp(key, "gemm_kphase_nl")) { t.kphase_nl = value; return 0; }
+    if (key && !strcmp(key, "gemm_skinny")) { t.skinny = value; return 0; }
+    if (key && !strcmp(key, "gemm_skinny_maxm")) { t.skinny_maxm = value; return 0; }
+    if (key && !strcmp(key, "gemm_skinny_mink")) { t.skinny_mink = value; return 0; }
+    if (key && !strcmp(key, "gemm_skinny_slices")) { t.skinny_slices = value; return 0; }
     if (key && !strcmp(key, "gemm_band")) { t.band = value; return 0; }
     if (key && !strcmp(key, "gemm_stagger")) { t.stagger = value; return 0; }
     if (key && c && !strcmp(key, "dx_stored")) { c->dx_stored = value; return 0; }

@@ -928,6 +928,155 @@ __global__ __launch_bounds__(256, 2) void gemm_streamk_kernel(GemmParams p, int 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Few-row long-K products (M <= 128, K >= 1536: c_proj forward and c_fc backward on the class-token rows of the last block):
+// 6 tiles of 128x128 for 256 CUs.  Stream-K gives such a tile two workgroups that walk 24 k-tiles each behind a two-stage
+// ring (31 us for 0.6 GFLOP), and is switched off under data parallelism (its consumers WAIT for their producers, which must
+// therefore be resident).  Here: 128x64 tiles, the K range cut into a few slices of ~12 k-tiles, one workgroup per
+// (tile, slice) with a FOUR-stage ring and exact vmcnt waits; the 128x64 f32 partial goes to a slab (write-through stores) and
+// the workgroup that draws the LAST ticket of its tile adds the slabs in slice order -- a fixed order, so the result does not
+// depend on who arrives last -- and runs the epilogue.  Nobody waits for anybody: no residency requirement.
+// Bounds (measured, profiles/r03_gemm_experiments.md 5c): one CU moves ~60 GB/s, so both the k-walk of a workgroup and the
+// slabs its tile's finisher re-reads must stay at a few hundred KB: 16 slices of 3 k-tiles made the finisher read 1 MB (27 us).
+// Slabs and ticket words are the stream-K workspace (GemmParams::sk_slab / sk_flag; tickets return to 0).
+template <int EPI>
+__global__ __launch_bounds__(256, 1) void gemm_skinny_kernel(GemmParams p, int tiles_n, int nslices, int ksl) {
+    constexpr int NW = 4, WN = 2, BM = 128, BN = 64, BK = 64, S = 4;
+    constexpr int ROWB = 128, CH = 8, RPP = 8;
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int PA = BM / RPP / NW, PB = BN / RPP / NW, KS = BK / 16, NPW = PA + PB;     // pieces per wave per k-tile
+    constexpr int SLAB = BM * BN;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ unsigned ticket;
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave w: rows 32w .. 32w+31, all 64 columns
+    const int tile = blockIdx.x / nslices, slice = blockIdx.x - tile * nslices;
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int nk = p.K / BK;
+    const int k0 = slice * ksl, n = min(nk, k0 + ksl) - k0;               // this slice: k-tiles [k0, k0 + n)
+    const char* a_src[PA];
+    const char* b_src[PB];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int row = (wid * PA + i) * RPP + lane / CH;
+        const int chunk = (lane % CH) ^ ((row >> 1) & (CH - 1));
+        int ar = m0 + row; ar = ar < p.M ? ar : p.M - 1;
+        a_src[i] = reinterpret_cast<const char*>(p.A + (size_t)ar * p.lda) + chunk * 16 + (size_t)k0 * 128;
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+        const int row = (wid * PB + i) * RPP + lane / CH;
+        const int chunk = (lane % CH) ^ ((row >> 1) & (CH - 1));
+        int br = n0 + row; br = br < p.Nb ? br : p.Nb - 1;
+        b_src[i] = reinterpret_cast<const char*>(p.B) + (size_t)br * p.ldb * 2 + chunk * 16 + (size_t)k0 * 128;
+    }
+    auto issue_tile = [&](int kt) {
+        char* st = smem + (kt & (S - 1)) * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) glds16(a_src[i] + kt * 128, st + (wid * PA + i) * 1024);
+#pragma unroll
+        for (int i = 0; i < PB; ++i) glds16(b_src[i] + kt * 128, st + A_BYTES + (wid * PB + i) * 1024);
+    };
+#pragma unroll
+    for (int kt = 0; kt < S - 1; ++kt)
+        if (kt < n) issue_tile(kt);
+    const int frow = lane & 31, fswz = (frow >> 1) & (CH - 1), fhalf = lane >> 5;
+    f32x16 acc[WN];
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+    for (int kt = 0; kt < n; ++kt) {
+        // k-tile kt has landed when at most the younger requested ones (up to kt + S - 2) are in flight
+        const int after = min(n - 1, kt + S - 2) - kt;
+        if (after >= 2) wait_vmcnt<2 * NPW>(); else if (after == 1) wait_vmcnt<NPW>(); else wait_vmcnt<0>();
+        __syncthreads();                                      // ... for every wave; and stage (kt - 1) % S is free again
+        if (kt + S - 1 < n) issue_tile(kt + S - 1);
+        const char* sa = smem + (kt & (S - 1)) * STAGE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int coff = (((ks * 2 + fhalf) ^ fswz) << 4);
+            const bf16x8 af = *reinterpret_cast<const bf16x8*>(sa + (wid * 32 + frow) * ROWB + coff);
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(sa + A_BYTES + (j * 32 + frow) * ROWB + coff);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[j], 0, 0, 0);
+            }
+        }
+    }
+    if (nslices > 1) {
+        // ---- publish this slice's partial, draw a ticket; the last arriver of the tile sums all slabs in slice order
+        float* slab = p.sk_slab + (size_t)blockIdx.x * SLAB;
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = {acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]};
+                sk_store16_sc1(slab + ((((wid * WN + j) * 4 + q) * 64 + lane) << 2), v);
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) ticket = __hip_atomic_fetch_add(p.sk_flag + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (ticket != (unsigned)(nslices - 1)) return;        // block-uniform
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (threadIdx.x == 0) __hip_atomic_store(p.sk_flag + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+        f32x4 part[6][WN][4];                                 // all slabs requested before the first add
+        const float* base = p.sk_slab + (size_t)tile * nslices * SLAB;
+#pragma unroll
+        for (int sl = 0; sl < 6; ++sl)
+            if (sl < nslices) {
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        part[sl][j][q] = *reinterpret_cast<const f32x4*>(base + (size_t)sl * SLAB + ((((wid * WN + j) * 4 + q) * 64 + lane) << 2));
+            }
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+#pragma unroll
+        for (int sl = 0; sl < 6; ++sl)
+            if (sl < nslices) {
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[j][4 * q + r] += part[sl][j][q][r];
+            }
+    }
+    __syncthreads();                                          // every wave is past its LDS reads: stage 0 serves as epilogue scratch
+    float* cw = reinterpret_cast<float*>(smem + wid * 4096);
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            cw[row * 32 + (lane & 31)] = acc[j][r];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int lr = pass * 16 + (lane >> 2);
+            const int lc = (lane & 3) * 8;
+            const int row = m0 + wid * 32 + lr;
+            const int col = n0 + j * 32 + lc;
+            const float4 x0 = *reinterpret_cast<const float4*>(cw + lr * 32 + lc);
+            const float4 x1 = *reinterpret_cast<const float4*>(cw + lr * 32 + lc + 4);
+            if (row < p.M && col < p.N) {
+                float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                epilogue_store<EPI, bf16>(p, row, col, v);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
 // The end of a k-split tile, shared by gemm_ksplit_kernel and gemm_kphase_kernel: the two groups' partial sums meet through
 // LDS (every wave is past its last k-tile and has no request in flight): fragment f = i * WN + j is FINISHED by group f % 2,
 // which receives the other group's partial at hand[((gw * NF + f) * 16 + r) * 64 + lane] and runs that fragment's epilogue.
@@ -1162,7 +1311,7 @@ __global__ __launch_bounds__(2 * WGM * WGN * 64, 1) void gemm_ksplit_kernel(Gemm
 template <int EPI, int WM, int NLREQ>
 __global__ __launch_bounds__(512, 2) void gemm_kphase_kernel(GemmParams p, int ntiles) {
     constexpr int NW = 8, NWG = 4, WN = 1, S = 4;
-    constexpr int BM = WM * 32, BN = 128, BK = 64, KS = 4;
+    constexpr int BM = WM * 32, BN = 128, BK = 64;
     constexpr int ROWB = 128, CH = 8, RPP = 8;
     constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE_BYTES = A_BYTES + B_BYTES;
     constexpr int PA_T = BM / RPP, NPT = (BM + BN) / RPP, NP = (NPT + NW - 1) / NW, NFULL = NPT % NW ? NPT % NW : NW;
@@ -1526,6 +1675,39 @@ int launch_streamk(const GemmParams& p_in, SkPlan plan, hipStream_t stream) {
     return 0;
 }
 
+// few-row long-K products on gemm_skinny_kernel: 2-6 slices of ~12 k-tiles, tiles x slices within the slab slots
+struct SkinnyPlan { int nslices, ksl; };
+SkinnyPlan skinny_plan(const GemmParams& p, const GemmTune& t) {
+    const SkinnyPlan none{0, 0};
+    if (!t.skinny || t.config >= 0 || t.ablate || p.b_fp8 || p.a_fp8 || !p.sk_slab || !p.sk_flag) return none;
+    const int nk = p.K / 64;
+    if (p.M > t.skinny_maxm || p.N < 64 || nk < t.skinny_mink) return none;
+    const long tiles = (long)ceil_div(p.M, 128) * ceil_div(p.N, 64);
+    const int slots = min(pevit_gemm_sk_slots(), p.sk_slots);       // a slot holds 128x128 floats: two of these slabs
+    const int nslices = t.skinny_slices > 0 ? min(6, max(1, t.skinny_slices)) : min(6, max(2, (nk + 6) / 12));
+    if (tiles * nslices > 2L * slots || tiles > slots) return none;  // tickets: one word per tile
+    return SkinnyPlan{nslices, ceil_div(nk, nslices)};
+}
+
+template <int EPI>
+int launch_skinny(const GemmParams& p, SkinnyPlan plan, hipStream_t stream) {
+    constexpr int lds = 4 * (128 + 64) * 128;
+    auto kern = gemm_skinny_kernel<EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+            pevit_set_error("hipFuncSetAttribute(few-row gemm epi %d) failed", EPI);
+            return -1;
+        }
+        attr_set = true;
+    }
+    const int tiles_n = ceil_div(p.N, 64), tiles = ceil_div(p.M, 128) * tiles_n;
+    hipLaunchKernelGGL(kern, dim3(tiles * plan.nslices), dim3(256), lds, stream, p, tiles_n, plan.nslices, plan.ksl);
+    LAUNCH_OK("gemm (few rows)");
+    g_last_path = 6;
+    return 0;
+}
+
 // the 160x128 two-group tile: where the heuristic takes a 4-wave tile for a long-K problem whose 160x128 tiling gives (almost)
 // every CU exactly one tile -- the N = E products of ViT-B/32 at B = 128 (240 tiles)
 // returns the tile height in fragments: 5 (160x128), 3 (96x128: M = 3200, the reference's own batch of 64, gives 204 tiles where
@@ -1574,6 +1756,11 @@ bool big8_ok(const GemmParams& p, const GemmTune& t) {
 
 template <int EPI, bool BF8>
 int launch_epi(const GemmParams& p, const GemmTune& t, hipStream_t stream) {
+    if constexpr (!BF8 && (EPI == EPI_BIAS_RESID_F32 || EPI == EPI_F32 || EPI == EPI_BF16 || EPI == EPI_BIAS_RESID_KEEP ||
+                           EPI == EPI_BIAS_GELU || EPI == EPI_DGELU_BF16)) {
+        const SkinnyPlan sp = skinny_plan(p, t);
+        if (sp.nslices) return launch_skinny<EPI>(p, sp, stream);
+    }
     const bool stag = big8_ok(p, t);
     const int cfg = pick_config(p, t, stag);
     if (stag) {

@@ -58,6 +58,8 @@ struct GemmTune {
     int ksplit = 1;       // N = E long-K products with ~one 160x128 tile per CU: 8-wave tile, two wave groups on alternate k-tiles
     int ksplit_small = 1;     // ... also as a 96x128 tile where that fills the chip and 160x128 does not (M = 3200)
     int ksplit_stagger = 2;   // ... 1: its two wave groups half an iteration apart (alternate k-tiles); 2: phased kernel (groups split each k-tile, 4 stages)
+    int skinny = 1;           // few-row long-K products (M <= skinny_maxm, K >= 64 * skinny_mink): K slices, last arriver sums the slabs (gemm_skinny_kernel)
+    int skinny_maxm = 128, skinny_mink = 24, skinny_slices = 0;   // skinny_slices > 0: measurement
     int kphase_nl = 8;        // ... phased kernel: LDS-DMA pieces per k-tile requested in the LOAD section (the rest between the MFMAs)
     int ksplit_mink = 512;    // ... from this K on
     int band = -1;        // >= 0 forces GemmParams::band of the one-round 8-wave launches (measurement); -1 = XCD-aligned
@@ -67,7 +69,7 @@ struct GemmTune {
 constexpr int PEVIT_SK_SLAB_FLOATS = 128 * 128;   // one partial tile per residency slot
 constexpr int PEVIT_SK_MAX_SLOTS = 1024;
 void pevit_lowrank_set_xcd(int v);                  // lowrank_grad: XCD-contiguous workgroup order (measurement knob, default on)
-int pevit_gemm_last_path();                        // 1 plain tile, 2 staggered 8-wave, 3 k-split (alternate k-tiles), 4 phased k-split, 5 stream-K
+int pevit_gemm_last_path();                        // 1 plain tile, 2 staggered 8-wave, 3 k-split (alternate k-tiles), 4 phased k-split, 5 stream-K, 6 few-row split-K
 int pevit_gemm_sk_slots();                         // residency slots of the stream-K kernel on this device (2 per CU, multiple of 8)
 
 int pevit_launch_gemm(int epi, const GemmParams& p, const GemmTune& t, hipStream_t stream);

@@ -397,3 +397,61 @@ def test_gemm_phased_ksplit_tile(lib, M, N, K, nl):
     assert max_rel(o2.cpu(), ref.cpu()) < 2e-4
     assert max_rel(o3.float().cpu(), ref.cpu()) < 1e-2
     assert torch.equal(x, o1)
+
+
+@pytest.mark.parametrize("M,N,K,slices", [(128, 768, 3072, 0), (64, 768, 3072, 0), (128, 768, 3072, 2), (128, 768, 3072, 6), (128, 768, 3072, 1),
+                                          (100, 512, 1600, 0), (1, 768, 2048, 3), (128, 760, 1536, 5), (37, 1024, 4096, 0)])
+def test_gemm_few_row_split_k(lib, M, N, K, slices):
+    """Few-row long-K products (c_proj forward / c_fc backward on the class-token rows of the last block) on gemm_skinny_kernel:
+    128x64 tiles, 2-6 K slices with a four-stage ring (slices of 4 to 48 k-tiles here, an odd count and a short last slice
+    included; one slice = no hand-off at all), the last arriver of a tile adds the partial slabs in slice order.  Every epilogue
+    the step runs on it against the torch product; launched twice (the tickets must be back at zero) with bit-identical results
+    (fixed summation order, whoever arrives last); strided A rows like the class-token view of a [B][N][E] buffer."""
+    assert lib.pevit_tune(None, b"gemm_skinny_slices", slices) == 0
+    A = rnd(M, K, seed=1, dtype=torch.bfloat16)
+    B = rnd(N, K, seed=2, scale=0.05, dtype=torch.bfloat16)
+    bias = rnd(N, seed=5, scale=0.1)
+    resid = rnd(M, N, seed=6)
+    acc = A.float() @ B.float().T
+    outs = []
+    for rep in range(2):
+        o1 = torch.full((M, N), float("nan"), device="cuda")
+        gemm(lib, EPI["BIAS_RESID"], A, B, M, N, K, bias=bias, resid=resid, outf=o1)
+        assert lib.pevit_debug_last_gemm_path() == 6, "the heuristic did not take the few-row kernel for this shape"
+        o2 = torch.full((M, N), float("nan"), device="cuda")
+        gemm(lib, EPI["F32"], A, B, M, N, K, outf=o2)
+        o3 = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
+        gemm(lib, EPI["BF16"], A, B, M, N, K, outb=o3)
+        h = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda"); g = torch.zeros_like(h)
+        gemm(lib, EPI["BIAS_GELU"], A, B, M, N, K, bias=bias, outb=h, outb2=g)
+        d = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
+        gemm(lib, EPI["DGELU"], A, B, M, N, K, outb=d, aux=h)
+        assert lib.pevit_debug_last_gemm_path() == 6
+        outs.append((o1, o2, o3, h, g, d))
+    o1, o2, o3, h, g, d = outs[0]
+    assert max_rel(o1.cpu(), (acc + bias + resid).cpu()) < 2e-4
+    assert max_rel(o2.cpu(), acc.cpu()) < 2e-4
+    assert max_rel(o3.float().cpu(), acc.cpu()) < 1e-2
+    assert max_rel(h.float().cpu(), (acc + bias).cpu()) < 1e-2
+    assert max_rel(g.float().cpu(), (h.float() * torch.sigmoid(1.702 * h.float())).cpu()) < 1e-2
+    s = torch.sigmoid(1.702 * h.float())
+    assert max_rel(d.float().cpu(), (acc * (s * (1 + 1.702 * h.float() * (1 - s)))).cpu()) < 1e-2
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    # rows three "tokens" apart, as the class-token rows of a [M][3][K] buffer
+    wide = rnd(M, 3 * K, seed=7, dtype=torch.bfloat16)
+    As = wide[:, :K]
+    o4 = torch.full((M, N), float("nan"), device="cuda")
+    gemm(lib, EPI["F32"], As, B, M, N, K, outf=o4)
+    assert lib.pevit_debug_last_gemm_path() == 6
+    assert max_rel(o4.cpu(), (As.float() @ B.float().T).cpu()) < 2e-4
+    # the plain tiling of the same product agrees to summation order
+    assert lib.pevit_tune(None, b"gemm_skinny", 0) == 0
+    try:
+        o5 = torch.full((M, N), float("nan"), device="cuda")
+        gemm(lib, EPI["F32"], A, B, M, N, K, outf=o5)
+        assert lib.pevit_debug_last_gemm_path() != 6
+    finally:
+        lib.pevit_tune(None, b"gemm_skinny", 1)
+    assert max_rel(o5.cpu(), o2.cpu()) < 2e-4
+    lib.pevit_tune(None, b"gemm_skinny_slices", 0)
