@@ -1684,7 +1684,7 @@ SkinnyPlan skinny_plan(const GemmParams& p, const GemmTune& t) {
     if (p.M > t.skinny_maxm || p.N < 64 || nk < t.skinny_mink) return none;
     const long tiles = (long)ceil_div(p.M, 128) * ceil_div(p.N, 64);
     const int slots = min(pevit_gemm_sk_slots(), p.sk_slots);       // a slot holds 128x128 floats: two of these slabs
-    const int nslices = t.skinny_slices > 0 ? min(6, max(1, t.skinny_slices)) : min(6, max(2, (nk + 6) / 12));
+    const int nslices = t.skinny_slices > 0 ? min(6, max(1, t.skinny_slices)) : nk < 24 ? 1 : min(6, max(2, (nk + 6) / 12));
     if (tiles * nslices > 2L * slots || tiles > slots) return none;  // tickets: one word per tile
     return SkinnyPlan{nslices, ceil_div(nk, nslices)};
 }

@@ -168,19 +168,54 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(SmallGemm p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     float rsum = 0.f;
-    // wave w takes k-pairs w, w+4, ... ; 8 pairs are loaded ahead of their MFMAs
-    const int npairs = (p.K + 1) / 2;
-    for (int pb = wid; pb < npairs; pb += 32) {
-        float a[8], b[8];
+    // chunks of 8 k: lane (row, half) takes k = 8c + 4 half + u of chunk c for its u-th MFMA (the contraction order is free as long
+    // as A and B agree); an operand that is contiguous along k is read with one 16-byte load per chunk (the logits product, K = 512:
+    // both; the d-feature product: dlogits).  With 4-byte loads 2 KiB apart the logits product took 22 us of the head's 60.
+    const bool va = p.sAk == 1 && (p.sAi & 3) == 0 && (reinterpret_cast<size_t>(p.A) & 15) == 0;
+    const bool vb = p.sBk == 1 && (p.sBj & 3) == 0 && (reinterpret_cast<size_t>(p.B) & 15) == 0;
+    const int nchunks = (va || vb) ? p.K >> 3 : 0;
+    constexpr int CU = 4;       // chunks requested ahead of their MFMAs (8 and 16 pairs below measured no faster: 16.1 / 11.6 / 7.4 us vs 16.3 / 12.2 / 6.2)
+    for (int cb = wid; cb < nchunks; cb += 4 * CU) {
+        float4 a4[CU], b4[CU];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int k = 2 * (pb + 4 * u) + lk;
+        for (int u = 0; u < CU; ++u) {
+            const int c = cb + 4 * u;
+            const bool cok = c < nchunks;
+            const long k = 8 * (cok ? c : 0) + 4 * lk;
+            a4[u] = b4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (cok && iok) {
+                if (va) a4[u] = *reinterpret_cast<const float4*>(ap + k);
+                else a4[u] = make_float4(ap[k * p.sAk], ap[(k + 1) * p.sAk], ap[(k + 2) * p.sAk], ap[(k + 3) * p.sAk]);
+            }
+            if (cok && jok) {
+                if (vb) b4[u] = *reinterpret_cast<const float4*>(bp + k);
+                else b4[u] = make_float4(bp[k * p.sBk], bp[(k + 1) * p.sBk], bp[(k + 2) * p.sBk], bp[(k + 3) * p.sBk]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < CU; ++u) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[u].x, b4[u].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[u].y, b4[u].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[u].z, b4[u].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[u].w, b4[u].w, acc, 0, 0, 0);
+            rsum += (a4[u].x + a4[u].y) + (a4[u].z + a4[u].w);
+        }
+    }
+    // the rest (everything when neither operand is contiguous along k): wave w takes k-pairs w, w+4, ... ; 8 pairs are loaded ahead
+    const int kbase = nchunks * 8;
+    const int npairs = (p.K - kbase + 1) / 2;
+    constexpr int PU = 8;
+    for (int pb = wid; pb < npairs; pb += 4 * PU) {
+        float a[PU], b[PU];
+#pragma unroll
+        for (int u = 0; u < PU; ++u) {
+            const int k = kbase + 2 * (pb + 4 * u) + lk;
             const bool kok = (pb + 4 * u) < npairs && k < p.K;
             a[u] = (kok && iok) ? ap[(long)k * p.sAk] : 0.f;
             b[u] = (kok && jok) ? bp[(long)k * p.sBk] : 0.f;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < PU; ++u) {
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
             rsum += a[u];
         }
