@@ -86,6 +86,14 @@ __global__ void prep_lora_kernel(const float* __restrict__ a1q, const float* __r
 // delta-add on the matrix core.  D[e][rr] = sum_j Q[e][j] t[rr][j] is a K=32 product, exactly one
 // v_mfma_f32_16x16x32_bf16; t and Q are f32, so each is split into bf16 hi + lo parts and the product
 // is taken as hi*hi + hi*lo + lo*hi (error ~2^-17, i.e. f32-class, at 3 MFMAs per 16x16 tile).
+__device__ __forceinline__ void split_bf16v(const float4 a, const float4 b, bf16x8& hi, bf16x8& lo) {
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        hi[i] = f2bf(v[i]);
+        lo[i] = f2bf(v[i] - bf2f(hi[i]));
+    }
+}
 __device__ __forceinline__ void split_bf16(const float* src, bf16x8& hi, bf16x8& lo) {
     const float4 a = *reinterpret_cast<const float4*>(src);
     const float4 b = *reinterpret_cast<const float4*>(src + 4);
@@ -138,24 +146,43 @@ __global__ __launch_bounds__(256) void delta_add_kernel(bf16* qbuf, bf16* vbuf, 
 #pragma unroll
         for (int k = 0; k < DA_RG; ++k)
             cur[st][k] = *reinterpret_cast<const raw8*>(reinterpret_cast<const ST*>(base) + boff[k] + part * DA_COLS + st * 32 + 8 * g);
-    bf16x8 th[DA_RG], tl[DA_RG];
+    // ... and so are the t rows, the Q rows and the bias of BOTH 32-column steps (L2 hits): a load issued after the first step's
+    // stores would make hipcc wait with vmcnt(0), i.e. for those stores as well (gfx950 counts them in vmcnt)
+    float4 traw[DA_RG][2], qraw[NST][2][2], braw[NST][2];
 #pragma unroll
-    for (int k = 0; k < DA_RG; ++k)
-        split_bf16(t + (size_t)row_of_ref(rrk[k], B, N) * 64 + which * 32 + 8 * g, th[k], tl[k]);
+    for (int k = 0; k < DA_RG; ++k) {
+        const float* src = t + (size_t)row_of_ref(rrk[k], B, N) * 64 + which * 32 + 8 * g;
+        traw[k][0] = *reinterpret_cast<const float4*>(src); traw[k][1] = *reinterpret_cast<const float4*>(src + 4);
+    }
     const int m = c16;
+    const float* bsrc = bias ? bias : q32;                 // a valid address either way; the value is dropped without a bias
 #pragma unroll
     for (int st = 0; st < NST; ++st) {
         const int eb = part * DA_COLS + st * 32;
         const int e_t0 = eb + 8 * (m >> 2) + (m & 3);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float* src = q32 + (size_t)(e_t0 + 4 * h) * 64 + which * 32 + 8 * g;
+            qraw[st][h][0] = *reinterpret_cast<const float4*>(src); qraw[st][h][1] = *reinterpret_cast<const float4*>(src + 4);
+        }
+        braw[st][0] = *reinterpret_cast<const float4*>(bsrc + eb + 8 * g);
+        braw[st][1] = *reinterpret_cast<const float4*>(bsrc + eb + 8 * g + 4);
+    }
+    // every request above has landed before the first store goes out: an s_waitcnt the compiler SEES (it folds existing ones into
+    // its model) -- otherwise, past the first conditional store, it no longer knows which loads are complete and waits with
+    // vmcnt(0) before every further store, i.e. for the previous store
+    __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0) only
+    bf16x8 th[DA_RG], tl[DA_RG];
+#pragma unroll
+    for (int k = 0; k < DA_RG; ++k) split_bf16v(traw[k][0], traw[k][1], th[k], tl[k]);
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+        const int eb = part * DA_COLS + st * 32;
         bf16x8 q0h, q0l, q1h, q1l;
-        split_bf16(q32 + (size_t)e_t0 * 64 + which * 32 + 8 * g, q0h, q0l);
-        split_bf16(q32 + (size_t)(e_t0 + 4) * 64 + which * 32 + 8 * g, q1h, q1l);
-        float bb[8];
-        if (bias) {
-            const float4 b0 = *reinterpret_cast<const float4*>(bias + eb + 8 * g);
-            const float4 b1 = *reinterpret_cast<const float4*>(bias + eb + 8 * g + 4);
-            bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
-        } else {
+        split_bf16v(qraw[st][0][0], qraw[st][0][1], q0h, q0l);
+        split_bf16v(qraw[st][1][0], qraw[st][1][1], q1h, q1l);
+        float bb[8] = {braw[st][0].x, braw[st][0].y, braw[st][0].z, braw[st][0].w, braw[st][1].x, braw[st][1].y, braw[st][1].z, braw[st][1].w};
+        if (!bias) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) bb[i] = 0.f;
         }

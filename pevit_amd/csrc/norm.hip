@@ -3,6 +3,7 @@
 // One 64-lane wavefront per row; the row lives in registers (E <= 1024), reductions are
 // wave shuffles, every global access is a 16-byte-per-lane coalesced segment.  These kernels
 // are pure HBM streaming: ~ (4+2) B/elem forward, (4+4+4+4) B/elem backward.
+#include <type_traits>
 #include "common.h"
 #include "kernels.h"
 
@@ -20,27 +21,33 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float* xr = x + (size_t)row * xstride;
-    float4 v[MAXV];
-    float s = 0.f;
+    // Every load of the row -- x, gamma, beta -- is requested before the first reduction, and none of them sits inside a bounds
+    // branch (columns beyond E read column 0 and are masked): a value loaded inside a branch makes hipcc wait with vmcnt(0) at its
+    // first use after the join, and on gfx950 that also waits for the STORES issued so far -- the store loop below then paid one
+    // store latency per 256 columns (profiles/r03_gemm_experiments.md section 3 has the same finding for the GEMM epilogues).
+    float4 v[MAXV], gm[MAXV], bt[MAXV];
+    bool ok[MAXV];
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int c = lane * 4 + i * 256;
-        if (c < E) {
-            v[i] = *reinterpret_cast<const float4*>(xr + c);
-            s += v[i].x + v[i].y + v[i].z + v[i].w;
-        }
+        ok[i] = c < E;
+        const int cc = ok[i] ? c : 0;
+        v[i] = *reinterpret_cast<const float4*>(xr + cc);
+        gm[i] = *reinterpret_cast<const float4*>(gamma + cc);
+        bt[i] = *reinterpret_cast<const float4*>(beta + cc);
     }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) s += ok[i] ? v[i].x + v[i].y + v[i].z + v[i].w : 0.f;
     const float mean = wave_sum(s) / (float)E;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-        const int c = lane * 4 + i * 256;
-        if (c < E) {
-            const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
-            q += a * a + b * b + cc * cc + d * d;
-        }
+        const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+        q += ok[i] ? a * a + b * b + cc * cc + d * d : 0.f;
     }
     const float rstd = rsqrtf(wave_sum(q) / (float)E + 1e-5f);
+    __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0), visible to the compiler: every load is in before the first (conditional) store
     if (lane == 0) {
         if (mean_out) mean_out[row] = mean;
         if (rstd_out) rstd_out[row] = rstd;
@@ -48,9 +55,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int c = lane * 4 + i * 256;
-        if (c < E) {
-            const float4 g = *reinterpret_cast<const float4*>(gamma + c);
-            const float4 b = *reinterpret_cast<const float4*>(beta + c);
+        if (ok[i]) {
+            const float4 g = gm[i], b = bt[i];
             float4 o;
             o.x = (v[i].x - mean) * rstd * g.x + b.x;
             o.y = (v[i].y - mean) * rstd * g.y + b.y;
@@ -82,50 +88,61 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
     const float mean = mean_in[row], rstd = rstd_in[row];
     const size_t base = (size_t)row * E;          // dy rows are always compact
     const size_t xb = (size_t)row * xstride;      // x, dres, dx, dx_bf16 share the row stride
-    float4 gd[MAXV], xh[MAXV];
+    // All loads -- dy, x, gamma, the residual gradient, the fp8 channel scales -- are requested up front and none sits inside a
+    // bounds branch (columns beyond E read column 0 and are masked; a missing residual gradient reads x and the value is dropped):
+    // with the loads inside `if (c < E)` hipcc waited for each 256-column group before requesting the next (four memory round
+    // trips per row), and the residual gradient, loaded between the stores, cost a fifth plus one store latency per group.
+    float4 gd[MAXV], xh[MAXV], rs[MAXV], sc[MAXV], xv[MAXV], gv[MAXV];
+    typename std::conditional<sizeof(DYT) == 2, bf16x4, float4>::type dv[MAXV];
+    bool ok[MAXV];
+    const float* rsrc = dres ? dres : x;
+    const bool has_res = dres != nullptr;
+    const bool scaled = dx_bf16 && bscale;
+    const float* ssrc = scaled ? bscale : gamma;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane * 4 + i * 256;
+        ok[i] = c < E;
+        const int cc = ok[i] ? c : 0;
+        if constexpr (sizeof(DYT) == 2) dv[i] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(dy_) + base + cc);
+        else dv[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(dy_) + base + cc);
+        xv[i] = *reinterpret_cast<const float4*>(x + xb + cc);
+        gv[i] = *reinterpret_cast<const float4*>(gamma + cc);
+        rs[i] = *reinterpret_cast<const float4*>(rsrc + xb + cc);
+        sc[i] = *reinterpret_cast<const float4*>(ssrc + cc);
+    }
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-        const int c = lane * 4 + i * 256;
-        if (c < E) {
-            float4 d;
-            if constexpr (sizeof(DYT) == 2) {
-                const bf16x4 d4 = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(dy_) + base + c);
-                d = make_float4(bf2f(d4[0]), bf2f(d4[1]), bf2f(d4[2]), bf2f(d4[3]));
-            } else {
-                d = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(dy_) + base + c);
-            }
-            const float4 xv = *reinterpret_cast<const float4*>(x + xb + c);
-            const float4 g = *reinterpret_cast<const float4*>(gamma + c);
-            gd[i] = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
-            xh[i] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
-            s1 += gd[i].x + gd[i].y + gd[i].z + gd[i].w;
-            s2 += gd[i].x * xh[i].x + gd[i].y * xh[i].y + gd[i].z * xh[i].z + gd[i].w * xh[i].w;
-        }
+        float4 d;
+        if constexpr (sizeof(DYT) == 2) d = make_float4(bf2f(dv[i][0]), bf2f(dv[i][1]), bf2f(dv[i][2]), bf2f(dv[i][3]));
+        else d = dv[i];
+        const float4 g = gv[i];
+        gd[i] = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
+        xh[i] = make_float4((xv[i].x - mean) * rstd, (xv[i].y - mean) * rstd, (xv[i].z - mean) * rstd, (xv[i].w - mean) * rstd);
+        s1 += ok[i] ? gd[i].x + gd[i].y + gd[i].z + gd[i].w : 0.f;
+        s2 += ok[i] ? gd[i].x * xh[i].x + gd[i].y * xh[i].y + gd[i].z * xh[i].z + gd[i].w * xh[i].w : 0.f;
+        rs[i] = has_res ? rs[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        sc[i] = scaled ? sc[i] : make_float4(1.f, 1.f, 1.f, 1.f);
     }
     const float m1 = wave_sum(s1) / (float)E;
     const float m2 = wave_sum(s2) / (float)E;
+    __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0), visible to the compiler: every load is in before the first (conditional) store
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int c = lane * 4 + i * 256;
-        if (c < E) {
+        if (ok[i]) {
             float4 o;
             o.x = rstd * (gd[i].x - m1 - xh[i].x * m2);
             o.y = rstd * (gd[i].y - m1 - xh[i].y * m2);
             o.z = rstd * (gd[i].z - m1 - xh[i].z * m2);
             o.w = rstd * (gd[i].w - m1 - xh[i].w * m2);
-            if (dres) {
-                const float4 r = *reinterpret_cast<const float4*>(dres + xb + c);
-                o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
-            }
+            o.x += rs[i].x; o.y += rs[i].y; o.z += rs[i].z; o.w += rs[i].w;       // zeros without a residual gradient
             *reinterpret_cast<float4*>(dx + xb + c) = o;
             if (dx_bf16) {
                 // fp8 weights: the consuming GEMM contracts over these columns; their power-of-two channel
-                // scales are folded into its bf16 operand here (exact), the f32 stream stays unscaled
-                if (bscale) {
-                    const float4 sc = *reinterpret_cast<const float4*>(bscale + c);
-                    o.x *= sc.x; o.y *= sc.y; o.z *= sc.z; o.w *= sc.w;
-                }
+                // scales are folded into its bf16 operand here (exact: ones otherwise), the f32 stream stays unscaled
+                o.x *= sc[i].x; o.y *= sc[i].y; o.z *= sc[i].z; o.w *= sc[i].w;
                 st_store4<ST>(dx_bf16, xb + c, o.x, o.y, o.z, o.w);
             }
         }
