@@ -355,17 +355,23 @@ __global__ __launch_bounds__(256, 2) void lowrank_grad_kernel(const bf16* __rest
     const int toff = (kind == 1) ? 0 : 32;
     const int c = tid & 7;
 
+    // No load of this kernel sits inside a bounds branch: rows beyond T read row T - 1 and are zeroed by a select.  (`v = 0;
+    // if (r < T) v = load` makes hipcc drain with vmcnt(0) right behind every such request -- the 16 Y loads below were 16
+    // consecutive memory round trips; scripts/isa_serial_loads.py finds the pattern in a -S listing.)
     bf16x8 xv[LG_ROWS / 32];
     auto load_x = [&](int e0) {
 #pragma unroll
         for (int it = 0; it < LG_ROWS / 32; ++it) {
             const int r = r0 + (tid >> 3) + 32 * it;
-            xv[it] = zero_bf16x8();
-            if (r < T) {
-                const bf16* src = (kind == 0) ? xn + (size_t)r * ldx + e0 : ddelta_slab(dqkv, ld, col0, r, e0, E, H, N);
-                xv[it] = load_bf16x8(src + 8 * c);
-            }
+            const int rc = r < T ? r : T - 1;
+            const bf16* src = (kind == 0) ? xn + (size_t)rc * ldx + e0 : ddelta_slab(dqkv, ld, col0, rc, e0, E, H, N);
+            xv[it] = load_bf16x8(src + 8 * c);
         }
+    };
+    auto mask_x = [&]() {                                    // after the loads have been consumed from registers: zero the rows beyond T
+#pragma unroll
+        for (int it = 0; it < LG_ROWS / 32; ++it)
+            if (r0 + (tid >> 3) + 32 * it >= T) xv[it] = zero_bf16x8();
     };
     load_x(eg * LG_ES * 64);
     // Y (f32): kind 0 -> 64 columns of u (16 float4 per row); else 32 columns of t (8 float4 per row)
@@ -375,24 +381,21 @@ __global__ __launch_bounds__(256, 2) void lowrank_grad_kernel(const bf16* __rest
         float4 yv[16];
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
-            yv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (it < nY) {
-                const int idx = tid + 256 * it;
-                const int y = idx >> sh, c4 = idx & ((1 << sh) - 1);
-                const int r = r0 + y;
-                if (r < T) {
-                    const float* src = (kind == 0) ? u32 + (size_t)r * 64 : t + (size_t)row_of_ref(r, B, N) * 64 + toff;
-                    yv[it] = *reinterpret_cast<const float4*>(src + 4 * c4);
-                }
-            }
+            const int idx = tid + 256 * (it < nY ? it : 0);   // the rounds beyond nY repeat round 0 (L1 hits) and are not stored
+            const int y = idx >> sh, c4 = idx & ((1 << sh) - 1);
+            const int r = r0 + y, rc = r < T ? r : T - 1;
+            const float* src = (kind == 0) ? u32 + (size_t)rc * 64 : t + (size_t)row_of_ref(rc, B, N) * 64 + toff;
+            yv[it] = *reinterpret_cast<const float4*>(src + 4 * c4);
         }
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
             if (it < nY) {
                 const int idx = tid + 256 * it;
                 const int y = idx >> sh, j = 4 * (idx & ((1 << sh) - 1));
+                const bool rok = r0 + y < T;
                 bf16x4 o;
-                o[0] = f2bf(yv[it].x); o[1] = f2bf(yv[it].y); o[2] = f2bf(yv[it].z); o[3] = f2bf(yv[it].w);
+                o[0] = f2bf(rok ? yv[it].x : 0.f); o[1] = f2bf(rok ? yv[it].y : 0.f);
+                o[2] = f2bf(rok ? yv[it].z : 0.f); o[3] = f2bf(rok ? yv[it].w : 0.f);
                 *reinterpret_cast<bf16x4*>(Ys + y * LG_LD + j) = o;
             }
         }
@@ -415,6 +418,7 @@ __global__ __launch_bounds__(256, 2) void lowrank_grad_kernel(const bf16* __rest
         float colsum[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) colsum[i] = 0.f;
+        mask_x();
 #pragma unroll
         for (int it = 0; it < LG_ROWS / 32; ++it) {
             const int y = (tid >> 3) + 32 * it;
@@ -443,6 +447,9 @@ __global__ __launch_bounds__(256, 2) void lowrank_grad_kernel(const bf16* __rest
             for (int nt = 0; nt < 4; ++nt)
                 if (nt < NT) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfr[ks][nt], acc[nt], 0, 0, 0);
         }
+        // the next slab's X panel (requested above) is in before this slab's stores go out: the compiler then knows that no load
+        // is pending behind them and does not wait for the STORES when the panel is used (vmcnt counts both on gfx950)
+        __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0) only
         // C layout: col j = 16nt + c16, rows e = 16w + 4g + reg
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
