@@ -88,24 +88,54 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const bf16* __restric
     const bf16* vh = v + (size_t)bh * N * 64;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, g = lane >> 4, c16 = lane & 15;
 
-    // K and V both stay row-major (16-byte LDS writes); V^T fragments come from the transposing read (tfrag_tr)
-    for (int idx = threadIdx.x; idx < NPAD * 8; idx += 64 * NW) {
-        const int y = idx >> 3, c = idx & 7;
-        const int ys = y < N ? y : N - 1;
-        const bf16x8 kk = load_bf16x8(kh + (size_t)ys * 64 + 8 * c);
-        const bf16x8 vv = y < N ? load_bf16x8(vh + (size_t)y * 64 + 8 * c) : zero_bf16x8();
-        *reinterpret_cast<bf16x8*>(Ks + y * LDK + 8 * c) = kk;
-        *reinterpret_cast<bf16x8*>(Vs + y * LDK + 8 * c) = vv;
+    // K and V both stay row-major (16-byte LDS writes); V^T fragments come from the transposing read (tfrag_tr).
+    // One round trip to HBM for everything the first query tile needs: all K / V pieces of this thread AND its Q fragments are
+    // requested before the first LDS write, and no load sits inside a bounds branch (rows beyond N read row N - 1; V's are
+    // zeroed by a select) -- a branch around a load makes hipcc drain behind it, one round trip per piece.
+    const int nxt = (N + 15) >> 4;
+    bf16x8 qf[2];
+    {
+        const int xs0 = min(16 * wid + c16, N - 1);
+        qf[0] = rowfrag(qh, 64, xs0, 0, g);
+        qf[1] = rowfrag(qh, 64, xs0, 1, g);
+    }
+    constexpr int IT = (NPAD * 8 + 64 * NW - 1) / (64 * NW);
+    if constexpr (IT <= 4) {
+        bf16x8 kk[IT], vv[IT];
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int idx = threadIdx.x + 64 * NW * it, y = idx >> 3, c = idx & 7;
+            const int ys = y < N ? y : N - 1;
+            kk[it] = load_bf16x8(kh + (size_t)ys * 64 + 8 * c);
+            vv[it] = load_bf16x8(vh + (size_t)ys * 64 + 8 * c);
+        }
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int idx = threadIdx.x + 64 * NW * it, y = idx >> 3, c = idx & 7;
+            if (idx < NPAD * 8) {
+                *reinterpret_cast<bf16x8*>(Ks + y * LDK + 8 * c) = kk[it];
+                *reinterpret_cast<bf16x8*>(Vs + y * LDK + 8 * c) = y < N ? vv[it] : zero_bf16x8();
+            }
+        }
+    } else {
+        for (int idx = threadIdx.x; idx < NPAD * 8; idx += 64 * NW) {
+            const int y = idx >> 3, c = idx & 7;
+            const int ys = y < N ? y : N - 1;
+            const bf16x8 kk = load_bf16x8(kh + (size_t)ys * 64 + 8 * c);
+            const bf16x8 vv = load_bf16x8(vh + (size_t)ys * 64 + 8 * c);
+            *reinterpret_cast<bf16x8*>(Ks + y * LDK + 8 * c) = kk;
+            *reinterpret_cast<bf16x8*>(Vs + y * LDK + 8 * c) = y < N ? vv : zero_bf16x8();
+        }
     }
     __syncthreads();
 
-    const int nxt = (N + 15) >> 4;
     for (int xt = wid; xt < nxt; xt += NW) {
         const int xq = 16 * xt + c16;                 // this lane's query (column)
         const int xs = xq < N ? xq : N - 1;
-        bf16x8 qf[2];
-        qf[0] = rowfrag(qh, 64, xs, 0, g);
-        qf[1] = rowfrag(qh, 64, xs, 1, g);
+        if (xt != wid) {
+            qf[0] = rowfrag(qh, 64, xs, 0, g);
+            qf[1] = rowfrag(qh, 64, xs, 1, g);
+        }
         f32x4 z[2 * KT32];
         float m = -3.0e38f;
 #pragma unroll
@@ -211,22 +241,25 @@ __global__ __launch_bounds__(64 * NW, (ALL4 ? ATT_BWD_MINW : 1)) void attn_bwd_k
         // One round trip to HBM: all five tensors of both loop iterations are requested before the first LDS write;
         // delta[y] = sum_d dO[y][d] * O[y][d] (== sum_keys P*dP) comes out of the same registers.  Padded rows are zero.
         constexpr int IT = NPAD * 8 / NT;
+        // (no load inside a bounds branch: rows beyond N read row N - 1 and are zeroed by a select afterwards -- with
+        // `v = 0; if (y < N) v = load` hipcc drains behind every group of requests: one round trip per `it`, and one more for lse)
         bf16x8 vq[IT], vk[IT], vv[IT], vd[IT], vo[IT];
+        float vl[IT];
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
             const int idx = threadIdx.x + NT * it, y = idx >> 3, c = idx & 7;
-            vq[it] = zero_bf16x8(); vk[it] = zero_bf16x8(); vv[it] = zero_bf16x8(); vd[it] = zero_bf16x8(); vo[it] = zero_bf16x8();
-            if (y < N) {
-                vq[it] = load_bf16x8(qh + (size_t)y * 64 + 8 * c);
-                vk[it] = load_bf16x8(kh + (size_t)y * 64 + 8 * c);
-                vv[it] = load_bf16x8(vh + (size_t)y * 64 + 8 * c);
-                vd[it] = load_bf16x8(doh + (size_t)y * lddo + 8 * c);
-                vo[it] = load_bf16x8(oh + (size_t)y * ldo + 8 * c);
-            }
+            const int yc = y < N ? y : N - 1;
+            vq[it] = load_bf16x8(qh + (size_t)yc * 64 + 8 * c);
+            vk[it] = load_bf16x8(kh + (size_t)yc * 64 + 8 * c);
+            vv[it] = load_bf16x8(vh + (size_t)yc * 64 + 8 * c);
+            vd[it] = load_bf16x8(doh + (size_t)yc * lddo + 8 * c);
+            vo[it] = load_bf16x8(oh + (size_t)yc * ldo + 8 * c);
+            vl[it] = lse[(size_t)bh * N + yc];
         }
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
             const int idx = threadIdx.x + NT * it, y = idx >> 3, c = idx & 7;
+            if (y >= N) { vq[it] = zero_bf16x8(); vk[it] = zero_bf16x8(); vv[it] = zero_bf16x8(); vd[it] = zero_bf16x8(); vo[it] = zero_bf16x8(); vl[it] = 0.f; }
             *reinterpret_cast<bf16x8*>(Qs + y * LDR + 8 * c) = vq[it];
             *reinterpret_cast<bf16x8*>(Ks + y * LDR + 8 * c) = vk[it];
             *reinterpret_cast<bf16x8*>(Vs + y * LDR + 8 * c) = vv[it];
@@ -239,7 +272,7 @@ __global__ __launch_bounds__(64 * NW, (ALL4 ? ATT_BWD_MINW : 1)) void attn_bwd_k
             acc += __shfl_xor(acc, 4, 64);
             if (c == 0) {
                 del_s[y] = acc;
-                lse_s[y] = y < N ? lse[(size_t)bh * N + y] : 0.f;
+                lse_s[y] = vl[it];
             }
         }
     } else {
