@@ -342,25 +342,37 @@ __global__ __launch_bounds__(WGM * WGN * 64, MINW) void gemm_kernel(GemmParams p
             if (nk > 0) issue_tile(0);
         }
         float* cw = reinterpret_cast<float*>(smem + STAGE_BYTES + wid * 4096);
-        // column constants (bias; fp8: channel scale of the accumulator) of this lane's 8 columns per fragment column j, loaded
-        // ONCE: a load between the stores below would make hipcc wait with vmcnt(0), which on gfx950 waits for the stores
-        // issued so far as well
+        // column constants (bias; dGELU / fp8: channel scales) of this lane's 8 columns per fragment column j, loaded ONCE, and the
+        // per-element operand (residual, positional embedding, saved activation) requested one fragment AHEAD, both from clamped
+        // addresses: no load between two stores, none inside a bounds branch (gemm_epilogue.h, epilogue_store_full)
         float cc[WN][8], bs[WN][8];
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
-            const int col = cn0 + wn * WN * 32 + j * 32 + (lane & 3) * 8;
+            const int col = min(cn0 + wn * WN * 32 + j * 32 + (lane & 3) * 8, p.N - 8);
+            epi_cols<EPI>(p, col, cc[j]);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { cc[j][e] = 0.f; bs[j][e] = 1.f; }
-            if (col < p.N) {
-                if constexpr (epi_has_pre<EPI>) epi_load_cols<EPI>(p, col, cc[j]);
-                if constexpr (BF8) {
-                    if (p.bscale) {
-                        const float4 b0 = *reinterpret_cast<const float4*>(p.bscale + col), b1 = *reinterpret_cast<const float4*>(p.bscale + col + 4);
-                        bs[j][0] = b0.x; bs[j][1] = b0.y; bs[j][2] = b0.z; bs[j][3] = b0.w; bs[j][4] = b1.x; bs[j][5] = b1.y; bs[j][6] = b1.z; bs[j][7] = b1.w;
-                    }
+            for (int e = 0; e < 8; ++e) bs[j][e] = 1.f;
+            if constexpr (BF8) {
+                if (p.bscale) {
+                    const float4 b0 = *reinterpret_cast<const float4*>(p.bscale + col), b1 = *reinterpret_cast<const float4*>(p.bscale + col + 4);
+                    bs[j][0] = b0.x; bs[j][1] = b0.y; bs[j][2] = b0.z; bs[j][3] = b0.w; bs[j][4] = b1.x; bs[j][5] = b1.y; bs[j][6] = b1.z; bs[j][7] = b1.w;
                 }
             }
         }
+        constexpr bool OPND = epi_reads_resid<EPI> || epi_reads_aux<EPI>;
+        EpiOperand opc[2], opn[2];
+        auto prefetch = [&](int f, EpiOperand (&o)[2]) {
+            if constexpr (OPND) {
+                const int i = f / WN, j = f - i * WN;
+#pragma unroll
+                for (int pass = 0; pass < 2; ++pass) {
+                    const int row = min(cm0 + wm * WM * 32 + i * 32 + pass * 16 + (lane >> 2), p.M - 1);
+                    const int col = min(cn0 + wn * WN * 32 + j * 32 + (lane & 3) * 8, p.N - 8);
+                    epi_prefetch<EPI, bf16>(p, row, col, o[pass]);
+                }
+            }
+        };
+        prefetch(0, opc);
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -370,6 +382,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, MINW) void gemm_kernel(GemmParams p
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     cw[row * 32 + (lane & 31)] = acc[i][j][r];
                 }
+                if (i * WN + j + 1 < WM * WN) prefetch(i * WN + j + 1, opn);      // before this fragment's stores
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
@@ -380,18 +393,16 @@ __global__ __launch_bounds__(WGM * WGN * 64, MINW) void gemm_kernel(GemmParams p
                     const int col = cn0 + wn * WN * 32 + j * 32 + lc;
                     const float4 x0 = *reinterpret_cast<const float4*>(cw + lr * 32 + lc);
                     const float4 x1 = *reinterpret_cast<const float4*>(cw + lr * 32 + lc + 4);
-                    if (row < p.M && col < p.N && !GEMM_DBG(p, 2)) {
-                        float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-                        if constexpr (BF8) {
+                    float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                    if constexpr (BF8) {
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] *= bs[j][e];
-                        }
-                        if constexpr (epi_has_pre<EPI> && !epi_reads_aux<EPI>) epilogue_store_pre<EPI, bf16>(p, row, col, v, cc[j], cc[j]);
-                        else epilogue_store<EPI, bf16>(p, row, col, v);
+                        for (int e = 0; e < 8; ++e) v[e] *= bs[j][e];
                     }
+                    if (row < p.M && col < p.N && !GEMM_DBG(p, 2)) epilogue_store_full<EPI, bf16>(p, row, col, v, cc[j], opc[pass]);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if constexpr (OPND) { opc[0] = opn[0]; opc[1] = opn[1]; }
             }
         if (next >= ntiles) break;
         tile = next;

@@ -221,3 +221,90 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int row, int
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Load-free form of EVERY epilogue, for kernels that walk a tile fragment by fragment (gemm_kernel): the per-column
+// constants (epi_cols: bias / channel scale) are loaded once per tile, the per-element operand (f32 residual, positional
+// embedding, saved activation) is requested one fragment AHEAD from clamped addresses (epi_prefetch) -- so no load sits between
+// two stores or inside a bounds branch, and every s_waitcnt hipcc places is an exact vmcnt(N) over loads that are OLDER than the
+// stores in flight.  (A load issued after a store is only consumed once that store has been acknowledged: gfx950 counts both
+// in vmcnt, in order.  On these tiles that was one store latency per 16-row pass.)
+template <int EPI> constexpr bool epi_reads_resid = (EPI == EPI_BIAS_RESID_F32 || EPI == EPI_BIAS_RESID_KEEP || EPI == EPI_PATCH_EMBED);
+template <int EPI> constexpr bool epi_has_bias = (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID_F32 || EPI == EPI_BIAS_RESID_KEEP ||
+                                                  EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELUNEW || EPI == EPI_BIAS_RELU_BF16);
+struct EpiOperand { float4 r0, r1; bf16x8 a; };
+
+// column constants of columns col..col+7 (col < N): bias where the epilogue has one, the dGELU channel scale, else unused
+template <int EPI>
+__device__ __forceinline__ void epi_cols(const GemmParams& p, int col, float c[8]) {
+    if constexpr (epi_has_pre<EPI>) epi_load_cols<EPI>(p, col, c);
+    else if constexpr (epi_has_bias<EPI>) {
+        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + col), b1 = *reinterpret_cast<const float4*>(p.bias + col + 4);
+        c[0] = b0.x; c[1] = b0.y; c[2] = b0.z; c[3] = b0.w; c[4] = b1.x; c[5] = b1.y; c[6] = b1.z; c[7] = b1.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) c[i] = 0.f;
+    }
+}
+
+// the per-element operand at (row, col), both already clamped into the matrix: unconditional loads
+template <int EPI, typename ST>
+__device__ __forceinline__ void epi_prefetch(const GemmParams& p, int row, int col, EpiOperand& o) {
+    if constexpr (EPI == EPI_PATCH_EMBED) {
+        const int G2 = p.Ntok - 1;
+        const int g = row - (row / G2) * G2;
+        const float* src = p.resid + (size_t)(1 + g) * p.ldr + col;
+        o.r0 = *reinterpret_cast<const float4*>(src); o.r1 = *reinterpret_cast<const float4*>(src + 4);
+    } else if constexpr (epi_reads_resid<EPI>) {
+        const float* src = p.resid + (size_t)row * p.ldr + col;
+        o.r0 = *reinterpret_cast<const float4*>(src); o.r1 = *reinterpret_cast<const float4*>(src + 4);
+    } else if constexpr (epi_reads_aux<EPI>) {
+        static_assert(sizeof(ST) == 2, "bf16 activation storage");
+        o.a = load_bf16x8(p.aux + (size_t)row * p.ldaux + col);
+    }
+}
+
+// row < M and col < N (col multiple of 8) are guaranteed by the caller; c = epi_cols, o = epi_prefetch of this position
+template <int EPI, typename ST>
+__device__ __forceinline__ void epilogue_store_full(const GemmParams& p, int row, int col, float v[8], const float c[8], const EpiOperand& o) {
+    if constexpr (EPI == EPI_QKV_HEADS || EPI == EPI_BIAS_GELU) {
+        epilogue_store_pre<EPI, ST>(p, row, col, v, c, c);
+    } else if constexpr (epi_reads_aux<EPI>) {
+        float h[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) h[i] = bf2f(o.a[i]);
+        if constexpr (EPI == EPI_DGELU_BF16) epilogue_store_pre<EPI, ST>(p, row, col, v, c, h);
+        else epilogue_store_aux<EPI, ST>(p, row, col, v, h);
+    } else if constexpr (EPI == EPI_BIAS_RESID_F32 || EPI == EPI_BIAS_RESID_KEEP) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] += c[i];
+        if constexpr (EPI == EPI_BIAS_RESID_KEEP) store8f(p.outf2 + (size_t)row * p.ldo2 + col, v);
+        v[0] += o.r0.x; v[1] += o.r0.y; v[2] += o.r0.z; v[3] += o.r0.w; v[4] += o.r1.x; v[5] += o.r1.y; v[6] += o.r1.z; v[7] += o.r1.w;
+        store8f(p.outf + (size_t)row * p.ldo + col, v);
+    } else if constexpr (EPI == EPI_PATCH_EMBED) {
+        const int G2 = p.Ntok - 1;
+        const int b = row / G2, g = row - b * G2;
+        v[0] += o.r0.x; v[1] += o.r0.y; v[2] += o.r0.z; v[3] += o.r0.w; v[4] += o.r1.x; v[5] += o.r1.y; v[6] += o.r1.z; v[7] += o.r1.w;
+        store8f(p.outf + ((size_t)b * p.Ntok + 1 + g) * p.ldo + col, v);
+    } else if constexpr (EPI == EPI_F32) {
+        store8f(p.outf + (size_t)row * p.ldo + col, v);
+    } else if constexpr (EPI == EPI_BF16) {
+        store8s<ST>(p.outb, (size_t)row * p.ldob + col, v);
+    } else if constexpr (EPI == EPI_BIAS_BF16) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] += c[i];
+        store8s<ST>(p.outb, (size_t)row * p.ldob + col, v);
+    } else if constexpr (EPI == EPI_BIAS_GELUNEW) {
+        float g[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            v[i] = as_stored<ST>(v[i] + c[i]);
+            g[i] = gelu_new_f(v[i]);
+        }
+        store8s<ST>(p.outb, (size_t)row * p.ldob + col, v);
+        store8s<ST>(p.outb2, (size_t)row * p.ldob2 + col, g);
+    } else if constexpr (EPI == EPI_BIAS_RELU_BF16) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i] + c[i], 0.0f);
+        store8s<ST>(p.outb, (size_t)row * p.ldob + col, v);
+    }
+}

@@ -183,7 +183,7 @@ def _engines(arch_name, method, B, classes=10, lora_r=4, seed=2):
             v["layers.0.weight"].copy_(hw); v["layers.0.bias"].copy_(hb)
         # bit identity needs the same summation split on both sides: the stream-K and k-split forms of the few-tile long-K
         # products exist for bf16 weights only (the fp8 products keep the plain tiling), so they are switched off here
-        e.tune("gemm_streamk", 0); e.tune("gemm_ksplit", 0)
+        e.tune("gemm_streamk", 0); e.tune("gemm_ksplit", 0); e.tune("gemm_skinny", 0)
     return arch, e8, e16, sdq, hw, hb
 
 
