@@ -185,66 +185,75 @@ __global__ __launch_bounds__(64 * LNA_WAVES) void ln_bwd_affine_kernel(const flo
     for (int i = 0; i < LNA_MAXV; ++i) {
         ag[i] = make_float4(0.f, 0.f, 0.f, 0.f); ab[i] = make_float4(0.f, 0.f, 0.f, 0.f); ar[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    // a wave walks its LNA_ROWS / LNA_WAVES rows with the NEXT row's operands already requested: processed one after the other
-    // each row paid a full HBM round trip before its reductions could start (27.8 us for 88 MB in step; with the next row in
-    // flight the kernel is bound by the bytes)
+    // A wave walks its LNA_ROWS / LNA_WAVES rows with the NEXT row's operands already requested (processed one after the other
+    // each row paid a full HBM round trip before its reductions could start: 27.8 us for 88 MB in step).  The walk is unrolled and
+    // no load sits inside a bounds branch: rows beyond `rows` / columns beyond E read a clamped address and are masked, gamma is
+    // loaded once, the next row's mean / rstd travel with its operands, and the next row is IN before this row's (conditional)
+    // stores go out -- otherwise hipcc waits with vmcnt(0) at the next use, which on gfx950 also waits for those stores.
+    constexpr int RPW = LNA_ROWS / LNA_WAVES;
+    const float* rsrc = dres ? dres : x;
+    const bool has_res = dres != nullptr;
+    bool cok[LNA_MAXV];
+    int cc[LNA_MAXV];
+    float4 gv[LNA_MAXV];
+#pragma unroll
+    for (int i = 0; i < LNA_MAXV; ++i) {
+        const int c = lane * 4 + i * 256;
+        cok[i] = c < E; cc[i] = cok[i] ? c : 0;
+        gv[i] = *reinterpret_cast<const float4*>(gamma + cc[i]);
+    }
     float4 nd[LNA_MAXV], nx[LNA_MAXV], nr[LNA_MAXV];
-    auto request = [&](int row) {
+    float nmean, nrstd;
+    auto request = [&](int row) {                 // row already clamped into [0, rows)
         const size_t base = (size_t)row * E;
 #pragma unroll
         for (int i = 0; i < LNA_MAXV; ++i) {
-            const int c = lane * 4 + i * 256;
-            nd[i] = nx[i] = nr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (c < E) {
-                nd[i] = *reinterpret_cast<const float4*>(dy + base + c);
-                nx[i] = *reinterpret_cast<const float4*>(x + base + c);
-                if (dres) nr[i] = *reinterpret_cast<const float4*>(dres + base + c);
-            }
+            nd[i] = *reinterpret_cast<const float4*>(dy + base + cc[i]);
+            nx[i] = *reinterpret_cast<const float4*>(x + base + cc[i]);
+            nr[i] = *reinterpret_cast<const float4*>(rsrc + base + cc[i]);
         }
+        nmean = mean_in[row]; nrstd = rstd_in[row];
     };
-    {
-        const int row0 = blockIdx.x * LNA_ROWS + wid;
-        if (row0 < rows) request(row0);
-    }
-    for (int rr = wid; rr < LNA_ROWS; rr += LNA_WAVES) {
-        const int row = blockIdx.x * LNA_ROWS + rr;
-        if (row >= rows) break;
-        const float mean = mean_in[row], rstd = rstd_in[row];
+    const int row_first = blockIdx.x * LNA_ROWS + wid;
+    request(min(row_first, rows - 1));
+#pragma unroll
+    for (int k = 0; k < RPW; ++k) {
+        const int row = row_first + k * LNA_WAVES;
+        const bool rok = row < rows;
+        const float mean = nmean, rstd = nrstd;
         const size_t base = (size_t)row * E;
         float4 cd[LNA_MAXV], cx[LNA_MAXV], cr[LNA_MAXV];
 #pragma unroll
-        for (int i = 0; i < LNA_MAXV; ++i) { cd[i] = nd[i]; cx[i] = nx[i]; cr[i] = nr[i]; }
-        if (rr + LNA_WAVES < LNA_ROWS && row + LNA_WAVES < rows) request(row + LNA_WAVES);
+        for (int i = 0; i < LNA_MAXV; ++i) { cd[i] = nd[i]; cx[i] = nx[i]; cr[i] = has_res ? nr[i] : make_float4(0.f, 0.f, 0.f, 0.f); }
+        if (k + 1 < RPW) request(min(row + LNA_WAVES, rows - 1));
         float4 gd[LNA_MAXV], xh[LNA_MAXV];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < LNA_MAXV; ++i) {
-            const int c = lane * 4 + i * 256;
-            if (c < E) {
-                const float4 d = cd[i];
-                const float4 xv = cx[i];
-                const float4 g = *reinterpret_cast<const float4*>(gamma + c);
-                xh[i] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+            const bool on = rok && cok[i];
+            const float4 d = cd[i];
+            const float4 xv = cx[i];
+            const float4 g = gv[i];
+            xh[i] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+            if (on) {
                 ag[i].x += d.x * xh[i].x; ag[i].y += d.y * xh[i].y; ag[i].z += d.z * xh[i].z; ag[i].w += d.w * xh[i].w;
                 ab[i].x += d.x; ab[i].y += d.y; ab[i].z += d.z; ab[i].w += d.w;
-                gd[i] = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
-                s1 += gd[i].x + gd[i].y + gd[i].z + gd[i].w;
-                s2 += gd[i].x * xh[i].x + gd[i].y * xh[i].y + gd[i].z * xh[i].z + gd[i].w * xh[i].w;
+                ar[i].x += cr[i].x; ar[i].y += cr[i].y; ar[i].z += cr[i].z; ar[i].w += cr[i].w;
             }
+            gd[i] = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
+            s1 += cok[i] ? gd[i].x + gd[i].y + gd[i].z + gd[i].w : 0.f;
+            s2 += cok[i] ? gd[i].x * xh[i].x + gd[i].y * xh[i].y + gd[i].z * xh[i].z + gd[i].w * xh[i].w : 0.f;
         }
         const float m1 = wave_sum(s1) / (float)E, m2 = wave_sum(s2) / (float)E;
+        __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0), visible to the compiler: the next row is in, nothing is pending behind the stores
 #pragma unroll
         for (int i = 0; i < LNA_MAXV; ++i) {
-            const int c = lane * 4 + i * 256;
-            if (c < E) {
+            if (rok && cok[i]) {
+                const int c = lane * 4 + i * 256;
                 float4 o;
                 o.x = rstd * (gd[i].x - m1 - xh[i].x * m2); o.y = rstd * (gd[i].y - m1 - xh[i].y * m2);
                 o.z = rstd * (gd[i].z - m1 - xh[i].z * m2); o.w = rstd * (gd[i].w - m1 - xh[i].w * m2);
-                if (dres) {
-                    const float4 r = cr[i];
-                    o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
-                    ar[i].x += r.x; ar[i].y += r.y; ar[i].z += r.z; ar[i].w += r.w;
-                }
+                o.x += cr[i].x; o.y += cr[i].y; o.z += cr[i].z; o.w += cr[i].w;
                 *reinterpret_cast<float4*>(dx + base + c) = o;
                 if (dx_bf16) st_store4<ST>(dx_bf16, base + c, o.x, o.y, o.z, o.w);
             }

@@ -227,15 +227,23 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(SmallGemm p) {
     }
     __syncthreads();
     if (wid != 0) return;
+    // the bias and (when accumulating) all 16 old values are requested before the first store, from clamped addresses: loaded one
+    // by one inside the bounds branch they were 16 consecutive load -> wait -> store round trips
+    const float* bsrc = p.bias ? p.bias : p.C;
+    const float bv0 = bsrc[jok ? j : 0];
+    const float bv = p.bias ? bv0 : 0.f;
+    float old[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int oi = min(i0 + (r & 3) + 8 * (r >> 2) + 4 * lk, p.M - 1);
+        old[r] = p.C[(long)oi * p.ldc + (jok ? j : 0)];
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0), visible to the compiler: nothing is pending behind the stores below
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const float v = acc[r] + red[0][lane][r] + red[1][lane][r] + red[2][lane][r];
         const int oi = i0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (oi < p.M && jok) {
-            float* c = p.C + (long)oi * p.ldc + j;
-            const float bv = p.bias ? p.bias[j] : 0.f;
-            *c = (p.accumulate ? *c : 0.f) + v + bv;
-        }
+        if (oi < p.M && jok) p.C[(long)oi * p.ldc + j] = (p.accumulate ? old[r] : 0.f) + v + bv;
     }
     if (p.rowsumA && blockIdx.x == 0) {
         rsum += rs[0][lane] + rs[1][lane] + rs[2][lane];

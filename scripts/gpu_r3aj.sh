@@ -1,0 +1,8 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
+mkdir -p gpurun_out
+J='import sys,json; d=json.loads(sys.stdin.readline()); r=d["roofline"]; print(sys.argv[1], round(d["value"],1), round(d["ms_per_step"],3), "gemm ms", round(r.get("gemm_ms_per_step",0),3))'
+echo "== ops tests"; timeout 1500 python -m pytest tests/test_gpu_ops.py tests/test_gpu_ops2.py tests/test_gpu_adapters.py -x -q -m gpu 2>&1 | tail -4
+echo "== methods"
+for m in kadaptation adapter compacter; do timeout 600 python bench.py --method $m --steps 50 --warmup 10 --no-cpu-baseline 2>/dev/null | python -c "$J" "$m"; done
+echo "== adapter kstats"; KSTATS_LINES=60 bash scripts/gpu_kstats.sh r3aj_adapter --method adapter | grep -E "ln_bwd_affine|small_gemm|tn_gemm|total|colsum" | cut -c1-150
