@@ -632,7 +632,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmParams p, int ntiles)
         // 78 MB in step (profiles/r03_gemm_epilogues.md).
         constexpr int COLS = WN * 32, LPR = COLS / 8, RPASS = 64 / LPR, NPASS = 32 / RPASS;   // lanes per row, rows per pass, passes
         float* cw = reinterpret_cast<float*>(smem + STAGE_BYTES + wid * (32 * COLS * 4));
-        static_assert(STAGE_BYTES >= NW * 32 * COLS * 4, "the epilogue borrows 32 x COLS floats per wave of stage 1");
+        // 32 x COLS floats per wave behind stage 0: stage 1, and beyond it where a stage is smaller than that (launch_big8 sizes the LDS)
         const int erow = lane / LPR, ec8 = lane % LPR;                 // pass-local row, 8-column group of this lane
         const int gr0 = cm0 + wm * WM * 32, gc0 = cn0 + wn * WN * 32, gc = gc0 + ec8 * 8;
         auto to_lds = [&](int i) {
@@ -1739,7 +1739,8 @@ int use_ksplit(const GemmParams& p, const GemmTune& t, int cfg) {
 // the staggered 8-wave kernel: 256x256 (configuration 4) and 320x256 (5), bf16 B, operands addressable with 31-bit byte offsets
 template <int EPI, int WGM, int WGN, int WM, int WN, int KSP, int OPS>
 int launch_big8(const GemmParams& p, const GemmTune& t, hipStream_t stream) {
-    constexpr int bm = WGM * WM * 32, bn = WGN * WN * 32, lds = 2 * (bm + bn) * 128;
+    constexpr int bm = WGM * WM * 32, bn = WGN * WN * 32, stage = (bm + bn) * 128, scratch = 8 * 32 * WN * 32 * 4;
+    constexpr int lds = stage + (stage > scratch ? stage : scratch);
     auto kern = gemm8_kernel<EPI, WGM, WGN, WM, WN, KSP, OPS>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -1778,6 +1779,7 @@ int launch_epi(const GemmParams& p, const GemmTune& t, hipStream_t stream) {
         if (cfg == 5) return launch_big8<EPI, 2, 4, 5, 2, 1, BF8 ? 1 : 0>(p, t, stream);
         if (cfg == 4) return launch_big8<EPI, 2, 4, 4, 2, 1, BF8 ? 1 : 0>(p, t, stream);
         if (cfg == CFG_160x256) return launch_big8<EPI, 1, 8, 5, 1, 1, BF8 ? 1 : 0>(p, t, stream);
+        if (cfg == 3 && t.stagger >= 2) return launch_big8<EPI, 4, 2, 2, 2, 2, BF8 ? 1 : 0>(p, t, stream);   // 256x128, two k-steps per phase (measurement)
     }
     if constexpr (!BF8 && (EPI == EPI_BIAS_RESID_F32 || EPI == EPI_F32 || EPI == EPI_BF16 || EPI == EPI_BIAS_RESID_KEEP || EPI == EPI_PATCH_EMBED)) {
         const int kwm = use_ksplit(p, t, cfg);

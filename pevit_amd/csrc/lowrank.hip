@@ -474,16 +474,24 @@ __global__ void lowrank_reduce_kernel(const float* __restrict__ partial, const f
     const int total = 4 * E * 32, l = blockIdx.y;
     partial += (size_t)l * partial_layer;
     if (idx < total) {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;     // fixed summation tree: deterministic
+        // fixed summation tree: deterministic.  Eight chunks per round (one memory round trip each: 25 chunks = 4 trips, not 7)
+        float sacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         int c = 0;
-        for (; c + 3 < chunks; c += 4) {
-            s0 += partial[(size_t)c * total + idx];
-            s1 += partial[(size_t)(c + 1) * total + idx];
-            s2 += partial[(size_t)(c + 2) * total + idx];
-            s3 += partial[(size_t)(c + 3) * total + idx];
+        for (; c + 7 < chunks; c += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(c + u) * total + idx];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sacc[u] += v[u];
         }
-        for (; c < chunks; ++c) s0 += partial[(size_t)c * total + idx];
-        G[(size_t)l * total + idx] = (s0 + s1) + (s2 + s3);
+        {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)min(c + u, chunks - 1) * total + idx];    // clamped: no load inside a branch
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sacc[u] += (c + u < chunks) ? v[u] : 0.f;
+        }
+        G[(size_t)l * total + idx] = ((sacc[0] + sacc[1]) + (sacc[2] + sacc[3])) + ((sacc[4] + sacc[5]) + (sacc[6] + sacc[7]));
     }
     if (g_b && idx < E) {
         const float* db = dbias_partial + (size_t)l * dbias_layer;

@@ -1,0 +1,6 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
+mkdir -p gpurun_out
+echo "== all gpu tests"; timeout 2400 python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3
+echo "== pmc passes"; bash scripts/run_pmc_passes.sh r03 2>&1 | tail -12 | cut -c1-1200
+echo "== batch 64 line"; timeout 300 python bench.py --batch 64 --no-cpu-baseline 2>/dev/null | tee gpurun_out/r3_bench_b64.json | cut -c1-300
