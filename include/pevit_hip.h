@@ -244,7 +244,12 @@ int pevit_op_im2col(void* stream, const float* images, void* patches_bf16, int B
  * "gemm_cfg_shortk" (configuration of the few-tile problems above / below kswitch), "gemm_ablate" (bit 0 skips the
  * k-loop, bit 1 the epilogue stores, bit 2 the operand stream, bit 3 ds_read + MFMA), "side_stream" (ctx only),
  * "gemm_streamk" (0 = never use the stream-K decomposition of the few-tile long-K products), "gemm_ksplit" (0 = never
- * use the 160x128 tile whose two wave groups take alternate k-tiles);
+ * use the one-tile-per-CU 160x128 / 96x128 k-split tile of the N = E products; 2 = also on problems of several rounds),
+ * "gemm_ksplit_stagger" (2 = phased kernel, default; 1 / 0 = the alternate-k-tile kernel with / without the half-iteration
+ * offset), "gemm_ksplit_small", "gemm_ksplit_mink", "gemm_kphase_nl" (requests in the LOAD section: 8, or between the
+ * MFMAs: 2), "gemm_stagger" (0 = legacy 8-wave kernel, 1 = staggered, 2 = also the 256x128 tile), "gemm_band",
+ * "gemm_skinny" (0 = never use the few-row split-K kernel), "gemm_skinny_maxm" / "_mink" / "_slices", "gemm_sk_share" /
+ * "gemm_sk_band" (with gemm_streamk = 2), "lowrank_xcd", "fused_bottleneck" and "dx_stored" (ctx only);
  * returns 0, or -1 for an unknown key */
 int pevit_tune(pevit_ctx* ctx, const char* key, int value);
 
