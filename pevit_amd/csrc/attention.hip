@@ -100,7 +100,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const bf16* __restric
         qf[1] = rowfrag(qh, 64, xs0, 1, g);
     }
     constexpr int IT = (NPAD * 8 + 64 * NW - 1) / (64 * NW);
-    if constexpr (IT <= 4) {
+    if constexpr (IT <= 6) {
         bf16x8 kk[IT], vv[IT];
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
@@ -194,12 +194,24 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const bf16* __restric
 
 // ------------------------------------------------------------------------------------
 // rows [0, NPAD) of a row-major LDS tile <- src rows (stride elements apart), zero beyond N; 16-byte loads and writes
+// Four pieces per thread are requested before the first LDS write and none inside a bounds branch (rows beyond N read row N - 1
+// and are zeroed by a select): with `v = 0; if (y < N) v = load` hipcc drains behind every request, one round trip per piece.
 __device__ __forceinline__ void stage_rows(bf16* dst, int LDR, const bf16* src, size_t stride, int N, int NPAD) {
-    for (int idx = threadIdx.x; idx < NPAD * 8; idx += blockDim.x) {
-        const int y = idx >> 3, c = idx & 7;
-        bf16x8 v = zero_bf16x8();
-        if (y < N) v = load_bf16x8(src + (size_t)y * stride + 8 * c);
-        *reinterpret_cast<bf16x8*>(dst + y * LDR + 8 * c) = v;
+    const int total = NPAD * 8, step = blockDim.x;
+    for (int idx0 = threadIdx.x; idx0 < total; idx0 += 4 * step) {
+        bf16x8 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = min(idx0 + u * step, total - 1);
+            const int y = idx >> 3, c = idx & 7;
+            v[u] = load_bf16x8(src + (size_t)min(y, N - 1) * stride + 8 * c);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = idx0 + u * step;
+            const int y = idx >> 3, c = idx & 7;
+            if (idx < total) *reinterpret_cast<bf16x8*>(dst + y * LDR + 8 * c) = y < N ? v[u] : zero_bf16x8();
+        }
     }
 }
 
@@ -279,21 +291,31 @@ __global__ __launch_bounds__(64 * NW, (ALL4 ? ATT_BWD_MINW : 1)) void attn_bwd_k
         stage_rows(Ks, LDR, kh, 64, N, NPAD);
         stage_rows(Vs, LDR, vh, 64, N, NPAD);
         // delta[y] = sum_d dO[y][d] * O[y][d]   (== sum_keys P*dP), 8 lanes per row
-        for (int idx = threadIdx.x; idx < NPAD * 8; idx += NT) {
-            const int y = idx >> 3, c = idx & 7;
-            float acc = 0.f;
-            if (y < N) {
-                const bf16x8 a = load_bf16x8(doh + (size_t)y * lddo + 8 * c);
-                const bf16x8 o = load_bf16x8(oh + (size_t)y * ldo + 8 * c);
+        for (int idx0 = threadIdx.x; idx0 < NPAD * 8; idx0 += 2 * NT) {     // two pieces per round, clamped rows, no load in a branch
+            bf16x8 a[2], o[2];
+            float ls[2];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) acc += bf2f(a[i]) * bf2f(o[i]);
+            for (int u = 0; u < 2; ++u) {
+                const int idx = min(idx0 + u * NT, NPAD * 8 - 1);
+                const int y = min(idx >> 3, N - 1), c = idx & 7;
+                a[u] = load_bf16x8(doh + (size_t)y * lddo + 8 * c);
+                o[u] = load_bf16x8(oh + (size_t)y * ldo + 8 * c);
+                ls[u] = lse[(size_t)bh * N + y];
             }
-            acc += __shfl_xor(acc, 1, 64);
-            acc += __shfl_xor(acc, 2, 64);
-            acc += __shfl_xor(acc, 4, 64);
-            if (c == 0) {
-                del_s[y] = acc;
-                lse_s[y] = y < N ? lse[(size_t)bh * N + y] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int idx = idx0 + u * NT;
+                const int y = idx >> 3, c = idx & 7;
+                float acc = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc += bf2f(a[u][i]) * bf2f(o[u][i]);
+                acc += __shfl_xor(acc, 1, 64);
+                acc += __shfl_xor(acc, 2, 64);
+                acc += __shfl_xor(acc, 4, 64);
+                if (c == 0 && idx < NPAD * 8) {
+                    del_s[y] = y < N ? acc : 0.f;
+                    lse_s[y] = y < N ? ls[u] : 0.f;
+                }
             }
         }
     }
