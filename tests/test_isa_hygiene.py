@@ -60,7 +60,8 @@ CASES = [
     ("norm", "ln_fwd_kernelIDF16b", 0, 0, 0),
     ("norm", "ln_bwd_kernelIDF16bDF16b", 1, 0, 0),
     ("lowrank", "delta_add_kernelIDF16b", 0, 0, 0),
-XX
+    # the next slab's X panel is requested between two slabs' stores, and the one explicit vmcnt(0) that brings it in sits there too
+    ("lowrank", "lowrank_grad_kernel", 0, 1, 8),
     ("attention", "attn_fwd_kernelILi2ELi4E", 0, 0, 0),
     ("attention", "attn_bwd_kernelILi2ELb1ELi4E", 0, 0, 0),
 ]
