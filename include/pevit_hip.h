@@ -259,6 +259,11 @@ int pevit_tune(pevit_ctx* ctx, const char* key, int value);
  * entry points) and clears the word, 0 otherwise, -1 on a HIP error.  The reference has no counterpart (its GEMMs are
  * ATen calls, model.py:675,817); the engine checks it after the first step. */
 int pevit_streamk_error(pevit_ctx* ctx, void* stream);
+/* The same word WITHOUT clearing it, and the number of optimizer updates pevit_sgd_step has withheld on device since the word
+ * was raised (the fused SGD kernel leaves parameters and momentum untouched while it is non-zero, so a corrupted tile never
+ * reaches them).  The word stays raised -- and every further update withheld -- until pevit_streamk_error clears it: a caller
+ * that swallows the error cannot silently train on. */
+int pevit_streamk_status(pevit_ctx* ctx, void* stream, unsigned* error_word, unsigned* skipped_updates);
 
 #ifdef __cplusplus
 }

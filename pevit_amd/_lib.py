@@ -88,6 +88,7 @@ SIGNATURES = {
     "pevit_op_im2col": (c_int, [P, P, P, c_int, c_int, c_int, c_int]),
     "pevit_tune": (c_int, [P, c_char_p, c_int]),
     "pevit_streamk_error": (c_int, [P, P]),
+    "pevit_streamk_status": (c_int, [P, P, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
 }
 
 _lib = None

@@ -108,6 +108,7 @@ struct pevit_ctx {
     int dx_stored = 1;        // dX GEMMs hand the LN-input gradient to LayerNorm backward in the activation storage type (bf16)
     int fused_bn = 0;         // post-MLP adapters: down -> activation -> up (and its backward) as one launch each (adapter.hip
                               // bottleneck_pair_kernel): 24.4 + 22.1 us against 22.9 + 19.5 us for the four GEMM launches -- opt-in
+    int lowrank_xcd = 1;      // lowrank_grad: XCD-contiguous workgroup order (+0.2 % per step)
     int side_stream = 0;      // adapter-gradient contractions on a second stream: +0.5 % step throughput, but it slows the GEMMs
                               // it overlaps by 4 %, which blurs the per-kernel roofline measurement: off by default
 };
@@ -124,7 +125,7 @@ void layout_workspace(pevit_ctx* c, int B, LayerSaved* sav, size_t* total, pevit
     const size_t T = (size_t)B * c->N, E = c->E, es = c->es;
     size_t o;
     // stream-K hand-off flags (+1 error word) and partial-tile slabs: first, so that their place does not depend on the batch
-    o = cv.take((size_t)(PEVIT_SK_MAX_SLOTS + 1) * 4);                        if (fill) fill->w_skflag = o;
+    o = cv.take((size_t)(PEVIT_SK_MAX_SLOTS + 2) * 4);                        if (fill) fill->w_skflag = o;   // + error word + skipped-update counter
     o = cv.take((size_t)c->sk_slots * PEVIT_SK_SLAB_FLOATS * 4);              if (fill) fill->w_skslab = o;
     for (int l = 0; l < c->L; ++l) {
         LayerSaved s;
@@ -369,7 +370,7 @@ extern "C" int pevit_bind(pevit_ctx* c, void* arena, size_t arena_bytes, void* w
     if (((uintptr_t)arena | (uintptr_t)ws) & 255) { pevit_set_error("bind: buffers must be 256-byte aligned"); return -1; }
     c->arena = (char*)arena; c->ws = (char*)ws; c->max_batch = max_batch; c->ws_bytes_for_max = need;
     // the stream-K flags must read 0 before the first launch (every launch leaves them 0 again)
-    HIP_OK(hipMemset(c->ws, 0, (size_t)(PEVIT_SK_MAX_SLOTS + 1) * 4));
+    HIP_OK(hipMemset(c->ws, 0, (size_t)(PEVIT_SK_MAX_SLOTS + 2) * 4));
     return 0;
 }
 
@@ -411,7 +412,7 @@ extern "C" int pevit_load_block(pevit_ctx* c, void* stream, int l, const float* 
         CHECK(pevit_launch_quant_transpose_fp8(pr_w, e, 4 * e, at<float>(A, b.spr), at<u8>(A, b.wprT), e, 0, 1.0f, s));
         // QKV backward (bf16): the transposed copy holds the DE-QUANTISED weights, exactly representable in bf16
         HIP_OK(hipMemsetAsync(A + b.wqkvT, 0, E * (size_t)c->NQ * 2, s));
-        const size_t skip = align_up((size_t)(PEVIT_SK_MAX_SLOTS + 1) * 4, 256);    // the stream-K flags stay zero
+        const size_t skip = align_up((size_t)(PEVIT_SK_MAX_SLOTS + 2) * 4, 256);    // the stream-K flags stay zero
         // 3E*E floats of the bound workspace serve as packing scratch: whatever activations a previous forward saved there
         // are overwritten, so a backward through them is refused from here on (saved_batch = 0), and the load must be
         // issued on the stream the engine trains on (include/pevit_hip.h: one stream per context)
@@ -799,7 +800,7 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0, bool cls_
             else
                 CHECK(pevit_launch_lowrank_grad(at<bf16>(W, v.xn1), E, at<float>(W, c->w_u32), dqkv, c->NQ, at<float>(W, v.t),
                                                 at<float>(W, c->w_partial + (size_t)l * c->partial_layer),
-                                                at<float>(W, c->w_dbias + (size_t)l * c->dbias_layer), chunks, B, H, N, E, gs));
+                                                at<float>(W, c->w_dbias + (size_t)l * c->dbias_layer), chunks, B, H, N, E, gs, c->lowrank_xcd));
             if (use_side) { HIP_OK(hipEventRecord(c->ev_join, c->side)); side_pending = true; }
         }
         if (l > 0 || need_dx0) {
@@ -822,8 +823,9 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0, bool cls_
                                         at<float>(W, c->w_dbias + (size_t)l_lo * c->dbias_layer), c->dbias_layer / 4, chunks,
                                         c->ascale, nl, at<float>(W, c->w_G) + (size_t)l_lo * 4 * E * 32,
                                         at<float>(W, c->w_rule) + (size_t)l_lo * 4096, c->params, c->grads, pl0, c->p_layer_stride, E, s));
-        // the shared rule factors collect from every layer: summed once, in layer order, when the last range is done
-        if (l_lo == 0) CHECK(pevit_launch_rule_sum(at<float>(W, c->w_rule), c->grads, c->L, s));
+        // the shared rule factors collect from every layer: each range adds its own layers (top first, one running sum), so a
+        // backward that never reaches block 0 keeps its rule contributions and a walk in ranges equals the one-call backward
+        CHECK(pevit_launch_rule_sum(at<float>(W, c->w_rule), c->grads, l_lo, l_hi, s));
     } else if (c->d.method == PEVIT_LORA) {
         CHECK(pevit_launch_chain_lora(at<float>(W, c->w_partial + (size_t)l_lo * c->partial_layer), c->partial_layer / 4, chunks,
                                       c->ascale, c->d.lora_rank, nl, at<float>(W, c->w_G) + (size_t)l_lo * 4 * E * 32, c->grads, pl0,
@@ -865,9 +867,6 @@ extern "C" int pevit_blocks_forward(pevit_ctx* c, void* stream, const float* x_n
     if (l_lo < 0 || l_hi > c->L || l_lo >= l_hi) { pevit_set_error("blocks_forward: bad block range [%d, %d)", l_lo, l_hi); return -1; }
     hipStream_t s = (hipStream_t)stream;
     size_t total; layout_workspace(c, B, c->sav, &total, c);
-    // a walk over the blocks starts at block 0: the per-layer scratch of the shared KAdaptation rule gradients starts clean, so
-    // that a backward through SOME blocks only never adds another step's contribution (rule_sum adds all L layers)
-    if (l_lo == 0 && c->d.method == PEVIT_KADAPTATION) HIP_OK(hipMemsetAsync(c->ws + c->w_rule, 0, (size_t)c->L * 4096 * 4, s));
     CHECK(pevit_launch_permute_rows(x_nbe, at<float>(c->ws, c->sav[l_lo].x_in), c->N, B, c->E, 1, s));
     CHECK(blocks_forward(c, s, B, false, l_lo, l_hi));
     const size_t out = l_hi < c->L ? c->sav[l_hi].x_in : c->w_xfinal;
@@ -917,9 +916,12 @@ extern "C" int pevit_zero_grads(pevit_ctx* c, void* stream) {
 extern "C" int pevit_sgd_step(pevit_ctx* c, void* stream, float lr, float momentum, float wd, float grad_scale,
                               int flags) {
     if (!c || !c->params || !c->grads || !c->mom) { pevit_set_error("sgd_step: parameters/momentum not set"); return -1; }
-    const unsigned* poison = (c->ws && c->sk_slots) ? at<unsigned>(c->ws, c->w_skflag) + c->sk_slots : nullptr;
+    // the error word of the workspace bound NOW (a re-bind moves it; without stream-K slots -- f32 verification mode -- there is
+    // no hand-off that could fail and nothing to guard)
+    unsigned* poison = (c->ws && c->sk_slots) ? at<unsigned>(c->ws, c->w_skflag) + c->sk_slots : nullptr;
+    unsigned* skipped = poison ? at<unsigned>(c->ws, c->w_skflag) + PEVIT_SK_MAX_SLOTS + 1 : nullptr;
     return pevit_launch_sgd(c->params, c->grads, c->mom, c->grad_mask, c->n_total, lr, momentum, wd, flags,
-                            grad_scale, (hipStream_t)stream, poison);
+                            grad_scale, (hipStream_t)stream, poison, skipped);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1145,8 +1147,25 @@ extern "C" int pevit_streamk_error(pevit_ctx* c, void* stream) {
     unsigned v = 0;
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return -1;
     if (hipMemcpy(&v, flag, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    if (v) (void)hipMemset(flag, 0, 4);
+    if (v) {
+        (void)hipMemset(flag, 0, 4);
+        if (c) (void)hipMemset(at<unsigned>(c->ws, c->w_skflag) + PEVIT_SK_MAX_SLOTS + 1, 0, 4);    // the skipped-update counter with it
+    }
     return v ? 1 : 0;
+}
+// the same word without clearing it, plus the number of optimizer updates the fused SGD kernel withheld because of it.  A caller
+// that wants to go on after the error calls pevit_streamk_error (which clears the word) and knows how many steps it lost.
+extern "C" int pevit_streamk_status(pevit_ctx* c, void* stream, unsigned* error_word, unsigned* skipped_updates) {
+    if (!c) { pevit_set_error("streamk_status: null context"); return -1; }
+    unsigned v[2] = {0, 0};
+    if (c->ws && c->sk_slots) {
+        if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return -1;
+        if (hipMemcpy(&v[0], at<unsigned>(c->ws, c->w_skflag) + c->sk_slots, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        if (hipMemcpy(&v[1], at<unsigned>(c->ws, c->w_skflag) + PEVIT_SK_MAX_SLOTS + 1, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    }
+    if (error_word) *error_word = v[0];
+    if (skipped_updates) *skipped_updates = v[1];
+    return 0;
 }
 extern "C" int pevit_op_gemm_fp8(void* stream, int epi, const void* A, int lda, const void* Bcodes, int ldb, int b_rows,
                                  const float* bscale, const float* oscale, int M, int N, int K, const float* bias,
@@ -1293,7 +1312,7 @@ extern "C" int pevit_tune(pevit_ctx* c, const char* key, int value) {
     if (key && !strcmp(key, "gemm_band")) { t.band = value; return 0; }
     if (key && !strcmp(key, "gemm_stagger")) { t.stagger = value; return 0; }
     if (key && c && !strcmp(key, "dx_stored")) { c->dx_stored = value; return 0; }
-    if (key && !strcmp(key, "lowrank_xcd")) { pevit_lowrank_set_xcd(value); return 0; }
+    if (key && c && !strcmp(key, "lowrank_xcd")) { c->lowrank_xcd = value; return 0; }
     pevit_set_error("tune: unknown key %s", key ? key : "(null)");
     return -1;
 }

@@ -40,7 +40,7 @@
 #include "gemm_epilogue.h"
 
 namespace {
-int g_last_path = 0;   // which kernel family the last pevit_launch_gemm took (pevit_debug_last_gemm_path; tests)
+thread_local int g_last_path = 0;   // which kernel family the last pevit_launch_gemm OF THIS THREAD took (pevit_debug_last_gemm_path; tests): contexts driven from different threads do not share it
 
 // measurement bits of GemmParams::dbg; -DGEMM_NO_DBG compiles them out
 #ifdef GEMM_NO_DBG

@@ -68,7 +68,6 @@ struct GemmTune {
 };
 constexpr int PEVIT_SK_SLAB_FLOATS = 128 * 128;   // one partial tile per residency slot
 constexpr int PEVIT_SK_MAX_SLOTS = 1024;
-void pevit_lowrank_set_xcd(int v);                  // lowrank_grad: XCD-contiguous workgroup order (measurement knob, default on)
 int pevit_gemm_last_path();                        // 1 plain tile, 2 staggered 8-wave, 3 k-split (alternate k-tiles), 4 phased k-split, 5 stream-K, 6 few-row split-K
 int pevit_gemm_sk_slots();                         // residency slots of the stream-K kernel on this device (2 per CU, multiple of 8)
 
@@ -122,14 +121,14 @@ int pevit_launch_lowrank_u(const bf16* dqkv, int ld, const bf16* qT, float* u32,
 // partial[chunk][4][E][32]: dP_q, dP_v (= xn^T u), dQ_q, dQ_v (= dDelta^T t_ref); dbias partial[chunk][E]
 int pevit_launch_lowrank_grad(const bf16* xn, int ldx, const float* u32, const bf16* dqkv, int ld,
                               const float* t, float* partial, float* dbias_partial, int chunks,
-                              int B, int H, int N, int E, hipStream_t s);
+                              int B, int H, int N, int E, hipStream_t s, int xcd_order = 1);   // xcd_order: XCD-contiguous workgroup order (measurement knob)
 int pevit_lowrank_chunks(int T);
 // reduce the per-chunk partials of all layers and apply the chain rule onto the reference's
 // parameter tensors (flat gradient buffer, accumulating)
 int pevit_launch_chain_kadapt(const float* partial, size_t partial_layer, const float* dbias_partial, size_t dbias_layer,
                               int chunks, float ascale, int layers, float* G, float* rule_scratch, const float* params,
                               float* grads, size_t p_layer0, size_t p_layer_stride, int E, hipStream_t s);
-int pevit_launch_rule_sum(const float* rule_scratch, float* grads, int layers, hipStream_t s);
+int pevit_launch_rule_sum(const float* rule_scratch, float* grads, int l_lo, int l_hi, hipStream_t s);
 int pevit_launch_chain_lora(const float* partial, size_t partial_layer, int chunks, float ascale, int r, int layers,
                             float* G, float* grads, size_t p_layer0, size_t p_layer_stride, int E, hipStream_t s);
 
@@ -143,7 +142,8 @@ int pevit_launch_permute_rows(const float* src, float* dst, int N, int B, int E,
 int pevit_launch_scale_f32(float* p, size_t n, float scale, hipStream_t s);
 int pevit_launch_sgd(float* p, const float* g, float* mom, const unsigned char* has_grad, size_t n,
                      float lr, float momentum, float wd, int first_step, float grad_scale, hipStream_t s,
-                     const unsigned* poison = nullptr);   // device word: non-zero = skip the update (stream-K hand-off error)
+                     const unsigned* poison = nullptr,    // device word: non-zero = skip the update (stream-K hand-off error)
+                     unsigned* skipped = nullptr);        // device counter of the updates skipped that way
 
 // ---- fp8.hip (e4m3 codes + power-of-two channel scales of the frozen weights) -----------------
 int pevit_launch_quant_rows_fp8(const float* W, int rows, int cols, unsigned char* out, int ldo, float* scale, int scaled_rows,

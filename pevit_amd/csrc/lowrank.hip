@@ -547,13 +547,16 @@ __global__ __launch_bounds__(256) void chain_kadapt_kernel(const float* __restri
     }
 }
 
-// g_rule[0:4096] += sum_l rule_scratch[l][0:4096]   (rule1_left | rule1_right | rule2_left | rule2_right)
-__global__ void rule_sum_kernel(const float* __restrict__ rule_scratch, float* g_rule, int L) {
+// g_rule[0:4096] += rule_scratch[l][0:4096] for l = l_hi-1 .. l_lo, ONE running sum that starts from the value already in
+// g_rule (rule1_left | rule1_right | rule2_left | rule2_right).  A backward over [l_lo, l_hi) adds exactly its own layers, and a
+// tower walked in several ranges from the top (data parallelism: (L, L/2) then (L/2, 0); a block-by-block autograd walk)
+// performs the same additions in the same order as the one-call backward: bit-identical shared-rule gradients.
+__global__ void rule_sum_kernel(const float* __restrict__ rule_scratch, float* g_rule, int l_lo, int l_hi) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 4096) return;
-    float s = 0.f;
-    for (int l = 0; l < L; ++l) s += rule_scratch[(size_t)l * 4096 + i];
-    g_rule[i] += s;
+    float s = g_rule[i];
+    for (int l = l_hi - 1; l >= l_lo; --l) s += rule_scratch[(size_t)l * 4096 + i];
+    g_rule[i] = s;
 }
 
 __global__ void chain_lora_kernel(const float* __restrict__ G, float ascale, int r, float* g_a1q, float* g_a2q,
@@ -570,10 +573,7 @@ __global__ void chain_lora_kernel(const float* __restrict__ G, float ascale, int
     g_a2v[(size_t)e * r + j] += ascale * G[3 * plane + (size_t)e * 32 + j];
 }
 
-int g_lowrank_xcd = 1;
 }  // namespace
-
-void pevit_lowrank_set_xcd(int v) { g_lowrank_xcd = v; }
 
 int pevit_launch_prep_kadapt(const float* rule1_l, const float* rule1_r, const float* rule2_l, const float* rule2_r,
                              const float* q_left, const float* q_right, AdapterPanels pan, int E, float ascale,
@@ -624,12 +624,12 @@ int pevit_lowrank_chunks(int T) { return ceil_div(T, LG_ROWS); }
 
 int pevit_launch_lowrank_grad(const bf16* xn, int ldx, const float* u32, const bf16* dqkv, int ld, const float* t,
                               float* partial, float* dbias_partial, int chunks, int B, int H, int N, int E,
-                              hipStream_t s) {
+                              hipStream_t s, int xcd_order) {
     const int T = B * N;
     if (chunks != ceil_div(T, LG_ROWS)) { pevit_set_error("lowrank_grad: chunks mismatch"); return -1; }
     if (E % (64 * LG_ES)) { pevit_set_error("lowrank_grad: width %d must be a multiple of %d", E, 64 * LG_ES); return -1; }
     hipLaunchKernelGGL(lowrank_grad_kernel, dim3(chunks * (E / 64 / LG_ES) * 3), dim3(256), 0, s, xn, ldx, u32, dqkv, ld, t,
-                       partial, dbias_partial, B, H, N, E, g_lowrank_xcd);
+                       partial, dbias_partial, B, H, N, E, xcd_order);
     LAUNCH_OK("lowrank_grad_kernel");
     return 0;
 }
@@ -652,9 +652,10 @@ int pevit_launch_chain_kadapt(const float* partial, size_t partial_layer, const 
     return 0;
 }
 
-// shared phm_rule factors: g_rule[0:4096] += sum over ALL layers (fixed order), once per step after the last chain call
-int pevit_launch_rule_sum(const float* rule_scratch, float* grads, int layers, hipStream_t s) {
-    hipLaunchKernelGGL(rule_sum_kernel, dim3(16), dim3(256), 0, s, rule_scratch, grads, layers);
+// shared phm_rule factors: the contributions of layers [l_lo, l_hi) (rule_scratch is indexed by absolute layer) are added
+// to the flat gradient buffer, top layer first, after the chain call of that range
+int pevit_launch_rule_sum(const float* rule_scratch, float* grads, int l_lo, int l_hi, hipStream_t s) {
+    hipLaunchKernelGGL(rule_sum_kernel, dim3(16), dim3(256), 0, s, rule_scratch, grads, l_lo, l_hi);
     LAUNCH_OK("rule_sum_kernel");
     return 0;
 }

@@ -239,7 +239,10 @@ class HipEngine:
         N, B, E = x_nbe.shape
         if (N, E) != (self.arch.tokens, self.arch.width) or x_nbe.device != self.device:
             raise _lib.PevitError(f"blocks_forward expects ({self.arch.tokens}, B, {self.arch.width}) on {self.device}")
-        for l in range(l_lo, l_hi):
+        # every forward -- also one through a few blocks -- overwrites activations a pending whole-tower backward would read;
+        # the output of block l_hi - 1 also lands in the saved INPUT of block l_hi
+        self.forward_generation += 1
+        for l in range(l_lo, min(l_hi + 1, self.arch.layers)):
             self.block_generation[l] = self.block_generation.get(l, 0) + 1
         x = x_nbe.contiguous().float()
         y = torch.empty_like(x)
@@ -321,11 +324,22 @@ class HipEngine:
 
     def check_streamk(self):
         """Stream-K GEMMs hand partial tiles between workgroups inside one launch; a consumer that never saw its
-        producer gives up after ~1 s and raises an error word instead of hanging.  Fails loudly if that happened."""
+        producer gives up after ~1 s and raises an error word instead of hanging.  Fails loudly if that happened, and says how
+        many optimizer updates the fused SGD kernel withheld since.  The word is NOT cleared here: every later update is
+        withheld and every later check raises again until the caller acknowledges with ``clear_streamk_error()``."""
+        word, skipped = C.c_uint(), C.c_uint()
+        _lib.check(self.lib.pevit_streamk_status(self._ctx, _lib.stream_ptr(), C.byref(word), C.byref(skipped)), "pevit_streamk_status")
+        if word.value:
+            raise _lib.PevitError(f"stream-K GEMM hand-off timed out: the logits / loss returned since are invalid and "
+                                  f"{skipped.value} optimizer update(s) were withheld on device (parameters and momentum are those "
+                                  f"of the last good step); call clear_streamk_error() to resume")
+
+    def clear_streamk_error(self) -> bool:
+        """Acknowledge a stream-K error (clears the device word and the withheld-update counter); True if one was pending."""
         rc = self.lib.pevit_streamk_error(self._ctx, _lib.stream_ptr())
-        if rc != 0:
-            raise _lib.PevitError("stream-K GEMM hand-off timed out (results of that step are invalid)" if rc > 0
-                                  else "pevit_streamk_error failed")
+        if rc < 0:
+            raise _lib.PevitError("pevit_streamk_error failed")
+        return rc > 0
 
     def profile_gemms(self, fn, max_launches=4096):
         """Run ``fn()`` with HIP events around every GEMM launch; returns (ms, flops, launches); the algorithmic

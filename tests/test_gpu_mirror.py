@@ -381,3 +381,80 @@ def test_walking_resblocks_equals_the_transformer_call(method, ckpt):
             assert torch.equal(g0[n], g1[n]), n
     # the Sequential itself is callable too
     assert torch.equal(model.visual.transformer.resblocks(x.cuda()), y0)
+
+
+def _kadapt_tiny_model(seed=4):
+    from oracle import ref_cpu
+    from pevit_amd.evaluation.model import build_peft_model
+    from pevit_amd.synth import randomize_adapters
+    model = build_peft_model(dict(load_tiny_sd()), "kadaptation").cuda()
+    named = [(n, p) for n, p in model.visual.named_parameters() if ref_cpu.is_trainable("kadaptation", "visual." + n)]
+    model.visual.engine()
+    randomize_adapters([(n, p) for n, p in named], seed=seed)
+    for _, p in named:
+        p.requires_grad_(True)
+    return model, named
+
+
+def test_a_backward_that_stops_above_block_0_keeps_its_shared_rule_gradients(ckpt):
+    """The four phm_rule* tensors are shared by every block (model.py:1003-1009).  A graph that is detached below block 1 (or a C
+    caller that differentiates blocks [1, 2) alone) must still receive block 1's contribution to them: every
+    pevit_blocks_backward range adds the rule partials of exactly its own blocks.  Upper-only + lower-only == the whole walk,
+    bit for bit (the same additions in the same order)."""
+    model, named = _kadapt_tiny_model()
+    blocks = model.visual.transformer.resblocks
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(10, 5, 128, generator=g).cuda(); dy = torch.randn(10, 5, 128, generator=g).cuda()
+
+    def grads():
+        torch.cuda.synchronize()
+        out = {n: (p.grad.clone() if p.grad is not None else None) for n, p in named}
+        for _, p in named:
+            p.grad = None
+        return out
+    model.visual.transformer(x.clone().requires_grad_(True)).backward(dy)
+    g_full = grads()
+    # block 1 alone: the graph is cut below it
+    with torch.no_grad():
+        h = blocks[0](x)
+    h = h.detach().requires_grad_(True)
+    blocks[1](h).backward(dy)
+    dh = h.grad.clone()
+    g_up = grads()
+    # block 0 alone, driven by the gradient block 1 handed down
+    blocks[0](x.clone().requires_grad_(True)).backward(dh)
+    g_lo = grads()
+    rules = [n for n, _ in named if "phm_rule" in n]
+    assert len(rules) == 4
+    for n in rules:
+        assert float(g_up[n].abs().max()) > 0.0, f"{n}: block 1's contribution was dropped by a backward that never reached block 0"
+        assert float(g_lo[n].abs().max()) > 0.0, n
+        assert torch.equal(g_up[n] + g_lo[n], g_full[n]), n
+    for n, _ in named:
+        if n in rules or g_full[n] is None:
+            continue
+        own_up, own_lo = ".resblocks.1." in n, ".resblocks.0." in n
+        assert own_up != own_lo, n
+        part = g_up[n] if own_up else g_lo[n]
+        other = g_lo[n] if own_up else g_up[n]
+        assert torch.equal(part, g_full[n]), n
+        assert other is None or float(other.abs().max()) == 0.0, n
+
+
+def test_a_block_forward_between_a_tower_forward_and_its_backward_is_refused(ckpt):
+    """One activation set per context: resblocks[i](x) overwrites block i's saved activations AND block i+1's saved input, so a
+    whole-tower backward that was pending must fail loudly instead of differentiating the wrong activations."""
+    from pevit_amd._lib import PevitError
+    model, named = _kadapt_tiny_model()
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(10, 5, 128, generator=g).cuda(); dy = torch.randn(10, 5, 128, generator=g).cuda()
+    y = model.visual.transformer(x.clone().requires_grad_(True))
+    model.visual.transformer.resblocks[0](x.clone().requires_grad_(True))       # grad-enabled, same batch: used to slip through
+    with pytest.raises(PevitError, match="no longer holds"):
+        y.backward(dy)
+    # ... and a block walk is invalidated by a later forward through the block BELOW (its output is this block's saved input)
+    h = model.visual.transformer.resblocks[0](x.clone().requires_grad_(True))
+    y1 = model.visual.transformer.resblocks[1](h)
+    model.visual.transformer.resblocks[0](x.clone().requires_grad_(True))
+    with pytest.raises(PevitError, match="no longer holds"):
+        y1.backward(dy)
