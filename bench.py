@@ -42,6 +42,8 @@ def train_gflop_per_image(E, L, P, R, D, C, rank, attention_site=True):
 
 
 PEAK_TFLOPS_BF16 = 2500.0     # dense MFMA bf16, MI355X_MICROARCH.md
+PEAK_TFLOPS_FP8 = 5000.0      # dense MX-fp8 MFMA (the forward frozen products of --weights fp8-act run on it)
+PEAK_HBM_TBS = 8.0            # HBM3E, spec (6.3 TB/s is what a streaming copy reaches on this chip)
 CPU_BASELINE_THREADS = 16     # best of the sweep 8/16/32/64/128 on the GPU box's host (profiles/r03_cpu_thread_sweep.md)
 EPI_NAMES = {0: "qkv(+t) -> head layout", 1: "bias+residual f32", 2: "bias+QuickGELU", 3: "dQuickGELU", 4: "f32", 5: "bf16",
              6: "bias bf16", 7: "patch embed", 8: "bias+ReLU", 9: "bias+residual (keep h)", 10: "bias+gelu_new",
@@ -138,8 +140,8 @@ def pmc_traffic(arch, method, batch):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=100)      # 20 warm-up + >= 100 timed steps
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=128, help="images per GPU (BASELINE config 2: 128)")
     ap.add_argument("--method", default="kadaptation")
     ap.add_argument("--arch", default="ViT-B/32")
@@ -152,6 +154,10 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="(tests only) process-group backend; RCCL refuses two ranks on one device, "
                                                             "gloo carries device tensors")
     ap.add_argument("--share-device", action="store_true", help="(tests only) every rank uses cuda:0")
+    ap.add_argument("--strict-traffic", action="store_true",
+                    help="exit with status 3 when the committed PMC pass (profiles/hbm_traffic.json) was not taken with this "
+                         "build's kernel sources, instead of printing the line with traffic null and traffic_stale true "
+                         "(tests/test_zz_profiles_current.py enforces the same on the committed tree)")
     ap.add_argument("--pmc-calib", action="store_true",
                     help="(profiling runs only) first move a known byte count through HBM so that the FETCH_SIZE / "
                          "WRITE_SIZE counters of the same rocprofv3 pass can be calibrated (scripts/pmc_traffic.py)")
@@ -228,18 +234,26 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
+    # one event per step on the launch stream (the engine launches on torch's current stream): the median step time
+    # next to the wall-clock mean
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         logits, loss = step()
+        marks[i + 1].record()
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
-    print(f"[bench rank {rank}/{world}] {dt / args.steps * 1e3:.3f} ms/step", file=sys.stderr, flush=True)   # stragglers show here
+    per_step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = per_step_ms[len(per_step_ms) // 2] if len(per_step_ms) % 2 else \
+        0.5 * (per_step_ms[len(per_step_ms) // 2 - 1] + per_step_ms[len(per_step_ms) // 2])
+    print(f"[bench rank {rank}/{world}] {dt / args.steps * 1e3:.3f} ms/step (median {median_ms:.3f})", file=sys.stderr, flush=True)   # stragglers show here
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt, median_ms], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tt)
+        dt, median_ms = float(tt[0]), float(tt[1])
     final_loss = float(loss)
     eng.check_streamk()          # a stream-K hand-off that timed out would make the timed steps invalid: fail loudly
 
@@ -247,6 +261,13 @@ def main():
     # extra steps right after the timed region so that event recording does not perturb `value`.
     prof_steps = max(1, min(args.steps, 10))
     gemm_ms, gemm_flops, gemm_launches = eng.profile_gemms(lambda: [step() for _ in range(prof_steps)])
+    gemm_by_shape = dict(eng.last_profile_by_shape)
+    algo_bytes_total = eng.last_profile_bytes
+    # ... and a second pass that also brackets the HBM-bound kernels (their own pass: more events between the kernels)
+    eng.profile_gemms(lambda: [step() for _ in range(prof_steps)], all_kernels=True)
+    hbm_kernels = {k: {"launches_per_step": c / prof_steps, "avg_us": m * 1e3 / max(c, 1), "algorithmic_bytes_per_launch": b / max(c, 1),
+                       "achieved_TBps": b / max(m * 1e-3, 1e-12) / 1e12, "frac_of_hbm_peak": b / max(m * 1e-3, 1e-12) / 1e12 / PEAK_HBM_TBS}
+                   for k, (c, m, b) in sorted(eng.last_profile_hbm.items(), key=lambda kv: -kv[1][1])}
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -256,24 +277,33 @@ def main():
         gflop = train_gflop_per_image(arch.width, arch.layers, arch.patch, arch.resolution, arch.embed_dim, classes, r, site)
         step_tflops = value / world * gflop / 1e3      # whole-step algorithmic TFLOP/s per GPU
         gemm_tflops = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-        algo_bytes = eng.last_profile_bytes / max(gemm_launches, 1)
+        algo_bytes = algo_bytes_total / max(gemm_launches, 1)
         traffic, traffic_how = pmc_traffic(args.arch, args.method, args.batch) if args.weights == "bf16" else (None, "no PMC pass for fp8 weights")
+        traffic_stale = traffic is None and "different kernel sources" in traffic_how
+        if traffic_stale:
+            print("[bench] " + traffic_how, file=sys.stderr, flush=True)
+            if args.strict_traffic:
+                raise SystemExit(3)
         attainable = measured_attainable_peak(dev)
+        # the matrix peak the family is priced against: bf16 MFMA, except for the fp8 x fp8 forward path
+        peak = PEAK_TFLOPS_FP8 if args.weights == "fp8-act" else PEAK_TFLOPS_BF16
         # the GEMM launches of a step by (epilogue, M, N, K), largest share of the time first: which product is furthest
         # from the peak
         per_kernel = []
-        for (epi, M, N, K), (cnt, ms_k, fl_k) in sorted(eng.last_profile_by_shape.items(), key=lambda kv: -kv[1][1])[:8]:
+        for (epi, M, N, K), (cnt, ms_k, fl_k, by_k) in sorted(gemm_by_shape.items(), key=lambda kv: -kv[1][1])[:8]:
+            sec = max(ms_k, 1e-9) * 1e-3
             per_kernel.append({"epilogue": EPI_NAMES.get(epi, str(epi)), "M": M, "N": N, "K": K,
                                "launches_per_step": cnt / prof_steps, "avg_us": ms_k * 1e3 / cnt,
-                               "share_of_gemm_time": ms_k / gemm_ms, "tflops": fl_k / (ms_k * 1e-3) / 1e12,
-                               "frac": fl_k / (ms_k * 1e-3) / 1e12 / PEAK_TFLOPS_BF16})
+                               "share_of_gemm_time": ms_k / max(gemm_ms, 1e-9), "tflops": fl_k / sec / 1e12,
+                               "frac": fl_k / sec / 1e12 / peak, "algorithmic_TBps": by_k / sec / 1e12})
         headline = (args.arch, args.method, args.batch, args.weights) == ("ViT-B/32", "kadaptation", 128, "bf16")
         metric = "images/sec fine-tune, CLIP ViT-B/32 + KAdaptation, bs=128, 1/2/4/8 GPU" if headline else \
             f"images/sec fine-tune, CLIP {args.arch} + {args.method}, bs={args.batch}/GPU, {args.weights} weights"
         out = {
             "metric": metric,
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms, "median_ms_per_step": median_ms, "value_at_median": args.batch * world / (median_ms * 1e-3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             # the arithmetic type of the path: bf16 operands on the bf16 MFMA, f32 accumulate; with --weights fp8 the frozen
             # weights are e4m3 codes converted to bf16 in the GEMM (the activation side stays bf16)
             "dtype": {"bf16": "bf16", "fp8": "bf16 x fp8-e4m3 weights", "fp8-act": "fp8-e4m3 x fp8-e4m3 (forward frozen products), bf16 x fp8 (backward)"}[args.weights], "data": "synthetic",
@@ -285,8 +315,14 @@ def main():
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "train_gflop_per_image": gflop, "final_loss": final_loss},
             "roofline": {"bound": "mfma", "kernel": "gemm8_kernel<...> + gemm_kphase_kernel<...> + gemm_kernel<...> + gemm_streamk_kernel<...> (pevit_amd/csrc/gemm.hip: all epilogues / tile shapes)",
-                         "achieved": gemm_tflops, "peak": PEAK_TFLOPS_BF16, "unit": "TFLOP/s",
-                         "frac": gemm_tflops / PEAK_TFLOPS_BF16, "traffic": traffic, "traffic_unit": "bytes/launch",
+                         "achieved": gemm_tflops, "peak": peak, "unit": "TFLOP/s",
+                         "frac": gemm_tflops / peak, "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_stale": traffic_stale,
+                         # the whole step against the same peak: images/s x algorithmic GFLOP/image, and the matrix-core work
+                         # actually executed (class-token pruning of the last block) over the step time
+                         "whole_step_frac": step_tflops / peak,
+                         "executed_gemm_frac_of_peak": gemm_flops / prof_steps / 1e12 / (ms * 1e-3) / peak,
+                         "non_gemm_ms_per_step": ms - gemm_ms / prof_steps,
+                         "hbm_kernels": hbm_kernels,
                          "peak_attainable_measured": {"value": attainable, "unit": "TFLOP/s",
                                                       "how": "vendor-library bf16 GEMM 4096^3 (torch.matmul), measured in this run "
                                                              "after the timed region; not used by the product path"},
@@ -299,12 +335,12 @@ def main():
                          "flops_per_launch": gemm_flops / max(gemm_launches, 1),
                          "how": "2*M*N*K of every GEMM launch / HIP-event duration of that launch (events on the "
                                 "launch stream), summed over %d steps" % prof_steps,
-                         "whole_step": {"achieved": step_tflops, "frac": step_tflops / PEAK_TFLOPS_BF16,
+                         "whole_step": {"achieved": step_tflops, "frac": step_tflops / peak,
                                         "how": "images/s x algorithmic GFLOP/image (SURVEY 8d) / peak",
                                         # the last block runs its post-attention products on the class-token rows only
                                         # (identical results): the matrix-core work actually executed per step is lower
                                         "executed_gemm_tflop_per_step": gemm_flops / prof_steps / 1e12,
-                                        "executed_gemm_frac_of_peak": gemm_flops / prof_steps / 1e12 / (ms * 1e-3) / PEAK_TFLOPS_BF16}},
+                                        "executed_gemm_frac_of_peak": gemm_flops / prof_steps / 1e12 / (ms * 1e-3) / peak}},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

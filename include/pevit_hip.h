@@ -162,11 +162,20 @@ int pevit_train_forward_backward(pevit_ctx* ctx, void* stream, const float* imag
                                  float* loss, int batch);
 
 /* ---- measurement: HIP events around every MFMA GEMM launch of the context (the dominant kernel
- * family); totals over the launches recorded between begin and end ---------------------------- */
+ * family); totals over the GEMM launches recorded between begin and end.  With pevit_tune(ctx, "profile_all", 1) the
+ * HBM-bound kernels of the step are bracketed as well: their records carry epi_mnk[0] = 100 + pevit_prof_kind, the row
+ * count in epi_mnk[1], flops 0 and their algorithmic bytes; *launches counts every record, the totals only the GEMMs. */
+enum pevit_prof_kind {
+    PEVIT_PROF_LN_FWD = 0, PEVIT_PROF_LN_BWD = 1, PEVIT_PROF_ATTN_FWD = 2, PEVIT_PROF_ATTN_BWD = 3, PEVIT_PROF_DELTA_ADD = 4,
+    PEVIT_PROF_LOWRANK_U = 5, PEVIT_PROF_LOWRANK_GRAD = 6, PEVIT_PROF_IM2COL = 7, PEVIT_PROF_LOWRANK_BWD = 8,
+    PEVIT_PROF_ATTN_FWD_DELTA = 9
+};
 int pevit_profile_begin(pevit_ctx* ctx, int max_launches);
 int pevit_profile_end(pevit_ctx* ctx, double* total_ms, double* total_flops, double* total_bytes, int* launches);
 /* launch i (0 <= i < *launches of the last pevit_profile_end): its duration, 2*M*N*K and {epilogue, M, N, K} */
 int pevit_profile_launch(pevit_ctx* ctx, int i, double* ms, double* flops, int* epi_mnk);
+/* ... and the bytes it must move at least: every operand read once, every result written once */
+int pevit_profile_launch_bytes(pevit_ctx* ctx, int i, double* bytes);
 
 /* ---- single kernels, exposed for parity tests and profiling ------------------------- */
 int pevit_op_gemm(void* stream, int epilogue, const void* A_bf16, int lda, const void* B_bf16, int ldb, int b_rows,
@@ -209,8 +218,18 @@ int pevit_op_attn_fwd(void* stream, const void* q, const void* k, const void* v,
 int pevit_op_attn_bwd(void* stream, const void* q, const void* k, const void* v, const void* out, int ldo,
                       const void* dout, int lddo, const float* lse, void* dqkv, int ld, int B, int H, int N);
 int pevit_op_cast_bf16(void* stream, const float* src, void* dst, size_t n, float scale);
-int pevit_op_delta_add(void* stream, void* qbuf, void* vbuf, const float* t, const float* q32, const float* bias,
+/* q16: Q as a bf16 panel [E][64] (Q_q | Q_v), the production operand of the forward delta */
+int pevit_op_delta_add(void* stream, void* qbuf, void* vbuf, const float* t, const void* q16_bf16, const float* bias,
                        float ascale, int B, int N, int E);
+/* delta_add + attn_fwd as ONE launch (attn_delta.hip) for geometries where pevit_op_attn_delta_hpw(B, H, N) > 0 (runs of that
+ * many heads own whole reference rows of the raw reshape, model.py:796-799; N <= 64): q and v are rewritten with q + delta,
+ * v + delta; bit-identical to pevit_op_delta_add followed by pevit_op_attn_fwd */
+int pevit_op_attn_fwd_delta(void* stream, void* q, const void* k, void* v, const float* t, const void* q16_bf16, const float* bias,
+                            float ascale, void* out, int ldo, float* lse, int B, int H, int N);
+int pevit_op_attn_delta_hpw(int B, int H, int N);
+/* measurement only: device buffer of 8 uint64 per workgroup that the next pevit_op_attn_fwd_delta launches fill with s_memtime
+ * stamps at their phase boundaries (NULL switches it off) */
+int pevit_debug_timeline(void* buf);
 int pevit_op_lowrank_u(void* stream, const void* dqkv, int ld, const void* qT, float* u32, void* u_cols, int B,
                        int H, int N, int E);
 int pevit_op_lowrank_grad(void* stream, const void* xn, int ldx, const float* u32, const void* dqkv, int ld,
@@ -249,7 +268,8 @@ int pevit_op_im2col(void* stream, const float* images, void* patches_bf16, int B
  * offset), "gemm_ksplit_small", "gemm_ksplit_mink", "gemm_kphase_nl" (requests in the LOAD section: 8, or between the
  * MFMAs: 2), "gemm_stagger" (0 = legacy 8-wave kernel, 1 = staggered, 2 = also the 256x128 tile), "gemm_band",
  * "gemm_skinny" (0 = never use the few-row split-K kernel), "gemm_skinny_maxm" / "_mink" / "_slices", "gemm_sk_share" /
- * "gemm_sk_band" (with gemm_streamk = 2), "lowrank_xcd", "fused_bottleneck" and "dx_stored" (ctx only);
+ * "gemm_sk_band" (with gemm_streamk = 2), "lowrank_xcd", "fused_bottleneck", "profile_all", "fused_attn_delta" (0 = delta_add + attn_fwd as two launches) and
+ * "dx_stored" (ctx only);
  * returns 0, or -1 for an unknown key */
 int pevit_tune(pevit_ctx* ctx, const char* key, int value);
 

@@ -14,7 +14,7 @@ Storage points reproduced (engine buffer -> here):
             frozen weights bf16, q rows pre-scaled 1/8   bf(W)
             q, k, v in head layout (bf16)                QKVAug / LinearE(round_out)
             t = xn P with P stored bf16, t kept f32      QKVAug
-            delta = ascale t Q^T + b in f32, q/v RMW     RoundSTE(q + delta)
+            delta = ascale t bf16(Q)^T + b, q/v RMW       RoundSTE(q + delta)
             probabilities bf16, row sum of the ROUNDED p AttnCore
             attention output bf16                        AttnCore
             h (bf16), gelu(h) (bf16, from the stored h)  LinearE(round_out), QuickGeluE
@@ -196,7 +196,7 @@ class QKVAug(torch.autograd.Function):
 
 
 class DeltaFromT(torch.autograd.Function):
-    """delta = ascale t Q^T + b in f32 (the engine's split-bf16 product is f32-class).
+    """delta = ascale t bf16(Q)^T + b (the engine multiplies the bf16 panel of Q by t split into bf16 hi + lo: exact in t).
     backward: returns u = dDelta bf16(Q) for t (see QKVAug), dQ = ascale dDelta^T bf16(t), d b = colsum(dDelta)."""
 
     @staticmethod
@@ -204,7 +204,7 @@ class DeltaFromT(torch.autograd.Function):
         ctx.save_for_backward(t, Q)
         ctx.ascale = ascale
         ctx.has_bias = bias is not None
-        d = ascale * (t @ Q.t())
+        d = ascale * (t @ bf(Q).t())        # Q enters the delta product as its bf16 panel (round 4), t in f32 (hi + lo)
         return d + bias if bias is not None else d
 
     @staticmethod

@@ -58,6 +58,7 @@ SIGNATURES = {
     "pevit_profile_begin": (c_int, [P, c_int]),
     "pevit_profile_end": (c_int, [P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_int)]),
     "pevit_profile_launch": (c_int, [P, c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_int)]),
+    "pevit_profile_launch_bytes": (c_int, [P, c_int, C.POINTER(C.c_double)]),
     "pevit_op_gemm": (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, c_int,
                               P, c_int, P, c_int, P, c_int, c_size_t, c_int, c_int, c_int]),
     "pevit_op_gemm_fp8": (c_int, [P, c_int, P, c_int, P, c_int, c_int, P, P, c_int, c_int, c_int, P, P, c_int, P, c_int,
@@ -75,6 +76,9 @@ SIGNATURES = {
     "pevit_op_attn_bwd": (c_int, [P, P, P, P, P, c_int, P, c_int, P, P, c_int, c_int, c_int, c_int]),
     "pevit_op_cast_bf16": (c_int, [P, P, P, c_size_t, c_float]),
     "pevit_op_delta_add": (c_int, [P, P, P, P, P, P, c_float, c_int, c_int, c_int]),
+    "pevit_op_attn_fwd_delta": (c_int, [P, P, P, P, P, P, P, c_float, P, c_int, P, c_int, c_int, c_int]),
+    "pevit_op_attn_delta_hpw": (c_int, [c_int, c_int, c_int]),
+    "pevit_debug_timeline": (c_int, [P]),
     "pevit_op_lowrank_u": (c_int, [P, P, c_int, P, P, P, c_int, c_int, c_int, c_int]),
     "pevit_op_lowrank_grad": (c_int, [P, P, c_int, P, P, c_int, P, P, P, c_int, c_int, c_int, c_int]),
     "pevit_op_lowrank_chunks": (c_int, [c_int]),

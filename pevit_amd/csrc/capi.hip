@@ -40,7 +40,7 @@ struct Carver {
 struct BlockArena {        // byte offsets inside the weight arena, one per layer
     size_t wqkv, wqkvT, wo, woT, wfc, wfcT, wpr, wprT;
     size_t bqkv, bo, bfc, bpr, ln1w, ln1b, ln2w, ln2b;
-    size_t q32, qT;
+    size_t q32, qT, q16;
     size_t wd, wdT, wu, wuT;      // post-MLP adapter panels (bf16), rewritten every step
     size_t wpan;                  // fp8 weights only: the 64 adapter rows P_q^T | P_v^T (bf16) of the separate t = xn P product
     size_t sqkv, so, sfc, spr;    // fp8 weights only: per-output-channel scales (f32, powers of two)
@@ -93,6 +93,7 @@ struct pevit_ctx {
     int saved_kind = 0;       // which forward the saved activations belong to: 1 = transformer seam, 2 = visual (class-token pruned)
     // optional per-GEMM timing (HIP events on the caller's stream), see pevit_profile_begin
     bool prof_on = false;
+    int prof_all = 0;         // also bracket the HBM-bound kernels (pevit_tune "profile_all")
     int prof_n = 0, prof_cap = 0;
     hipEvent_t* prof_ev = nullptr;      // 2 per launch
     double* prof_flops = nullptr;
@@ -108,6 +109,7 @@ struct pevit_ctx {
     int dx_stored = 1;        // dX GEMMs hand the LN-input gradient to LayerNorm backward in the activation storage type (bf16)
     int fused_bn = 0;         // post-MLP adapters: down -> activation -> up (and its backward) as one launch each (adapter.hip
                               // bottleneck_pair_kernel): 24.4 + 22.1 us against 22.9 + 19.5 us for the four GEMM launches -- opt-in
+    int fused_attn_delta = 1; // delta-add + attention forward as one launch where the geometry allows (attn_delta.hip)
     int lowrank_xcd = 1;      // lowrank_grad: XCD-contiguous workgroup order (+0.2 % per step)
     int side_stream = 0;      // adapter-gradient contractions on a second stream: +0.5 % step throughput, but it slows the GEMMs
                               // it overlaps by 4 %, which blurs the per-kernel roofline measurement: off by default
@@ -278,7 +280,7 @@ extern "C" int pevit_ctx_create(const pevit_dims* dims, pevit_ctx** out) {
         }
         b.bqkv = cv.take(3 * E * 4); b.bo = cv.take(E * 4); b.bfc = cv.take(4 * E * 4); b.bpr = cv.take(E * 4);
         b.ln1w = cv.take(E * 4); b.ln1b = cv.take(E * 4); b.ln2w = cv.take(E * 4); b.ln2b = cv.take(E * 4);
-        b.q32 = cv.take(E * 64 * 4); b.qT = cv.take(64 * E * c->es);
+        b.q32 = cv.take(E * 64 * 4); b.qT = cv.take(64 * E * c->es); b.q16 = cv.take(E * 64 * 2);
         b.wd = cv.take(64 * E * c->es); b.wdT = cv.take(64 * E * c->es); b.wu = cv.take(64 * E * c->es); b.wuT = cv.take(64 * E * c->es);
     }
     c->a_conv = cv.take(align_up(E, 128) * (size_t)c->Kpatch * c->es);
@@ -447,6 +449,7 @@ extern "C" int pevit_load_block(pevit_ctx* c, void* stream, int l, const float* 
     HIP_OK(hipMemcpyAsync(A + b.ln2b, ln2b, E * 4, hipMemcpyDeviceToDevice, s));
     HIP_OK(hipMemsetAsync(A + b.q32, 0, E * 64 * 4, s));
     HIP_OK(hipMemsetAsync(A + b.qT, 0, 64 * E * c->es, s));
+    HIP_OK(hipMemsetAsync(A + b.q16, 0, E * 64 * 2, s));
     return 0;
 }
 
@@ -469,6 +472,7 @@ AdapterPanels panels(pevit_ctx* c, int l) {
     p.ldwT = c->NQ;
     p.q32 = at<float>(c->arena, b.q32);
     p.qT = at<bf16>(c->arena, b.qT);
+    p.q16 = at<bf16>(c->arena, b.q16);
     return p;
 }
 
@@ -499,26 +503,47 @@ int prep_adapters(pevit_ctx* c, hipStream_t s) {
     return 0;
 }
 
+// ---- optional per-launch timing: HIP events on the caller's stream around a launch (pevit_profile_begin / _end) ----
+// GEMM launches are always recorded while profiling is on; the HBM-bound kernels of the step (LayerNorm, attention, the low-rank
+// adapter kernels, ...) only with pevit_tune(ctx, "profile_all", 1), so that the GEMM-family measurement keeps its own cadence.
+// Non-GEMM records carry shape[0] = 100 + kind (PEVIT_PROF_* in pevit_hip.h), flops 0 and the algorithmic bytes of the launch.
+int prof_open(pevit_ctx* c, hipStream_t s, bool is_gemm) {
+    if (!c->prof_on || c->prof_n >= c->prof_cap || (!is_gemm && !c->prof_all)) return -1;
+    (void)hipEventRecord(c->prof_ev[2 * c->prof_n], s);
+    return c->prof_n;
+}
+void prof_close(pevit_ctx* c, hipStream_t s, int slot, double flops, double bytes, int s0, int s1, int s2, int s3) {
+    if (slot < 0) return;
+    (void)hipEventRecord(c->prof_ev[2 * slot + 1], s);
+    c->prof_flops[slot] = flops; c->prof_bytes[slot] = bytes;
+    int* sh = c->prof_shape + 4 * slot;
+    sh[0] = s0; sh[1] = s1; sh[2] = s2; sh[3] = s3;
+    c->prof_n = slot + 1;
+}
+// CHECK() of a non-GEMM launch, bracketed when "profile_all" is on: kind = PEVIT_PROF_*, bytes = what the launch must move
+#define PROF(c, s, kind, rows, bytes, call)                                                  \
+    do {                                                                                     \
+        const int _slot = prof_open(c, s, false);                                            \
+        const int _rc = (call);                                                              \
+        prof_close(c, s, _slot, 0.0, (double)(bytes), 100 + (kind), (int)(rows), 0, 0);      \
+        if (_rc != 0) return -1;                                                             \
+    } while (0)
+
 // every GEMM of the step goes through here so that it can be bracketed with HIP events
 int gemm(pevit_ctx* c, int epi, const GemmParams& p_in, hipStream_t s) {
     GemmParams p = p_in;
     if (c->sk_slots && c->ws) {
         p.sk_flag = at<unsigned>(c->ws, c->w_skflag); p.sk_slab = at<float>(c->ws, c->w_skslab); p.sk_slots = c->sk_slots;
     }
-    const bool rec = c->prof_on && c->prof_n < c->prof_cap;
-    if (rec) (void)hipEventRecord(c->prof_ev[2 * c->prof_n], s);
+    const int slot = prof_open(c, s, true);
     const int rc = c->f32 ? pevit_launch_gemm_f32(epi, p, s) : pevit_launch_gemm(epi, p, c->tune, s);
-    if (rec) {
-        (void)hipEventRecord(c->prof_ev[2 * c->prof_n + 1], s);
-        c->prof_flops[c->prof_n] = 2.0 * (double)p.M * (double)p.N * (double)p.K;
-        int* sh = c->prof_shape + 4 * c->prof_n;
-        sh[0] = epi; sh[1] = p.M; sh[2] = p.N; sh[3] = p.K;
+    if (slot >= 0) {
         // every operand read once, every result written once (the minimum any schedule must move)
         const double mn = (double)p.M * (double)p.N;
-        c->prof_bytes[c->prof_n] = 2.0 * ((double)p.M + (double)p.N) * (double)p.K + (p.bias ? 4.0 * p.N : 0.0) +
-                                   mn * ((p.resid ? 4.0 : 0.0) + (p.aux ? 2.0 : 0.0) + (p.outf ? 4.0 : 0.0) +
-                                         (p.outf2 ? 4.0 : 0.0) + (p.outb ? 2.0 : 0.0) + (p.outb2 ? 2.0 : 0.0));
-        ++c->prof_n;
+        const double bytes = 2.0 * ((double)p.M + (double)p.N) * (double)p.K + (p.bias ? 4.0 * p.N : 0.0) +
+                             mn * ((p.resid ? 4.0 : 0.0) + (p.aux ? 2.0 : 0.0) + (p.outf ? 4.0 : 0.0) +
+                                   (p.outf2 ? 4.0 : 0.0) + (p.outb ? 2.0 : 0.0) + (p.outb2 ? 2.0 : 0.0));
+        prof_close(c, s, slot, 2.0 * (double)p.M * (double)p.N * (double)p.K, bytes, epi, p.M, p.N, p.K);
     }
     return rc;
 }
@@ -564,8 +589,9 @@ int blocks_forward(pevit_ctx* c, hipStream_t s, int B, bool cls_only, int l_lo =
         // x = x + attn(ln_1(x))                                         model.py:973
         unsigned char* a8 = c->fp8act ? at<unsigned char>(W, c->w_a8) : nullptr;
         unsigned char* attn8 = c->fp8act ? at<unsigned char>(W, c->w_attn8) : nullptr;
-        CHECK(pevit_launch_ln_fwd(x_in, at<float>(A, b.ln1w), at<float>(A, b.ln1b), T, E, at<bf16>(W, v.xn1), nullptr,
-                                  at<float>(W, v.mean1), at<float>(W, v.rstd1), s, 0, c->f32, a8));
+        PROF(c, s, PEVIT_PROF_LN_FWD, T, (double)T * E * (4 + c->es),
+             pevit_launch_ln_fwd(x_in, at<float>(A, b.ln1w), at<float>(A, b.ln1b), T, E, at<bf16>(W, v.xn1), nullptr,
+                                 at<float>(W, v.mean1), at<float>(W, v.rstd1), s, 0, c->f32, a8));
         if (!c->fp8) {
             GemmParams p = gp(at<bf16>(W, v.xn1), E, at<bf16>(A, b.wqkv), E, c->NQpad, T, site ? c->NQ : 3 * E, E);
             p.bias = at<float>(A, b.bqkv); p.outb = qkv; p.head_stride = plane; p.outf = at<float>(W, v.t); p.ldo = 64;
@@ -583,18 +609,29 @@ int blocks_forward(pevit_ctx* c, hipStream_t s, int B, bool cls_only, int l_lo =
                 CHECK(gemm(c, EPI_F32, q, s));
             }
         }
+        const float* dbias = nullptr;
+        if (c->d.method == PEVIT_KADAPTATION) dbias = c->params + c->p_layer0 + c->p_layer_stride * l + 4 * (size_t)E;
+        // delta-add and the attention core as ONE launch where a run of heads owns whole reference rows of the raw reshape
+        // (attn_delta.hip: N <= 64; ViT-B/32), otherwise delta_add + attn_fwd
+        const bool fused_ad = site && c->fused_attn_delta && !c->f32 && !attn8 && pevit_attn_delta_hpw(B, H, N) > 0;
+        if (fused_ad) {
+            PROF(c, s, PEVIT_PROF_ATTN_FWD_DELTA, T, (double)T * E * (3 + 2 + 1) * 2 + (double)T * 64 * 4 + (double)B * H * N * 4,   // q, k, v in; q', v', out
+                 pevit_launch_attn_fwd_delta(qkv, qkv + plane, qkv + 2 * plane, at<float>(W, v.t), at<bf16>(A, b.q16), dbias, c->ascale,
+                                             at<bf16>(W, v.attn_out), E, at<float>(W, v.lse), B, H, N, s));
+        } else {
         if (site) {
-            const float* bias = nullptr;
-            if (c->d.method == PEVIT_KADAPTATION) bias = c->params + c->p_layer0 + c->p_layer_stride * l + 4 * (size_t)E;
-            CHECK(pevit_launch_delta_add(qkv, eadv(c, qkv, 2 * plane), at<float>(W, v.t), at<float>(A, b.q32), bias, c->ascale, B, N,
-                                         E, s, c->f32));
+            PROF(c, s, PEVIT_PROF_DELTA_ADD, T, (double)T * E * 4 * c->es + (double)T * 64 * 4,     // q and v read + written, t read
+                 pevit_launch_delta_add(qkv, eadv(c, qkv, 2 * plane), at<float>(W, v.t), at<float>(A, b.q32), at<bf16>(A, b.q16), dbias,
+                                        c->ascale, B, N, E, s, c->f32));
         }
         if (c->f32)
             CHECK(pevit_launch_attn_fwd_f32((const float*)qkv, (const float*)eadv(c, qkv, plane), (const float*)eadv(c, qkv, 2 * plane),
                                             at<float>(W, v.attn_out), E, at<float>(W, v.lse), B, H, N, s));
         else
-            CHECK(pevit_launch_attn_fwd(qkv, qkv + plane, qkv + 2 * plane, at<bf16>(W, v.attn_out), E, at<float>(W, v.lse), B,
-                                        H, N, s, attn8));
+            PROF(c, s, PEVIT_PROF_ATTN_FWD, T, (double)T * E * 4 * 2 + (double)B * H * N * 4,
+                 pevit_launch_attn_fwd(qkv, qkv + plane, qkv + 2 * plane, at<bf16>(W, v.attn_out), E, at<float>(W, v.lse), B,
+                                       H, N, s, attn8));
+        }
         // rows of the tail of this block: all T, or (last block, cls_only) the B class-token rows, which
         // sit N*E elements apart in every [T][E] buffer
         const bool cls = cls_only && l == c->L - 1;
@@ -607,8 +644,9 @@ int blocks_forward(pevit_ctx* c, hipStream_t s, int B, bool cls_only, int l_lo =
             CHECK(gemm(c, EPI_BIAS_RESID_F32, p, s));
         }
         // x = x + mlp(ln_2(x))                                          model.py:974
-        CHECK(pevit_launch_ln_fwd(x_mid, at<float>(A, b.ln2w), at<float>(A, b.ln2b), R, E, at<bf16>(W, c->w_xn2), nullptr,
-                                  at<float>(W, v.mean2), at<float>(W, v.rstd2), s, (size_t)rs, c->f32, a8));
+        PROF(c, s, PEVIT_PROF_LN_FWD, R, (double)R * E * (4 + c->es),
+             pevit_launch_ln_fwd(x_mid, at<float>(A, b.ln2w), at<float>(A, b.ln2b), R, E, at<bf16>(W, c->w_xn2), nullptr,
+                                 at<float>(W, v.mean2), at<float>(W, v.rstd2), s, (size_t)rs, c->f32, a8));
         {
             GemmParams p = gpw(c, at<bf16>(W, c->w_xn2), E, b.wfc, E, 4 * E, R, 4 * E, E, b.sfc);
             if (a8) { p.A = reinterpret_cast<const bf16*>(a8); p.a_fp8 = 1; p.out2_fp8 = 1; }     // gelu(h) leaves as e4m3 codes
@@ -761,9 +799,11 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0, bool cls_
             else { p.outf = dxn; p.ldo = E; CHECK(gemm(c, EPI_F32, p, s)); }
         }
         // fp8: the bf16 copy feeds the out-projection backward, whose contraction runs over out_proj's output channels
-        CHECK(pevit_launch_ln_bwd(dxn, at<float>(W, v.x_mid), at<float>(W, v.mean2), at<float>(W, v.rstd2),
-                                  at<float>(A, b.ln2w), dxa, dxb, dyb, R, E, s, (size_t)rs,
-                                  c->fp8 ? at<float>(A, b.so) : nullptr, c->f32, c->dx_stored));
+        // dy (stored type or f32) + x + residual gradient read, f32 gradient + its stored copy written
+        PROF(c, s, PEVIT_PROF_LN_BWD, R, (double)R * E * ((c->dx_stored ? c->es : 4) + 4 + 4 + 4 + c->es),
+             pevit_launch_ln_bwd(dxn, at<float>(W, v.x_mid), at<float>(W, v.mean2), at<float>(W, v.rstd2),
+                                 at<float>(A, b.ln2w), dxa, dxb, dyb, R, E, s, (size_t)rs,
+                                 c->fp8 ? at<float>(A, b.so) : nullptr, c->f32, c->dx_stored));
         // ---- attention branch
         {
             GemmParams p = gpw(c, dyb, rs, b.woT, E, E, R, E, E, 0);
@@ -777,14 +817,16 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0, bool cls_
                                             at<float>(W, v.attn_out), E, at<float>(W, c->w_dO), E, at<float>(W, v.lse), (float*)dqkv,
                                             c->NQ, B, H, N, s));
         else
-            CHECK(pevit_launch_attn_bwd(qkv, qkv + plane, qkv + 2 * plane, at<bf16>(W, v.attn_out), E, at<bf16>(W, c->w_dO), E,
-                                        at<float>(W, v.lse), dqkv, c->NQ, B, H, N, s));
+            PROF(c, s, PEVIT_PROF_ATTN_BWD, T, (double)T * E * 8 * 2 + (double)B * H * N * 4,     // q, k, v, out, dout in; dq, dk, dv out
+                 pevit_launch_attn_bwd(qkv, qkv + plane, qkv + 2 * plane, at<bf16>(W, v.attn_out), E, at<bf16>(W, c->w_dO), E,
+                                       at<float>(W, v.lse), dqkv, c->NQ, B, H, N, s));
         if (site) {
             if (c->f32)
                 CHECK(pevit_launch_lowrank_u_f32((const float*)dqkv, c->NQ, at<float>(A, b.q32), at<float>(W, c->w_u32),
                                                  (float*)eadv(c, dqkv, 3 * (size_t)E), B, H, N, E, s));
             else
-                CHECK(pevit_launch_lowrank_u(dqkv, c->NQ, at<bf16>(A, b.qT), at<float>(W, c->w_u32), dqkv + 3 * E, B, H, N, E, s));
+                PROF(c, s, PEVIT_PROF_LOWRANK_U, T, (double)T * E * 2 * 2 + (double)T * 64 * 6,
+                     pevit_launch_lowrank_u(dqkv, c->NQ, at<bf16>(A, b.qT), at<float>(W, c->w_u32), dqkv + 3 * E, B, H, N, E, s));
             // the token-contracted adapter gradients feed nothing before the end of the step: run them beside
             // the QKV-backward GEMM / LayerNorm backward / next layer's MLP GEMMs on the second stream
             hipStream_t gs = s;
@@ -798,9 +840,10 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0, bool cls_
                                                     at<float>(W, v.t), at<float>(W, c->w_partial + (size_t)l * c->partial_layer),
                                                     at<float>(W, c->w_dbias + (size_t)l * c->dbias_layer), chunks, B, H, N, E, gs));
             else
-                CHECK(pevit_launch_lowrank_grad(at<bf16>(W, v.xn1), E, at<float>(W, c->w_u32), dqkv, c->NQ, at<float>(W, v.t),
-                                                at<float>(W, c->w_partial + (size_t)l * c->partial_layer),
-                                                at<float>(W, c->w_dbias + (size_t)l * c->dbias_layer), chunks, B, H, N, E, gs, c->lowrank_xcd));
+                PROF(c, gs, PEVIT_PROF_LOWRANK_GRAD, T, (double)T * E * 3 * 2 + (double)T * 64 * 8 + (double)chunks * 4 * E * 32 * 4,
+                     pevit_launch_lowrank_grad(at<bf16>(W, v.xn1), E, at<float>(W, c->w_u32), dqkv, c->NQ, at<float>(W, v.t),
+                                               at<float>(W, c->w_partial + (size_t)l * c->partial_layer),
+                                               at<float>(W, c->w_dbias + (size_t)l * c->dbias_layer), chunks, B, H, N, E, gs, c->lowrank_xcd));
             if (use_side) { HIP_OK(hipEventRecord(c->ev_join, c->side)); side_pending = true; }
         }
         if (l > 0 || need_dx0) {
@@ -808,9 +851,10 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0, bool cls_
             if (c->dx_stored) { p.outb = reinterpret_cast<bf16*>(dxn); p.ldob = E; CHECK(gemm(c, EPI_BF16, p, s)); }
             else { p.outf = dxn; p.ldo = E; CHECK(gemm(c, EPI_F32, p, s)); }
             // fp8: this bf16 copy is the upstream gradient of layer l-1's c_proj backward
-            CHECK(pevit_launch_ln_bwd(dxn, at<float>(W, v.x_in), at<float>(W, v.mean1), at<float>(W, v.rstd1),
-                                      at<float>(A, b.ln1w), dxb, dxa, dyb, T, E, s, 0,
-                                      (c->fp8 && l > 0) ? at<float>(A, c->blk[l - 1].spr) : nullptr, c->f32, c->dx_stored));
+            PROF(c, s, PEVIT_PROF_LN_BWD, T, (double)T * E * ((c->dx_stored ? c->es : 4) + 4 + 4 + 4 + c->es),
+                 pevit_launch_ln_bwd(dxn, at<float>(W, v.x_in), at<float>(W, v.mean1), at<float>(W, v.rstd1),
+                                     at<float>(A, b.ln1w), dxb, dxa, dyb, T, E, s, 0,
+                                     (c->fp8 && l > 0) ? at<float>(A, c->blk[l - 1].spr) : nullptr, c->f32, c->dx_stored));
         }
     }
     if (side_pending) HIP_OK(hipStreamWaitEvent(s, c->ev_join, 0));
@@ -960,7 +1004,8 @@ extern "C" int pevit_visual_forward(pevit_ctx* c, void* stream, const float* ima
     char* W = c->ws; char* A = c->arena;
     const int E = c->E, N = c->N, T = B * N;
     float* xpre = at<float>(W, c->w_dxn);               // scratch, free during the forward pass
-    CHECK(pevit_launch_im2col(images, at<bf16>(W, c->w_patches), B, c->R, c->P, c->Kpatch, s, c->f32));
+    PROF(c, s, PEVIT_PROF_IM2COL, B, (double)B * 3 * c->R * c->R * 4 + (double)B * c->G2 * c->Kpatch * c->es,
+         pevit_launch_im2col(images, at<bf16>(W, c->w_patches), B, c->R, c->P, c->Kpatch, s, c->f32));
     CHECK(pevit_launch_cls_row(at<float>(A, c->a_cls), at<float>(A, c->a_pos), xpre, B, N, E, s));
     {
         GemmParams p = gp(at<bf16>(W, c->w_patches), c->Kpatch, at<bf16>(A, c->a_conv), c->Kpatch, E, B * c->G2, E, c->Kpatch);
@@ -1094,7 +1139,7 @@ extern "C" int pevit_profile_end(pevit_ctx* c, double* total_ms, double* total_f
         float t = 0.f;
         HIP_OK(hipEventElapsedTime(&t, c->prof_ev[2 * i], c->prof_ev[2 * i + 1]));
         c->prof_ms[i] = t;
-        ms += t; fl += c->prof_flops[i]; by += c->prof_bytes[i];
+        if (c->prof_shape[4 * i] < 100) { ms += t; fl += c->prof_flops[i]; by += c->prof_bytes[i]; }     // totals: the GEMM family
     }
     if (total_ms) *total_ms = ms;
     if (total_flops) *total_flops = fl;
@@ -1109,6 +1154,13 @@ extern "C" int pevit_profile_launch(pevit_ctx* c, int i, double* ms, double* flo
     if (ms) *ms = c->prof_ms[i];
     if (flops) *flops = c->prof_flops[i];
     if (epi_mnk) for (int k = 0; k < 4; ++k) epi_mnk[k] = c->prof_shape[4 * i + k];
+    return 0;
+}
+
+// ... and the algorithmic bytes of that launch (operands read once + results written once)
+extern "C" int pevit_profile_launch_bytes(pevit_ctx* c, int i, double* bytes) {
+    if (!c || c->prof_on || i < 0 || i >= c->prof_n || !bytes) { pevit_set_error("profile_launch_bytes: no such recorded launch"); return -1; }
+    *bytes = c->prof_bytes[i];
     return 0;
 }
 
@@ -1228,10 +1280,17 @@ extern "C" int pevit_op_attn_bwd(void* stream, const void* q, const void* k, con
 extern "C" int pevit_op_cast_bf16(void* stream, const float* src, void* dst, size_t n, float scale) {
     return pevit_launch_cast_bf16(src, (bf16*)dst, n, scale, (hipStream_t)stream);
 }
-extern "C" int pevit_op_delta_add(void* stream, void* qbuf, void* vbuf, const float* t, const float* q32,
+extern "C" int pevit_op_delta_add(void* stream, void* qbuf, void* vbuf, const float* t, const void* q16,
                                   const float* bias, float ascale, int B, int N, int E) {
-    return pevit_launch_delta_add((bf16*)qbuf, (bf16*)vbuf, t, q32, bias, ascale, B, N, E, (hipStream_t)stream);
+    return pevit_launch_delta_add((bf16*)qbuf, (bf16*)vbuf, t, nullptr, (const bf16*)q16, bias, ascale, B, N, E, (hipStream_t)stream);
 }
+extern "C" int pevit_op_attn_fwd_delta(void* stream, void* q, const void* k, void* v, const float* t, const void* q16, const float* bias,
+                                       float ascale, void* out, int ldo, float* lse, int B, int H, int N) {
+    return pevit_launch_attn_fwd_delta((bf16*)q, (const bf16*)k, (bf16*)v, t, (const bf16*)q16, bias, ascale, (bf16*)out, ldo, lse, B, H, N,
+                                       (hipStream_t)stream);
+}
+extern "C" int pevit_debug_timeline(void* buf) { pevit_attn_delta_set_timeline(buf); return 0; }
+extern "C" int pevit_op_attn_delta_hpw(int B, int H, int N) { return pevit_attn_delta_hpw(B, H, N); }
 extern "C" int pevit_op_lowrank_u(void* stream, const void* dqkv, int ld, const void* qT, float* u32, void* u_cols, int B,
                                   int H, int N, int E) {
     return pevit_launch_lowrank_u((const bf16*)dqkv, ld, (const bf16*)qT, u32, (bf16*)u_cols, B, H, N, E,
@@ -1312,6 +1371,8 @@ extern "C" int pevit_tune(pevit_ctx* c, const char* key, int value) {
     if (key && !strcmp(key, "gemm_band")) { t.band = value; return 0; }
     if (key && !strcmp(key, "gemm_stagger")) { t.stagger = value; return 0; }
     if (key && c && !strcmp(key, "dx_stored")) { c->dx_stored = value; return 0; }
+    if (key && c && !strcmp(key, "profile_all")) { c->prof_all = value; return 0; }
+    if (key && c && !strcmp(key, "fused_attn_delta")) { c->fused_attn_delta = value; return 0; }
     if (key && c && !strcmp(key, "lowrank_xcd")) { c->lowrank_xcd = value; return 0; }
     pevit_set_error("tune: unknown key %s", key ? key : "(null)");
     return -1;

@@ -93,6 +93,15 @@ int pevit_launch_attn_bwd(const bf16* q, const bf16* k, const bf16* v, const bf1
                           const bf16* dout, int lddo, const float* lse, bf16* dqkv, int ld,
                           int B, int H, int N, hipStream_t s);
 
+// ---- attn_delta.hip (attention-site adapters fused with the attention core, N <= 64) --------------
+// heads per workgroup of the fused forms for this geometry, or 0 when there is none (the two-kernel path is used)
+int pevit_attn_delta_hpw(int B, int H, int N);
+// delta_add + attn_fwd in one launch: q, v (head layout) are rewritten with q + delta, v + delta (saved for backward)
+int pevit_launch_attn_fwd_delta(bf16* q, const bf16* k, bf16* v, const float* t, const bf16* q16, const float* bias,
+                                float ascale, bf16* out, int ldo, float* lse, int B, int H, int N, hipStream_t s);
+
+void pevit_attn_delta_set_timeline(void* buf);      // measurement only: 8 s_memtime stamps per workgroup of the next fused launches (null = off)
+
 // ---- lowrank.hip -----------------------------------------------------------------
 struct AdapterPanels {      // per layer, rewritten every step from the f32 master parameters
     bf16* w_aug_rows;       // &Wqkv_aug[3E][0]  : 64 rows x E  (P_q^T | P_v^T)
@@ -101,6 +110,7 @@ struct AdapterPanels {      // per layer, rewritten every step from the f32 mast
     int ldwT;
     float* q32;             // [E][64] f32 : Q_q | Q_v
     bf16* qT;               // [64][E] bf16: Q_q^T ; Q_v^T
+    bf16* q16;              // [E][64] bf16: Q_q | Q_v (operand of the forward delta; bf16 storage only)
 };
 struct LayerStrides { size_t arena_bytes; size_t param_floats; };   // per-layer pointer advance
 // KAdaptation: P[:,j] = s_j (x) l_j , Q[:,j] = t_j (x) r_j   (model.py:567-580); all layers
@@ -112,7 +122,8 @@ int pevit_launch_prep_lora(const float* a1q, const float* a2q, const float* a1v,
                            int r, AdapterPanels pan, int E, float ascale, int layers, LayerStrides st, hipStream_t s, int f32 = 0);
 // q_buf_flat[rr*E+e] += ascale * t[row(rr)][0:32] . Q_q[e] + bias[e]   (and v with cols 32:64)
 // rr is the reference's (n*B+b) row index of the raw reshape (model.py:796-799); row(rr)=b*N+n.
-int pevit_launch_delta_add(bf16* qbuf, bf16* vbuf, const float* t, const float* q32,
+// q16: the bf16 panel [E][64] of Q (production operand); q32: the f32 panel (f32 verification mode)
+int pevit_launch_delta_add(bf16* qbuf, bf16* vbuf, const float* t, const float* q32, const bf16* q16,
                            const float* bias, float ascale, int B, int N, int E, hipStream_t s, int f32 = 0);
 // u[row(rr)][0:32] = dDelta_q[rr] . Q_q ; [32:64] = dDelta_v[rr] . Q_v ; written f32 (u32) and
 // bf16 into dqkv[:, 3E:3E+64]

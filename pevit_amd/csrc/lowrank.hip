@@ -34,6 +34,7 @@ __device__ __forceinline__ AdapterPanels layer_panels(AdapterPanels pan, LayerSt
     pan.wT_aug_cols = reinterpret_cast<bf16*>(reinterpret_cast<char*>(pan.wT_aug_cols) + (size_t)l * st.arena_bytes);
     pan.q32 = reinterpret_cast<float*>(reinterpret_cast<char*>(pan.q32) + (size_t)l * st.arena_bytes);
     pan.qT = reinterpret_cast<bf16*>(reinterpret_cast<char*>(pan.qT) + (size_t)l * st.arena_bytes);
+    pan.q16 = reinterpret_cast<bf16*>(reinterpret_cast<char*>(pan.q16) + (size_t)l * st.arena_bytes);
     return pan;
 }
 
@@ -57,6 +58,10 @@ __global__ void prep_kadapt_kernel(const float* __restrict__ rule1_l, const floa
     st_store<ST>(pan.wT_aug_cols, (size_t)e * pan.ldwT + 32 + j, ascale * pv);
     pan.q32[(size_t)e * 64 + j] = qq;
     pan.q32[(size_t)e * 64 + 32 + j] = qv;
+    if constexpr (sizeof(ST) == 2) {           // the forward delta's operand: Q rounded to bf16 like P (rows of Wqkv_aug) and Q^T
+        pan.q16[(size_t)e * 64 + j] = f2bf(qq);
+        pan.q16[(size_t)e * 64 + 32 + j] = f2bf(qv);
+    }
     st_store<ST>(pan.qT, (size_t)j * E + e, qq);
     st_store<ST>(pan.qT, (size_t)(32 + j) * E + e, qv);
 }
@@ -78,14 +83,20 @@ __global__ void prep_lora_kernel(const float* __restrict__ a1q, const float* __r
     st_store<ST>(pan.wT_aug_cols, (size_t)e * pan.ldwT + 32 + j, ascale * pv);
     pan.q32[(size_t)e * 64 + j] = qq;
     pan.q32[(size_t)e * 64 + 32 + j] = qv;
+    if constexpr (sizeof(ST) == 2) {           // the forward delta's operand: Q rounded to bf16 like P (rows of Wqkv_aug) and Q^T
+        pan.q16[(size_t)e * 64 + j] = f2bf(qq);
+        pan.q16[(size_t)e * 64 + 32 + j] = f2bf(qv);
+    }
     st_store<ST>(pan.qT, (size_t)j * E + e, qq);
     st_store<ST>(pan.qT, (size_t)(32 + j) * E + e, qv);
 }
 
 // ---------------------------------------------------------------------------------
 // delta-add on the matrix core.  D[e][rr] = sum_j Q[e][j] t[rr][j] is a K=32 product, exactly one
-// v_mfma_f32_16x16x32_bf16; t and Q are f32, so each is split into bf16 hi + lo parts and the product
-// is taken as hi*hi + hi*lo + lo*hi (error ~2^-17, i.e. f32-class, at 3 MFMAs per 16x16 tile).
+// v_mfma_f32_16x16x32_bf16.  Production (bf16 storage): Q enters as its bf16 panel q16 -- the same rounding P carries in the
+// forward t = xn P product and Q^T in the backward u = dDelta Q -- and the f32 t as bf16 hi + lo parts: Q*t_lo + Q*t_hi, two
+// MFMAs per 16x16 tile (round 4; before, Q was split as well: three MFMAs and twice the operand bytes, which is what bounds
+// the fused kernel of attn_delta.hip).  f32 verification mode: both operands split, hi*hi + hi*lo + lo*hi (error ~2^-17).
 __device__ __forceinline__ void split_bf16v(const float4 a, const float4 b, bf16x8& hi, bf16x8& lo) {
     const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
@@ -115,8 +126,9 @@ __device__ __forceinline__ void split_bf16(const float* src, bf16x8& hi, bf16x8&
 constexpr int DA_RG = DA_RG_V, DA_COLS = 64;
 template <typename ST>
 __global__ __launch_bounds__(256) void delta_add_kernel(bf16* qbuf, bf16* vbuf, const float* __restrict__ t,
-                                                        const float* __restrict__ q32, const float* __restrict__ bias,
-                                                        float ascale, int B, int N, int E) {
+                                                        const float* __restrict__ q32, const bf16* __restrict__ q16,
+                                                        const float* __restrict__ bias, float ascale, int B, int N, int E) {
+    constexpr bool Q16 = sizeof(ST) == 2;
     const int lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
     const int wg = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int which = blockIdx.y;                  // 0: q, 1: v
@@ -149,21 +161,27 @@ __global__ __launch_bounds__(256) void delta_add_kernel(bf16* qbuf, bf16* vbuf, 
     // ... and so are the t rows, the Q rows and the bias of BOTH 32-column steps (L2 hits): a load issued after the first step's
     // stores would make hipcc wait with vmcnt(0), i.e. for those stores as well (gfx950 counts them in vmcnt)
     float4 traw[DA_RG][2], qraw[NST][2][2], braw[NST][2];
+    bf16x8 qb16[NST][2];
 #pragma unroll
     for (int k = 0; k < DA_RG; ++k) {
         const float* src = t + (size_t)row_of_ref(rrk[k], B, N) * 64 + which * 32 + 8 * g;
         traw[k][0] = *reinterpret_cast<const float4*>(src); traw[k][1] = *reinterpret_cast<const float4*>(src + 4);
     }
     const int m = c16;
-    const float* bsrc = bias ? bias : q32;                 // a valid address either way; the value is dropped without a bias
+    // a valid address of >= E floats either way; the value is dropped without a bias
+    const float* bsrc = bias ? bias : (Q16 ? reinterpret_cast<const float*>(q16) : q32);
 #pragma unroll
     for (int st = 0; st < NST; ++st) {
         const int eb = part * DA_COLS + st * 32;
         const int e_t0 = eb + 8 * (m >> 2) + (m & 3);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const float* src = q32 + (size_t)(e_t0 + 4 * h) * 64 + which * 32 + 8 * g;
-            qraw[st][h][0] = *reinterpret_cast<const float4*>(src); qraw[st][h][1] = *reinterpret_cast<const float4*>(src + 4);
+            if constexpr (Q16) {
+                qb16[st][h] = load_bf16x8(q16 + (size_t)(e_t0 + 4 * h) * 64 + which * 32 + 8 * g);
+            } else {
+                const float* src = q32 + (size_t)(e_t0 + 4 * h) * 64 + which * 32 + 8 * g;
+                qraw[st][h][0] = *reinterpret_cast<const float4*>(src); qraw[st][h][1] = *reinterpret_cast<const float4*>(src + 4);
+            }
         }
         braw[st][0] = *reinterpret_cast<const float4*>(bsrc + eb + 8 * g);
         braw[st][1] = *reinterpret_cast<const float4*>(bsrc + eb + 8 * g + 4);
@@ -179,8 +197,12 @@ __global__ __launch_bounds__(256) void delta_add_kernel(bf16* qbuf, bf16* vbuf, 
     for (int st = 0; st < NST; ++st) {
         const int eb = part * DA_COLS + st * 32;
         bf16x8 q0h, q0l, q1h, q1l;
-        split_bf16v(qraw[st][0][0], qraw[st][0][1], q0h, q0l);
-        split_bf16v(qraw[st][1][0], qraw[st][1][1], q1h, q1l);
+        if constexpr (Q16) {
+            q0h = qb16[st][0]; q1h = qb16[st][1]; q0l = q0h; q1l = q1h;      // (the lo parts are not used)
+        } else {
+            split_bf16v(qraw[st][0][0], qraw[st][0][1], q0h, q0l);
+            split_bf16v(qraw[st][1][0], qraw[st][1][1], q1h, q1l);
+        }
         float bb[8] = {braw[st][0].x, braw[st][0].y, braw[st][0].z, braw[st][0].w, braw[st][1].x, braw[st][1].y, braw[st][1].z, braw[st][1].w};
         if (!bias) {
 #pragma unroll
@@ -189,10 +211,10 @@ __global__ __launch_bounds__(256) void delta_add_kernel(bf16* qbuf, bf16* vbuf, 
 #pragma unroll
         for (int k = 0; k < DA_RG; ++k) {
             f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-            a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0l, th[k], a0, 0, 0, 0);
+            if constexpr (!Q16) a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0l, th[k], a0, 0, 0, 0);
             a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0h, tl[k], a0, 0, 0, 0);
             a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0h, th[k], a0, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1l, th[k], a1, 0, 0, 0);
+            if constexpr (!Q16) a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1l, th[k], a1, 0, 0, 0);
             a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1h, tl[k], a1, 0, 0, 0);
             a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1h, th[k], a1, 0, 0, 0);
             // lane: column rr, rows 4g+r of each tile -> e = eb + 8g + r (tile 0), eb + 8g + 4 + r (tile 1)
@@ -598,14 +620,14 @@ int pevit_launch_prep_lora(const float* a1q, const float* a2q, const float* a1v,
     return 0;
 }
 
-int pevit_launch_delta_add(bf16* qbuf, bf16* vbuf, const float* t, const float* q32, const float* bias, float ascale,
+int pevit_launch_delta_add(bf16* qbuf, bf16* vbuf, const float* t, const float* q32, const bf16* q16, const float* bias, float ascale,
                            int B, int N, int E, hipStream_t s, int f32) {
     if (E % DA_COLS) { pevit_set_error("delta_add: width %d must be a multiple of %d", E, DA_COLS); return -1; }
     const int T = B * N;
     const int waves = ceil_div(T, 16 * DA_RG) * (E / DA_COLS);
-    if (f32) hipLaunchKernelGGL(delta_add_kernel<float>, dim3(ceil_div(waves, 4), 2), dim3(256), 0, s, qbuf, vbuf, t, q32, bias, ascale,
+    if (f32) hipLaunchKernelGGL(delta_add_kernel<float>, dim3(ceil_div(waves, 4), 2), dim3(256), 0, s, qbuf, vbuf, t, q32, q16, bias, ascale,
                                 B, N, E);
-    else hipLaunchKernelGGL(delta_add_kernel<bf16>, dim3(ceil_div(waves, 4), 2), dim3(256), 0, s, qbuf, vbuf, t, q32, bias, ascale,
+    else hipLaunchKernelGGL(delta_add_kernel<bf16>, dim3(ceil_div(waves, 4), 2), dim3(256), 0, s, qbuf, vbuf, t, q32, q16, bias, ascale,
                             B, N, E);
     LAUNCH_OK("delta_add_kernel");
     return 0;

@@ -341,24 +341,40 @@ class HipEngine:
             raise _lib.PevitError("pevit_streamk_error failed")
         return rc > 0
 
-    def profile_gemms(self, fn, max_launches=4096):
-        """Run ``fn()`` with HIP events around every GEMM launch; returns (ms, flops, launches); the algorithmic
-        operand+result bytes of those launches are left in ``self.last_profile_bytes``."""
-        _lib.check(self.lib.pevit_profile_begin(self._ctx, max_launches), "pevit_profile_begin")
-        fn()
-        ms, fl, by, n = C.c_double(), C.c_double(), C.c_double(), C.c_int()
-        _lib.check(self.lib.pevit_profile_end(self._ctx, C.byref(ms), C.byref(fl), C.byref(by), C.byref(n)),
-                   "pevit_profile_end")
+    PROF_KINDS = {0: "ln_fwd", 1: "ln_bwd", 2: "attn_fwd", 3: "attn_bwd", 4: "delta_add", 5: "lowrank_u", 6: "lowrank_grad",
+                  7: "im2col", 8: "lowrank_bwd", 9: "attn_fwd_delta"}     # include/pevit_hip.h: enum pevit_prof_kind
+
+    def profile_gemms(self, fn, max_launches=8192, all_kernels=False):
+        """Run ``fn()`` with HIP events around every GEMM launch; returns (ms, flops, launches) of the GEMM family; the
+        algorithmic operand+result bytes of those launches are left in ``self.last_profile_bytes``, the per-shape table in
+        ``self.last_profile_by_shape``.  ``all_kernels``: the HBM-bound kernels of the step are bracketed too and land in
+        ``self.last_profile_hbm`` = {kernel: [launches, ms, algorithmic bytes]}."""
+        self.tune("profile_all", int(all_kernels))
+        try:
+            _lib.check(self.lib.pevit_profile_begin(self._ctx, max_launches), "pevit_profile_begin")
+            fn()
+            ms, fl, by, n = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+            _lib.check(self.lib.pevit_profile_end(self._ctx, C.byref(ms), C.byref(fl), C.byref(by), C.byref(n)),
+                       "pevit_profile_end")
+        finally:
+            self.tune("profile_all", 0)
         self.last_profile_bytes = by.value
-        # per launch: (epilogue, M, N, K) -> [launches, ms, flops]
-        per = {}
-        one_ms, one_fl, shape = C.c_double(), C.c_double(), (C.c_int * 4)()
+        # per launch: (epilogue, M, N, K) -> [launches, ms, flops, bytes]
+        per, hbm, n_gemm = {}, {}, 0
+        one_ms, one_fl, one_by, shape = C.c_double(), C.c_double(), C.c_double(), (C.c_int * 4)()
         for i in range(n.value):
             _lib.check(self.lib.pevit_profile_launch(self._ctx, i, C.byref(one_ms), C.byref(one_fl), shape), "pevit_profile_launch")
-            e = per.setdefault(tuple(shape), [0, 0.0, 0.0])
-            e[0] += 1; e[1] += one_ms.value; e[2] += one_fl.value
+            _lib.check(self.lib.pevit_profile_launch_bytes(self._ctx, i, C.byref(one_by)), "pevit_profile_launch_bytes")
+            if shape[0] >= 100:
+                e = hbm.setdefault(self.PROF_KINDS.get(shape[0] - 100, str(shape[0] - 100)), [0, 0.0, 0.0])
+                e[0] += 1; e[1] += one_ms.value; e[2] += one_by.value
+            else:
+                n_gemm += 1
+                e = per.setdefault(tuple(shape), [0, 0.0, 0.0, 0.0])
+                e[0] += 1; e[1] += one_ms.value; e[2] += one_fl.value; e[3] += one_by.value
         self.last_profile_by_shape = per
-        return ms.value, fl.value, n.value
+        self.last_profile_hbm = hbm
+        return ms.value, fl.value, n_gemm
 
     def reset_optimizer(self):
         self._steps = 0

