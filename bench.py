@@ -81,6 +81,68 @@ def cpu_baseline(seconds_budget=25.0):
                       f"logical cores of {cpu_model()}"}
 
 
+def harness_throughput(dev, steps=20):
+    """images/s of the reference-API path: ``train_one`` (kadaptation_clip.py:321-361 -> pevit_amd/evaluation/_harness.py) over a
+    synthetic TensorLoader of ``steps`` full batches, epoch-end read-back and train metric included, at bs 128 and bs 64, with
+    the set resident in HBM as f32 and with uint8 pixels on the HOST (pinned staging, uploaded one batch ahead on a side stream,
+    ToTensor + Normalize inside the engine) -- next to the bare engine step on a resident batch of the same size."""
+    import dataclasses
+    import tempfile
+    from pevit_amd.config import vitb32_clip_config
+    from pevit_amd.evaluation import _harness, kadaptation_clip as mod
+    from pevit_amd.evaluation.dataloader import TensorLoader, _Tensors
+    from pevit_amd.optim import build_optimizer
+    from pevit_amd.synth import ARCHS, synth_state_dict
+    arch = dataclasses.replace(ARCHS["ViT-B/32"], text_layers=1)          # the text tower is not on this path: keep the file small
+    out = {"how": f"train_one over {steps} full batches of a synthetic TensorLoader (shuffle on, fused engine step, one read-back per "
+                  "epoch, train accuracy computed), second epoch timed; engine_step = eng.train_step on one resident batch"}
+    with tempfile.TemporaryDirectory() as tmp:
+        ckpt = os.path.join(tmp, "vitb32_synth.pt")
+        torch.save(synth_state_dict(arch, seed=2, text_tower=True), ckpt)
+        cfg = vitb32_clip_config()
+        cfg.MODEL.NAME = ckpt
+        cfg.DATASET.NUM_CLASSES = 100
+        cfg.TRAIN.LR, cfg.TRAIN.WD = 0.01, 1e-6
+        cfg.TRAIN.BATCH_SIZE_PER_GPU = cfg.TEST.BATCH_SIZE_PER_GPU = 128
+        cfg.GPUS = (dev.index or 0,)
+        model = mod.Classifier(cfg, 0).cuda(dev)
+        crit = torch.nn.CrossEntropyLoss()
+        opt = build_optimizer(cfg, model)
+        assert model.can_fuse(crit, opt)
+        g = torch.Generator().manual_seed(0)
+        for bs in (128, 64):
+            n = steps * bs
+            u8 = torch.randint(0, 256, (n, 3, 224, 224), dtype=torch.uint8, generator=g)
+            labels = torch.randint(0, 100, (n,), generator=g)
+            mean = torch.tensor(cfg.INPUT.MEAN, device=dev).view(1, 3, 1, 1); std = torch.tensor(cfg.INPUT.STD, device=dev).view(1, 3, 1, 1)
+            f32_dev = (u8.to(dev).float() / 255.0 - mean) / std
+            res = {}
+            for name, imgs, lbl in (("resident_f32", f32_dev, labels.to(dev)), ("host_uint8_prefetched", u8, labels)):
+                loader = TensorLoader(_Tensors(imgs, lbl), batch_size=bs, shuffle=True)
+                mod.train_one(loader, model, crit, opt, 0, cfg)                       # warm-up epoch (staging buffers, workspace)
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                mod.train_one(loader, model, crit, opt, 1, cfg)
+                torch.cuda.synchronize(dev)
+                res[name] = n / (time.perf_counter() - t0)
+            eng = model.engine()
+            xb, yb = f32_dev[:bs].contiguous(), labels[:bs].to(dev)
+            for _ in range(5):
+                eng.train_step(xb, yb, lr=0.01, momentum=0.9, weight_decay=1e-6)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(2 * steps):
+                eng.train_step(xb, yb, lr=0.01, momentum=0.9, weight_decay=1e-6)
+            torch.cuda.synchronize(dev)
+            res["engine_step_resident"] = 2 * steps * bs / (time.perf_counter() - t0)
+            res["harness_over_engine"] = {k: res[k] / res["engine_step_resident"] for k in ("resident_f32", "host_uint8_prefetched")}
+            out[f"bs{bs}"] = res
+            del f32_dev, u8
+        del model, opt
+        _harness._BACKBONES.clear()
+    return out
+
+
 def cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -148,6 +210,7 @@ def main():
     ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8", "fp8-act"],
                     help="frozen block weights: bf16, or e4m3 codes + per-channel scales (BASELINE config 5 with --arch ViT-L/14)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-harness", action="store_true", help="skip the reference-API (train_one) throughput measurement")
     ap.add_argument("--cpu-sweep", action="store_true", help="only time the CPU baseline at 8/16/32/64/128 threads and exit")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=INT",
                     help="library tuning knob for A/B runs, e.g. gemm_big=0 (see pevit_tune)")
@@ -342,6 +405,10 @@ def main():
                                         "executed_gemm_tflop_per_step": gemm_flops / prof_steps / 1e12,
                                         "executed_gemm_frac_of_peak": gemm_flops / prof_steps / 1e12 / (ms * 1e-3) / peak}},
         }
+        if world == 1 and not args.no_harness and headline:
+            del eng, images, labels
+            torch.cuda.empty_cache()
+            out["harness_images_per_sec"] = harness_throughput(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

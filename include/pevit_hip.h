@@ -156,6 +156,15 @@ int pevit_zero_grads(pevit_ctx* ctx, void* stream);
 /* flags: bit 0 = first step of the run (momentum buffer := gradient, like torch), bit 1 = Nesterov momentum */
 int pevit_sgd_step(pevit_ctx* ctx, void* stream, float lr, float momentum, float weight_decay,
                    float grad_scale, int flags);
+/* uint8 pixels (B,3,R,R) instead of preprocessed f32: the dataset transforms of the reference (ToTensor + Normalize with
+ * INPUT.MEAN / INPUT.STD: feature.py:537-542, resources/model/vitb32_CLIP.yaml:4-6), x = (u8 / 255 - mean[c]) / std[c], run inside
+ * the patch gather -- bit for bit the f32 values `(x.float() / 255 - mean) / std` gives on the host; a quarter of the bytes
+ * to upload.  pevit_set_input_norm must have been called on the context. */
+int pevit_set_input_norm(pevit_ctx* ctx, const float* mean3, const float* std3);
+int pevit_visual_forward_u8(pevit_ctx* ctx, void* stream, const uint8_t* images, float* feat, int batch, int save_for_backward);
+int pevit_train_forward_backward_u8(pevit_ctx* ctx, void* stream, const uint8_t* images, const int64_t* labels,
+                                    float* running_mean, float* running_var, int bn_training, float* logits,
+                                    float* loss, int batch);
 /* whole fine-tune step: zero_grad -> forward -> CE -> backward -> (caller all-reduces) -> SGD */
 int pevit_train_forward_backward(pevit_ctx* ctx, void* stream, const float* images, const int64_t* labels,
                                  float* running_mean, float* running_var, int bn_training, float* logits,
@@ -256,6 +265,8 @@ int pevit_op_chain_bottleneck(void* stream, int method, const float* Gd, const f
                               const float* params, float* grads, int E, size_t off0, size_t off1, size_t off2, size_t off3);
 /* images (B,3,R,R) f32 -> patches [B*(R/P)^2][Kpad] bf16, k = c*P*P + py*P + px, zero padded (conv1, model.py:1036) */
 int pevit_op_im2col(void* stream, const float* images, void* patches_bf16, int B, int R, int P, int Kpad);
+int pevit_op_im2col_u8(void* stream, const uint8_t* images, const float* mean3, const float* std3, void* patches_bf16, int B,
+                       int R, int P, int Kpad);
 /* knobs for A/B measurements, held in the context (ctx == NULL: the process-wide defaults that only the
  * context-free pevit_op_* entry points above use): "gemm_config" (-1 = per-problem heuristic, 0..5 = force a tile
  * configuration: 128x128, 64x128, 64x64 with 4 waves; 256x128, 256x256, 320x256 with 8 waves; 6 = 128x64 with 4 waves),

@@ -55,6 +55,9 @@ SIGNATURES = {
     "pevit_zero_grads": (c_int, [P, P]),
     "pevit_sgd_step": (c_int, [P, P, c_float, c_float, c_float, c_float, c_int]),
     "pevit_train_forward_backward": (c_int, [P, P, P, P, P, P, c_int, P, P, c_int]),
+    "pevit_set_input_norm": (c_int, [P, P, P]),
+    "pevit_visual_forward_u8": (c_int, [P, P, P, P, c_int, c_int]),
+    "pevit_train_forward_backward_u8": (c_int, [P, P, P, P, P, P, c_int, P, P, c_int]),
     "pevit_profile_begin": (c_int, [P, c_int]),
     "pevit_profile_end": (c_int, [P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_int)]),
     "pevit_profile_launch": (c_int, [P, c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_int)]),
@@ -90,6 +93,7 @@ SIGNATURES = {
     "pevit_op_prep_bottleneck": (c_int, [P, c_int, P, P, P, P, P, P, P, P, P, c_int]),
     "pevit_op_chain_bottleneck": (c_int, [P, c_int, P, P, P, P, P, c_int, c_size_t, c_size_t, c_size_t, c_size_t]),
     "pevit_op_im2col": (c_int, [P, P, P, c_int, c_int, c_int, c_int]),
+    "pevit_op_im2col_u8": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int]),
     "pevit_tune": (c_int, [P, c_char_p, c_int]),
     "pevit_streamk_error": (c_int, [P, P]),
     "pevit_streamk_status": (c_int, [P, P, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),

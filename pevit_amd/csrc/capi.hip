@@ -89,6 +89,8 @@ struct pevit_ctx {
     size_t n_tower = 0, n_total = 0;
     size_t p_layer0 = 0, p_layer_stride = 0;     // offsets in floats
     size_t p_head_w = 0, p_head_b = 0;
+    float img_mean[3] = {0.f, 0.f, 0.f}, img_std[3] = {1.f, 1.f, 1.f};   // pevit_set_input_norm: preprocessing of uint8 pixels
+    bool img_norm_set = false;
     int saved_batch = 0;
     int saved_kind = 0;       // which forward the saved activations belong to: 1 = transformer seam, 2 = visual (class-token pruned)
     // optional per-GEMM timing (HIP events on the caller's stream), see pevit_profile_begin
@@ -995,17 +997,45 @@ extern "C" int pevit_load_phm_rule(pevit_ctx* c, void* stream, const float* phm_
     return 0;
 }
 
+// Preprocessing constants of the uint8 entry points: x = (u8 / 255 - mean[c]) / std[c], the dataset transforms of the reference
+// (ToTensor + Normalize(INPUT.MEAN, INPUT.STD), feature.py:537-542; resources/model/vitb32_CLIP.yaml:4-6)
+extern "C" int pevit_set_input_norm(pevit_ctx* c, const float* mean3, const float* std3) {
+    if (!c || !mean3 || !std3) { pevit_set_error("set_input_norm: null argument"); return -1; }
+    for (int i = 0; i < 3; ++i) {
+        if (!(std3[i] > 0.f)) { pevit_set_error("set_input_norm: std[%d] = %g must be positive", i, (double)std3[i]); return -1; }
+        c->img_mean[i] = mean3[i]; c->img_std[i] = std3[i];
+    }
+    c->img_norm_set = true;
+    return 0;
+}
+
 // images (B,3,R,R) f32 -> feat (B,D) f32                               model.py:1034-1051
+static int visual_forward_impl(pevit_ctx* c, void* stream, const void* images_any, int u8, float* feat, int B, int save_for_backward);
 extern "C" int pevit_visual_forward(pevit_ctx* c, void* stream, const float* images, float* feat, int B,
                                     int save_for_backward) {
+    return visual_forward_impl(c, stream, images, 0, feat, B, save_for_backward);
+}
+// the same from uint8 pixels (B,3,R,R): the reference's ToTensor + Normalize run inside the patch gather (pevit_set_input_norm)
+extern "C" int pevit_visual_forward_u8(pevit_ctx* c, void* stream, const uint8_t* images, float* feat, int B,
+                                       int save_for_backward) {
+    if (c && !c->img_norm_set) { pevit_set_error("visual_forward_u8: call pevit_set_input_norm first"); return -1; }
+    return visual_forward_impl(c, stream, images, 1, feat, B, save_for_backward);
+}
+static int visual_forward_impl(pevit_ctx* c, void* stream, const void* images_any, int u8, float* feat, int B, int save_for_backward) {
+    const float* images = (const float*)images_any;
     CHECK(check_ready(c, B, "visual_forward"));
     hipStream_t s = (hipStream_t)stream;
     size_t total; layout_workspace(c, B, c->sav, &total, c);
     char* W = c->ws; char* A = c->arena;
     const int E = c->E, N = c->N, T = B * N;
     float* xpre = at<float>(W, c->w_dxn);               // scratch, free during the forward pass
-    PROF(c, s, PEVIT_PROF_IM2COL, B, (double)B * 3 * c->R * c->R * 4 + (double)B * c->G2 * c->Kpatch * c->es,
-         pevit_launch_im2col(images, at<bf16>(W, c->w_patches), B, c->R, c->P, c->Kpatch, s, c->f32));
+    if (u8)
+        PROF(c, s, PEVIT_PROF_IM2COL, B, (double)B * 3 * c->R * c->R * 1 + (double)B * c->G2 * c->Kpatch * c->es,
+             pevit_launch_im2col_u8((const unsigned char*)images_any, c->img_mean, c->img_std, at<bf16>(W, c->w_patches), B, c->R, c->P,
+                                    c->Kpatch, s, c->f32));
+    else
+        PROF(c, s, PEVIT_PROF_IM2COL, B, (double)B * 3 * c->R * c->R * 4 + (double)B * c->G2 * c->Kpatch * c->es,
+             pevit_launch_im2col(images, at<bf16>(W, c->w_patches), B, c->R, c->P, c->Kpatch, s, c->f32));
     CHECK(pevit_launch_cls_row(at<float>(A, c->a_cls), at<float>(A, c->a_pos), xpre, B, N, E, s));
     {
         GemmParams p = gp(at<bf16>(W, c->w_patches), c->Kpatch, at<bf16>(A, c->a_conv), c->Kpatch, E, B * c->G2, E, c->Kpatch);
@@ -1094,12 +1124,24 @@ extern "C" int pevit_head_forward_backward(pevit_ctx* c, void* stream, const flo
                              logits, at<float>(W, c->w_dlogits), at<float>(W, c->w_dybn), loss, dfeat, B, c->D, c->C, s);
 }
 
+static int train_fb_impl(pevit_ctx* c, void* stream, const void* images, int u8, const int64_t* labels, float* running_mean,
+                         float* running_var, int bn_training, float* logits, float* loss, int B);
 extern "C" int pevit_train_forward_backward(pevit_ctx* c, void* stream, const float* images, const int64_t* labels,
                                             float* running_mean, float* running_var, int bn_training, float* logits,
                                             float* loss, int B) {
+    return train_fb_impl(c, stream, images, 0, labels, running_mean, running_var, bn_training, logits, loss, B);
+}
+extern "C" int pevit_train_forward_backward_u8(pevit_ctx* c, void* stream, const uint8_t* images, const int64_t* labels,
+                                               float* running_mean, float* running_var, int bn_training, float* logits,
+                                               float* loss, int B) {
+    if (c && !c->img_norm_set) { pevit_set_error("train_forward_backward_u8: call pevit_set_input_norm first"); return -1; }
+    return train_fb_impl(c, stream, images, 1, labels, running_mean, running_var, bn_training, logits, loss, B);
+}
+static int train_fb_impl(pevit_ctx* c, void* stream, const void* images, int u8, const int64_t* labels, float* running_mean,
+                         float* running_var, int bn_training, float* logits, float* loss, int B) {
     CHECK(check_ready(c, B, "train_forward_backward"));
     CHECK(pevit_zero_grads(c, stream));
-    CHECK(pevit_visual_forward(c, stream, images, nullptr, B, 1));
+    CHECK(visual_forward_impl(c, stream, images, u8, nullptr, B, 1));
     float* feat = at<float>(c->ws, c->w_feat);
     float* dfeat = at<float>(c->ws, c->w_dfeat);
     CHECK(pevit_head_forward_backward(c, stream, feat, labels, running_mean, running_var, bn_training, logits, loss,
@@ -1340,6 +1382,10 @@ extern "C" int pevit_op_chain_bottleneck(void* stream, int method, const float* 
         return pevit_launch_chain_compacter(Gd, Gu, rule, params, grads, E, 1, 0, 0, off0, off1, off2, off3, (hipStream_t)stream);
     pevit_set_error("chain_bottleneck: method %d is not a post-MLP adapter", method);
     return -1;
+}
+extern "C" int pevit_op_im2col_u8(void* stream, const uint8_t* images, const float* mean3, const float* std3, void* patches_bf16, int B,
+                                  int R, int P, int Kpad) {
+    return pevit_launch_im2col_u8(images, mean3, std3, (bf16*)patches_bf16, B, R, P, Kpad, (hipStream_t)stream);
 }
 extern "C" int pevit_op_im2col(void* stream, const float* images, void* patches_bf16, int B, int R, int P, int Kpad) {
     return pevit_launch_im2col(images, (bf16*)patches_bf16, B, R, P, Kpad, (hipStream_t)stream);

@@ -182,6 +182,9 @@ int pevit_launch_lowrank_grad_f32(const float* xn, int ldx, const float* u32, co
 
 // ---- stem_head.hip -----------------------------------------------------------------
 int pevit_launch_im2col(const float* img, bf16* out, int B, int R, int P, int Kp, hipStream_t s, int f32 = 0);
+// uint8 pixels with ToTensor + Normalize folded in: x = (u8 / 255 - mean[c]) / std[c] (feature.py:537-542)
+int pevit_launch_im2col_u8(const unsigned char* img, const float* mean3, const float* std3, bf16* out, int B, int R, int P, int Kp,
+                           hipStream_t s, int f32 = 0);
 int pevit_launch_conv_weight(const float* w, bf16* out, int E, int K, int Kp, hipStream_t s, int f32 = 0);
 int pevit_launch_cls_row(const float* cls, const float* pos, float* x, int B, int N, int E, hipStream_t s);
 int pevit_launch_head(const float* feat, const int64_t* labels, const float* W, const float* bias, float* gW, float* gb,

@@ -61,6 +61,60 @@ __global__ void im2col8_kernel(const float* __restrict__ img, bf16* __restrict__
     }
 }
 
+// The same gather from uint8 pixels with the reference's preprocessing folded in: ToTensor + Normalize of the dataset transforms
+// (feature.py:537-542, vitb32_CLIP.yaml INPUT.MEAN / STD), x = (u8 / 255 - mean[c]) / std[c] in f32 with correctly rounded
+// divisions -- bit for bit what `(x.float() / 255.0 - mean) / std` gives on the host -- then the bf16 rounding of the patches.
+// A quarter of the bytes to upload and to read here (8 pixels = one 8-byte load).  norm = {mean[3], std[3]}.
+struct PixelNorm { float mean[3], stdv[3]; };
+template <typename ST>
+__global__ void im2col8_u8_kernel(const unsigned char* __restrict__ img, bf16* __restrict__ out, int B, int R, int P, int Kp,
+                                  PixelNorm nm) {
+    const int G = R / P, G2 = G * G, K = 3 * P * P, K8 = Kp / 8;
+    const size_t total = (size_t)B * G2 * K8;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(idx % K8) * 8;
+        const size_t row = idx / K8;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (k < K) {
+            const int b = (int)(row / G2), gidx = (int)(row - (size_t)b * G2);
+            const int gy = gidx / G, gx = gidx - gy * G;
+            const int c = k / (P * P), rem = k - c * P * P;
+            const int i = rem / P, j = rem - i * P;
+            const uint2 raw = *reinterpret_cast<const uint2*>(img + (((size_t)b * 3 + c) * R + gy * P + i) * R + gx * P + j);
+            const float m = nm.mean[c], sd = nm.stdv[c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const unsigned px = ((u < 4 ? raw.x : raw.y) >> (8 * (u & 3))) & 255u;
+                v[u] = ((float)px / 255.0f - m) / sd;
+            }
+        }
+        st_store4<ST>(out, row * Kp + k, v[0], v[1], v[2], v[3]);
+        st_store4<ST>(out, row * Kp + k + 4, v[4], v[5], v[6], v[7]);
+    }
+}
+template <typename ST>
+__global__ void im2col_u8_kernel(const unsigned char* __restrict__ img, bf16* __restrict__ out, int B, int R, int P, int Kp, PixelNorm nm) {
+    const int G = R / P, G2 = G * G, K = 3 * P * P;
+    const size_t total = (size_t)B * G2 * (Kp / 2);
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int k2 = (int)(idx % (Kp / 2));
+        const size_t row = idx / (Kp / 2);
+        const int b = (int)(row / G2), gidx = (int)(row - (size_t)b * G2);
+        const int gy = gidx / G, gx = gidx - gy * G;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int k = 2 * k2 + u;
+            float v = 0.f;
+            if (k < K) {
+                const int c = k / (P * P), rem = k - c * P * P;
+                const int i = rem / P, j = rem - i * P;
+                v = ((float)img[(((size_t)b * 3 + c) * R + gy * P + i) * R + gx * P + j] / 255.0f - nm.mean[c]) / nm.stdv[c];
+            }
+            st_store<ST>(out, row * Kp + 2 * k2 + u, v);
+        }
+    }
+}
+
 // conv1.weight (E, 3, P, P) f32 -> [E][Kp] bf16 zero padded
 template <typename ST>
 __global__ void conv_weight_kernel(const float* __restrict__ w, bf16* __restrict__ out, int E, int K, int Kp) {
@@ -316,6 +370,25 @@ int pevit_launch_im2col(const float* img, bf16* out, int B, int R, int P, int Kp
     if (f32) hipLaunchKernelGGL(im2col_kernel<float>, dim3(blocks), dim3(256), 0, s, img, out, B, R, P, Kp);
     else hipLaunchKernelGGL(im2col_kernel<bf16>, dim3(blocks), dim3(256), 0, s, img, out, B, R, P, Kp);
     LAUNCH_OK("im2col_kernel");
+    return 0;
+}
+int pevit_launch_im2col_u8(const unsigned char* img, const float* mean3, const float* std3, bf16* out, int B, int R, int P, int Kp,
+                           hipStream_t s, int f32) {
+    PixelNorm nm;
+    for (int c = 0; c < 3; ++c) { nm.mean[c] = mean3[c]; nm.stdv[c] = std3[c]; }
+    if (P % 8 == 0 && R % 8 == 0) {
+        const size_t total8 = (size_t)B * (R / P) * (R / P) * (Kp / 8);
+        const int blocks8 = (int)((total8 + 255) / 256 > 16384 ? 16384 : (total8 + 255) / 256);
+        if (f32) hipLaunchKernelGGL(im2col8_u8_kernel<float>, dim3(blocks8), dim3(256), 0, s, img, out, B, R, P, Kp, nm);
+        else hipLaunchKernelGGL(im2col8_u8_kernel<bf16>, dim3(blocks8), dim3(256), 0, s, img, out, B, R, P, Kp, nm);
+        LAUNCH_OK("im2col8_u8_kernel");
+        return 0;
+    }
+    const size_t total = (size_t)B * (R / P) * (R / P) * (Kp / 2);
+    const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    if (f32) hipLaunchKernelGGL(im2col_u8_kernel<float>, dim3(blocks), dim3(256), 0, s, img, out, B, R, P, Kp, nm);
+    else hipLaunchKernelGGL(im2col_u8_kernel<bf16>, dim3(blocks), dim3(256), 0, s, img, out, B, R, P, Kp, nm);
+    LAUNCH_OK("im2col_u8_kernel");
     return 0;
 }
 int pevit_launch_conv_weight(const float* w, bf16* out, int E, int K, int Kp, hipStream_t s, int f32) {

@@ -205,14 +205,22 @@ class HipEngine:
                     v.copy_(sd[name].to(device=self.device, dtype=torch.float32).view_as(v))
 
     # ------------------------------------------------------------------ hot path
+    def set_input_normalization(self, mean, std):
+        """Preprocessing of uint8 batches, x = (u8 / 255 - mean[c]) / std[c] (the reference's ToTensor + Normalize,
+        feature.py:537-542 with INPUT.MEAN / INPUT.STD), applied inside the patch gather of the engine."""
+        m = (C.c_float * 3)(*[float(v) for v in mean]); sd = (C.c_float * 3)(*[float(v) for v in std])
+        _lib.check(self.lib.pevit_set_input_norm(self._ctx, m, sd), "pevit_set_input_norm")
+        self._input_norm = (tuple(float(v) for v in mean), tuple(float(v) for v in std))
+
     def _check_batch(self, images, labels=None):
-        """The C ABI takes raw pointers: reject anything that is not what it will read (f32 NCHW images and int64 class
-        indices, contiguous, on this engine's device)."""
+        """The C ABI takes raw pointers: reject anything that is not what it will read (f32 NCHW images -- or uint8 pixels once
+        set_input_normalization has been called -- and int64 class indices, contiguous, on this engine's device)."""
         a = self.arch
-        if images.device != self.device or images.dtype != torch.float32 or not images.is_contiguous() or \
+        ok_dtype = images.dtype == torch.float32 or (images.dtype == torch.uint8 and getattr(self, "_input_norm", None) is not None)
+        if images.device != self.device or not ok_dtype or not images.is_contiguous() or \
                 tuple(images.shape[1:]) != (3, a.resolution, a.resolution):
-            raise _lib.PevitError(f"images must be a contiguous float32 tensor (B,3,{a.resolution},{a.resolution}) on {self.device}; "
-                                  f"got {tuple(images.shape)} {images.dtype} on {images.device}")
+            raise _lib.PevitError(f"images must be a contiguous float32 tensor (B,3,{a.resolution},{a.resolution}) on {self.device} "
+                                  f"(or uint8 after set_input_normalization); got {tuple(images.shape)} {images.dtype} on {images.device}")
         if images.shape[0] > self.max_batch:
             raise _lib.PevitError(f"batch {images.shape[0]} exceeds the bound workspace ({self.max_batch}): call ensure_batch")
         if labels is not None and (labels.device != self.device or labels.dtype != torch.int64 or not labels.is_contiguous()
@@ -268,14 +276,14 @@ class HipEngine:
 
     def visual_forward(self, images: torch.Tensor, save: bool = True) -> torch.Tensor:
         B = images.shape[0]
-        img = images.contiguous().float()
+        img = images.contiguous() if images.dtype == torch.uint8 else images.contiguous().float()
         self._check_batch(img)
         self.forward_generation += 1
         for l in range(self.arch.layers):
             self.block_generation[l] = self.block_generation.get(l, 0) + 1
         feat = torch.empty((B, self.arch.embed_dim), dtype=torch.float32, device=self.device)
-        _lib.check(self.lib.pevit_visual_forward(self._ctx, _lib.stream_ptr(), _lib.ptr(img), _lib.ptr(feat), B, int(save)),
-                   "pevit_visual_forward")
+        fn = self.lib.pevit_visual_forward_u8 if img.dtype == torch.uint8 else self.lib.pevit_visual_forward
+        _lib.check(fn(self._ctx, _lib.stream_ptr(), _lib.ptr(img), _lib.ptr(feat), B, int(save)), "pevit_visual_forward")
         return feat
 
     def visual_backward(self, dfeat: torch.Tensor):
@@ -297,18 +305,28 @@ class HipEngine:
     def zero_grad(self):
         _lib.check(self.lib.pevit_zero_grads(self._ctx, _lib.stream_ptr()), "pevit_zero_grads")
 
-    def forward_backward(self, images, labels, bn_training=True):
+    def forward_backward(self, images, labels, bn_training=True, logits_out=None, loss_out=None):
         """zero_grad -> forward -> CE -> backward; gradients land in ``self.grads``.  Returns
         (logits, loss) as device tensors without synchronising (the reference's
-        ``loss.item()`` per step, kadaptation_clip.py:354, is the caller's choice)."""
+        ``loss.item()`` per step, kadaptation_clip.py:354, is the caller's choice).  ``logits_out`` (B, C) / ``loss_out`` (1,):
+        caller-owned f32 destinations (an epoch buffer of the harness) instead of the engine's per-step buffers, which the
+        next step overwrites."""
         B = images.shape[0]
         self._check_batch(images, labels)
         self.forward_generation += 1
-        _lib.check(self.lib.pevit_train_forward_backward(
-            self._ctx, _lib.stream_ptr(), _lib.ptr(images), _lib.ptr(labels), _lib.ptr(self.running_mean),
-            _lib.ptr(self.running_var), int(bn_training), _lib.ptr(self._logits), _lib.ptr(self._loss), B),
-            "pevit_train_forward_backward")
-        return self._logits[:B], self._loss
+        logits = self._logits[:B] if logits_out is None else self._out_buf(logits_out, (B, self.num_classes))
+        loss = self._loss if loss_out is None else self._out_buf(loss_out, (1,))
+        fn = self.lib.pevit_train_forward_backward_u8 if images.dtype == torch.uint8 else self.lib.pevit_train_forward_backward
+        _lib.check(fn(self._ctx, _lib.stream_ptr(), _lib.ptr(images), _lib.ptr(labels), _lib.ptr(self.running_mean),
+                      _lib.ptr(self.running_var), int(bn_training), _lib.ptr(logits), _lib.ptr(loss), B),
+                   "pevit_train_forward_backward")
+        return logits, loss
+
+    def _out_buf(self, t, shape):
+        if t.device != self.device or t.dtype != torch.float32 or not t.is_contiguous() or tuple(t.shape) != tuple(shape):
+            raise _lib.PevitError(f"output buffer must be a contiguous float32 tensor {tuple(shape)} on {self.device}; got "
+                                  f"{tuple(t.shape)} {t.dtype} on {t.device}")
+        return t
 
     def sgd_step(self, lr, momentum=0.9, weight_decay=0.0, grad_scale=1.0, nesterov=False):
         flags = int(self._steps == 0) | (2 if nesterov else 0)
@@ -388,17 +406,21 @@ class HipEngine:
         self.running_mean.zero_(); self.running_var.fill_(1.0)
 
     def train_step(self, images, labels, lr, momentum=0.9, weight_decay=0.0, bn_training=True, process_group=None,
-                   world_size=1, nesterov=False):
+                   world_size=1, nesterov=False, logits_out=None, loss_out=None):
         """One reference ``train_one`` iteration (kadaptation_clip.py:347-353).  With DP the flat gradient buffer
         is the only thing that crosses xGMI (the frozen backbone never does), in two buckets: the head gradients
         (available right after the head backward) are all-reduced while the tower backward runs, the adapter
         gradients (the per-layer partials are chained onto the reference's tensors at the very end of the
         backward) after it."""
         if world_size <= 1:
-            logits, loss = self.forward_backward(images, labels, bn_training)
+            logits, loss = self.forward_backward(images, labels, bn_training, logits_out, loss_out)
             self.sgd_step(lr, momentum, weight_decay, 1.0, nesterov)
             return logits, loss
         logits, loss = self.forward_backward_dp(images, labels, bn_training, process_group)
+        if logits_out is not None:
+            logits_out.copy_(logits)
+        if loss_out is not None:
+            loss_out.copy_(loss)
         self.sgd_step(lr, momentum, weight_decay, 1.0 / world_size, nesterov)
         return logits, loss
 

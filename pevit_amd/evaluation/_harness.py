@@ -48,8 +48,11 @@ def trainable_by_name(method: str, name: str) -> bool:
     return "adapter" in name
 
 
-def gpu_gc():
-    gc.collect()
+def gpu_gc(full=True):
+    """kadaptation_clip.py:72-75.  ``full=False`` (between the ~90 runs of a sweep): a young-generation collection only --
+    the Classifier of a run holds no reference cycle and is freed by its ``del``; a full collection walks the whole CLIP module
+    tree kept alive by the backbone cache and costs 0.07 s of a 0.3 s run."""
+    gc.collect() if full else gc.collect(0)
     torch.cuda.empty_cache()
 
 
@@ -212,6 +215,8 @@ class ClassifierBase(nn.Module):
         wf = config.MODEL.get("WEIGHT_FORMAT", None) if hasattr(config.MODEL, "get") else None
         if wf is not None:
             visual.weight_format = str(wf)
+        if hasattr(config, "INPUT") and getattr(config.INPUT, "MEAN", None) is not None:
+            visual.set_input_normalization(config.INPUT.MEAN, config.INPUT.STD)      # uint8 batches: ToTensor + Normalize in the engine
         visual._num_classes = output_dim
         visual._max_batch = max(int(config.TRAIN.BATCH_SIZE_PER_GPU), int(config.TEST.BATCH_SIZE_PER_GPU))
         if visual._engine is not None and (visual._engine.num_classes != output_dim or
@@ -240,7 +245,7 @@ class ClassifierBase(nn.Module):
         return eng
 
     def forward(self, img):
-        pdtype = img.dtype
+        pdtype = torch.float32 if img.dtype == torch.uint8 else img.dtype
         if img.is_cuda:
             self.engine()
         feature = self.backbone(img).to(pdtype)
@@ -276,16 +281,29 @@ class ClassifierBase(nn.Module):
         theirs = {id(p) for g in live for p in g["params"]}
         return mine == theirs
 
-    def fused_train_step(self, images, target, optimizer):
+    def fused_train_step(self, images, target, optimizer, logits_out=None, loss_out=None):
+        """One reference train_one iteration as one engine call.  ``logits_out`` (B, C) / ``loss_out`` (1,): rows of the caller's
+        epoch buffers the engine writes straight into; without them the results are copies of the engine's per-step buffers."""
         eng = self.engine()
         eng.ensure_batch(images.shape[0])
         g = next(g for g in optimizer.param_groups if len(g["params"]) > 0)
-        logits, loss = eng.train_step(images.contiguous().float(), target.contiguous(), lr=g["lr"], momentum=g["momentum"],
+        img = images.contiguous() if images.dtype == torch.uint8 else images.contiguous().float()
+        logits, loss = eng.train_step(img, target.contiguous(), lr=g["lr"], momentum=g["momentum"],
                                       weight_decay=g["weight_decay"], bn_training=self.channel_bn.training,
-                                      nesterov=bool(g["nesterov"]))
+                                      nesterov=bool(g["nesterov"]), logits_out=logits_out, loss_out=loss_out)
         if self.channel_bn.training:
-            self.channel_bn.num_batches_tracked += 1
-        return logits.clone(), loss.clone()
+            self._bn_steps = getattr(self, "_bn_steps", 0) + 1       # folded into num_batches_tracked once per epoch
+        if logits_out is None:
+            logits = logits.clone()
+        if loss_out is None:
+            loss = loss.clone()
+        return logits, loss
+
+    def flush_bn_counter(self):
+        n = getattr(self, "_bn_steps", 0)
+        if n and isinstance(self.channel_bn, nn.BatchNorm1d):
+            self.channel_bn.num_batches_tracked += n
+        self._bn_steps = 0
 
 
 def adjust_learning_rate(optimizer, epoch, config):
@@ -315,26 +333,155 @@ def _score(metric, outputs, targets):
         return 0.0, logits
 
 
+_FEED_STATE = {}        # device -> {"stream": copy stream, "slots": staging ring}; see DeviceFeeder
+
+
+class DeviceFeeder:
+    """Batches of any loader on the training GPU, one batch ahead of the consumer.
+
+    The reference feeds ``train_one`` from a 6-worker DataLoader with pinned memory and ``images.cuda(non_blocking=True)``
+    (feature.py:101, kadaptation_clip.py:340): the upload of batch i+1 overlaps the step of batch i.  Here a helper thread pulls
+    the next batch from the loader (for host-resident tensor sets that is the index gather, straight into a pinned staging
+    buffer), issues the host-to-device copies on a side stream into a device staging buffer and hands over
+    (images, target, event); the consumer makes its stream wait for the event.  SLOTS staging pairs (pinned host + device),
+    allocated once per epoch and re-used in a ring: a pair is rewritten only after the consumer has asked for the batch behind
+    it (its step is enqueued) -- the copy stream then waits for the event the consumer recorded at that moment.  Batches that
+    already live on the device pass through untouched."""
+    DEPTH = 2
+    SLOTS = DEPTH + 2
+
+    def __init__(self, loader, device):
+        self.loader, self.device = loader, torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+
+    def __iter__(self):
+        import queue
+        import threading
+        direct = hasattr(self.loader, "iter_indices") and hasattr(self.loader, "fetch")    # evaluation/dataloader.TensorLoader
+        if direct and self.loader.sample_spec()[2] == self.device:
+            for batch in self.loader:                        # resident set: nothing to move
+                yield batch[0], batch[1]
+            return
+        it = self.loader.iter_indices() if direct else iter(self.loader)
+        try:
+            first = next(it)
+        except StopIteration:
+            return
+        if not direct and all(not torch.is_tensor(t) or t.device == self.device for t in first[:2]):
+            yield first[0], first[1]
+            for batch in it:
+                yield batch[0], batch[1]
+            return
+        q = queue.Queue(maxsize=self.DEPTH)
+        # the copy stream and the staging ring outlive the epoch (pinning 4 x 19 MB of host memory costs tens of ms: more than
+        # the uploads of a 20-step epoch); every epoch ends with a stream synchronisation, so the next one finds them idle
+        cache = _FEED_STATE.setdefault(str(self.device), {})
+        if "stream" not in cache:
+            cache["stream"] = torch.cuda.Stream(self.device)
+            cache["slots"] = [dict(h_img=None, h_tgt=None, d_img=None, d_tgt=None, used=None) for _ in range(self.SLOTS)]
+        copy_stream, slots = cache["stream"], cache["slots"]
+        for sl in slots:
+            sl["used"] = None
+        stop = threading.Event()
+
+        def staging(slot, n, ishape, idt, tshape, tdt):
+            cap = max(n, getattr(self.loader, "batch_size", 1))
+            if slot["h_img"] is None or slot["h_img"].shape[0] < n or slot["h_img"].dtype != idt or tuple(slot["h_img"].shape[1:]) != ishape \
+                    or slot["h_tgt"].dtype != tdt or tuple(slot["h_tgt"].shape[1:]) != tshape:
+                slot["h_img"] = torch.empty((cap,) + ishape, dtype=idt).pin_memory()
+                slot["h_tgt"] = torch.empty((cap,) + tshape, dtype=tdt).pin_memory()
+                slot["d_img"] = torch.empty((cap,) + ishape, dtype=idt, device=self.device)
+                slot["d_tgt"] = torch.empty((cap,) + tshape, dtype=tdt, device=self.device)
+
+        def produce():
+            try:
+                torch.cuda.set_device(self.device)
+                i, batch = 0, first
+                while batch is not None and not stop.is_set():
+                    slot = slots[i % self.SLOTS]
+                    if direct:                               # gather straight into the pinned staging buffer
+                        (ishape, idt), (tshape, tdt), _ = self.loader.sample_spec()
+                        n = batch.shape[0]
+                        staging(slot, n, ishape, idt, tshape, tdt)
+                        if slot["used"] is not None:
+                            slot["used"].synchronize()       # (already complete: the consumer is SLOTS - DEPTH batches further on)
+                        self.loader.fetch(batch, slot["h_img"], slot["h_tgt"])
+                    else:
+                        images, target = batch[0], batch[1]
+                        n = images.shape[0]
+                        staging(slot, n, tuple(images.shape[1:]), images.dtype, tuple(target.shape[1:]), target.dtype)
+                        if slot["used"] is not None:
+                            slot["used"].synchronize()
+                        slot["h_img"][:n].copy_(images); slot["h_tgt"][:n].copy_(target)
+                    with torch.cuda.stream(copy_stream):
+                        slot["d_img"][:n].copy_(slot["h_img"][:n], non_blocking=True)
+                        slot["d_tgt"][:n].copy_(slot["h_tgt"][:n], non_blocking=True)
+                        ev = torch.cuda.Event(); ev.record(copy_stream)
+                    q.put((i % self.SLOTS, n, ev))
+                    i += 1
+                    batch = next(it, None)
+                q.put(None)
+            except BaseException as e:                       # surfaces in the consumer
+                q.put(e)
+
+        th = threading.Thread(target=produce, daemon=True)
+        th.start()
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                k, n, ev = item
+                cur = torch.cuda.current_stream(self.device)
+                cur.wait_event(ev)
+                yield slots[k]["d_img"][:n], slots[k]["d_tgt"][:n].clone()    # targets outlive the ring (epoch metric): a copy of their own
+                # back here the consumer has enqueued everything that reads this pair: the ring may come round to it after that
+                used = torch.cuda.Event(); used.record(torch.cuda.current_stream(self.device))
+                slots[k]["used"] = used
+        finally:
+            stop.set()
+            while th.is_alive():
+                try:
+                    q.get_nowait()
+                except Exception:
+                    pass
+                th.join(timeout=0.01)
+            torch.cuda.current_stream(self.device).synchronize()      # the staging buffers die with this generator
+
+
 def train_one(train_loader, model, criterion, optimizer, epoch, config):
     batch_time, data_time, losses = AverageMeter(), AverageMeter(), AverageMeter()
     metric = get_metric(config.TEST.METRIC)
     outputs, targets, step_losses, step_sizes = [], [], [], []
     fused = model.can_fuse(criterion, optimizer)
     dev = config.GPUS[0]
+    single = len(config.GPUS) == 1
+    # epoch buffers the fused step writes its logits / loss straight into (no per-step copies of the engine's buffers)
+    n_total = len(getattr(train_loader, "dataset", ())) if (fused and hasattr(train_loader, "__len__")) else 0
+    out_buf = loss_buf = None
+    if fused and n_total > 0:
+        out_buf = torch.empty((n_total, config.DATASET.NUM_CLASSES), dtype=torch.float32, device=torch.device("cuda", dev))
+        loss_buf = torch.empty((len(train_loader) + 1,), dtype=torch.float32, device=out_buf.device)
+    row = step = 0
     end = time.time()
-    for _, batch in enumerate(train_loader):
-        images, target = batch[:2]
+    for images, target in (DeviceFeeder(train_loader, dev) if single else ((b[0], b[1]) for b in train_loader)):
         data_time.update(time.time() - end)
-        if len(config.GPUS) == 1:
-            images = images.cuda(dev, non_blocking=True)
         if images.shape[0] == 1:
             continue                                      # BatchNorm cannot take a single-sample batch (reference :341)
         if target.shape[-1] == 1:
             target = target[:, 0]
-        target = target.cuda(dev, non_blocking=True)
+        if not target.is_cuda:
+            target = target.cuda(dev, non_blocking=True)
 
         if fused and target.dim() == 1 and target.dtype == torch.int64:
-            output, loss = model.fused_train_step(images, target, optimizer)
+            n = images.shape[0]
+            direct = out_buf is not None and row + n <= out_buf.shape[0] and step < loss_buf.shape[0]
+            output, loss = model.fused_train_step(images, target, optimizer,
+                                                  out_buf[row:row + n] if direct else None,
+                                                  loss_buf[step:step + 1] if direct else None)
+            row += n if direct else 0
+            step += 1 if direct else 0
         else:
             optimizer.zero_grad()
             output = model.forward(images)
@@ -342,10 +489,12 @@ def train_one(train_loader, model, criterion, optimizer, epoch, config):
             loss.backward()
             optimizer.step()
         step_losses.append(loss.detach().reshape(1)); step_sizes.append(images.size(0))
-        outputs.append(output.detach() if fused else output)
+        outputs.append(output.detach())
         targets.append(target)
         batch_time.update(time.time() - end)
         end = time.time()
+    if fused:
+        model.flush_bn_counter()
 
     if not outputs:
         return
@@ -367,11 +516,10 @@ def validate(val_loader, model, criterion, epoch, config, return_logits=False):
         eng.check_streamk()
     model.eval()
     dev = config.GPUS[0]
-    for batch in val_loader:
-        images, target = batch[:2]
-        if len(config.GPUS) == 1:
-            images = images.cuda(dev, non_blocking=True)
-        target = target.cuda(dev, non_blocking=True)
+    single = len(config.GPUS) == 1
+    for images, target in (DeviceFeeder(val_loader, dev) if single else ((b[0], b[1]) for b in val_loader)):
+        if not target.is_cuda:
+            target = target.cuda(dev, non_blocking=True)
         if target.shape[-1] == 1:
             target = target[:, 0]
         outputs.append(model(images))
@@ -420,7 +568,7 @@ def train_task(classifier_cls, train_dataloader, test_dataloader, config, sweep_
         return acc1
 
     del model, criterion, optimizer
-    gpu_gc()
+    gpu_gc(full=not sweep_run)
     return best_acc1 if sweep_run else (best_acc1, model_info)
 
 

@@ -63,13 +63,18 @@ class TensorLoader:
     def _base(self):
         if isinstance(self.dataset, _View):
             full = self.dataset.dataset
-            return full, torch.as_tensor(self.dataset.indices, dtype=torch.long, device=full.images.device)
+            key = (id(self.dataset.indices), len(self.dataset.indices), full.images.device)
+            if getattr(self, "_idx_key", None) != key:           # the index list of a view is uploaded once, not per batch
+                self._idx = torch.as_tensor(self.dataset.indices, dtype=torch.long, device=full.images.device)
+                self._idx_key = key
+            return full, self._idx
         return self.dataset, None
 
     def __len__(self):
         return (len(self.dataset) + self.batch_size - 1) // self.batch_size
 
-    def __iter__(self):
+    def iter_indices(self):
+        """The index tensors of one epoch's batches (on the device the set lives on)."""
         full, idx = self._base()
         n = len(self.dataset)
         dev = full.images.device
@@ -77,8 +82,32 @@ class TensorLoader:
         if idx is not None:
             order = idx[order]
         for lo in range(0, n, self.batch_size):
-            sel = order[lo:lo + self.batch_size]
-            yield full.images[sel], full.labels[sel]
+            yield order[lo:lo + self.batch_size]
+
+    def fetch(self, sel, out_images=None, out_labels=None):
+        """Gather one batch; with ``out_*`` (pinned staging buffers of _harness.DeviceFeeder) straight into them."""
+        full, _ = self._base()
+        if out_images is None:
+            return full.images[sel], full.labels[sel]
+        n = sel.shape[0]
+        if full.images.device.type == "cpu":
+            # one memcpy per row, single-threaded (numpy): torch.index_select fans a 19 MB gather out over every core of the
+            # host -- 69 ms per 128-image batch on the 256-thread GPU box against 1.4 ms this way (scripts/r4_feeder_timing.py)
+            idx = sel.numpy()
+            np.take(full.images.numpy().reshape(len(full), -1), idx, axis=0, out=out_images[:n].numpy().reshape(n, -1), mode="clip")
+            np.take(full.labels.numpy(), idx, axis=0, out=out_labels[:n].numpy(), mode="clip")
+        else:
+            torch.index_select(full.images, 0, sel, out=out_images[:n])
+            torch.index_select(full.labels, 0, sel, out=out_labels[:n])
+        return out_images[:n], out_labels[:n]
+
+    def sample_spec(self):
+        full, _ = self._base()
+        return (tuple(full.images.shape[1:]), full.images.dtype), (tuple(full.labels.shape[1:]), full.labels.dtype), full.images.device
+
+    def __iter__(self):
+        for sel in self.iter_indices():
+            yield self.fetch(sel)
 
 
 def class_balanced_split(labels: np.ndarray, val_split: float = 0.2):
@@ -103,12 +132,18 @@ def few_shot_subset(labels: np.ndarray, shots: int, seed: int):
 
 
 def _tensors(images, labels, config):
+    """uint8 archives stay uint8: the Classifier hands INPUT.MEAN / INPUT.STD to the engine, which applies the reference's
+    ToTensor + Normalize inside its patch gather (bit for bit the host arithmetic; a quarter of the memory and of the bytes to
+    upload).  DATASET.NORMALIZE_ON_HOST = True restores the float path."""
     x = torch.as_tensor(np.asarray(images))
     if x.dtype == torch.uint8:
-        mean = torch.tensor(config.INPUT.MEAN).view(1, 3, 1, 1)
-        std = torch.tensor(config.INPUT.STD).view(1, 3, 1, 1)
-        x = (x.float() / 255.0 - mean) / std
-    return x.float(), torch.as_tensor(np.asarray(labels)).long()
+        if config.DATASET.get("NORMALIZE_ON_HOST", False):
+            mean = torch.tensor(config.INPUT.MEAN).view(1, 3, 1, 1)
+            std = torch.tensor(config.INPUT.STD).view(1, 3, 1, 1)
+            x = (x.float() / 255.0 - mean) / std
+    else:
+        x = x.float()
+    return x.contiguous(), torch.as_tensor(np.asarray(labels)).long()
 
 
 def _synthetic(config):
@@ -118,7 +153,10 @@ def _synthetic(config):
     g = torch.Generator().manual_seed(int(config.DATASET.RANDOM_SEED_SAMPLING))
     out = []
     for n in sizes:
-        out.append((torch.randn((n, 3, R, R), generator=g), torch.arange(n) % C))
+        if config.DATASET.get("SYNTHETIC_UINT8", False):      # raw pixels, as an image archive would hold them
+            out.append((torch.randint(0, 256, (n, 3, R, R), generator=g, dtype=torch.uint8), torch.arange(n) % C))
+        else:
+            out.append((torch.randn((n, 3, R, R), generator=g), torch.arange(n) % C))
     return out
 
 
@@ -136,8 +174,8 @@ def construct_dataloader(config, feature_type="image", test_split_only=False):
         z = np.load(path)
         trx, try_ = _tensors(z["train_images"], z["train_labels"], config)
         tex, tey = _tensors(z["test_images"], z["test_labels"], config)
-    bs = 64                                              # get_dataloader's batch_size_per_gpu default
-    dev = _resident_device(config, trx.numel() * 4 + tex.numel() * 4)
+    bs = int(config.DATASET.get("LOADER_BATCH_SIZE", 64))    # get_dataloader's batch_size_per_gpu default is 64 (feature.py:101,597)
+    dev = _resident_device(config, trx.numel() * trx.element_size() + tex.numel() * tex.element_size())
     tex, tey = tex.to(dev), tey.to(dev)
     test_loader = TensorLoader(_Tensors(tex, tey), batch_size=bs, shuffle=False)
     if test_split_only:
@@ -155,7 +193,10 @@ def construct_dataloader(config, feature_type="image", test_split_only=False):
 
 
 def _resident_device(config, nbytes, limit=64 << 30):
-    """Keep the tensor set on the training GPU when it fits comfortably (288 GB of HBM per MI355X)."""
+    """Keep the tensor set on the training GPU when it fits comfortably (288 GB of HBM per MI355X); DATASET.RESIDENT = False
+    keeps it on the host (then _harness.DeviceFeeder uploads batch i+1 while batch i is trained on)."""
+    if not config.DATASET.get("RESIDENT", True):
+        return torch.device("cpu")
     if torch.cuda.is_available() and nbytes < limit and len(config.GPUS) == 1:
         return torch.device("cuda", int(config.GPUS[0]))
     return torch.device("cpu")

@@ -367,6 +367,8 @@ class VisionTransformer(nn.Module):
             k = named[n].numel()
             self._has_grad[n] = bool(mask[off:off + k].any())
             off += k
+        if getattr(self, "_input_norm", None) is not None:
+            eng.set_input_normalization(*self._input_norm)
         self._engine = eng
         return eng
 
@@ -395,11 +397,22 @@ class VisionTransformer(nn.Module):
             self._train_params = [named[n] for n in self._trainable_names]
         return self._train_params
 
+    def set_input_normalization(self, mean, std):
+        """uint8 batches (B,3,R,R) are accepted once the preprocessing constants are known: the reference's ToTensor +
+        Normalize(INPUT.MEAN, INPUT.STD) then runs inside the engine's patch gather (a quarter of the bytes to upload)."""
+        self._input_norm = (tuple(float(v) for v in mean), tuple(float(v) for v in std))
+        if self._engine is not None:
+            self._engine.set_input_normalization(*self._input_norm)
+
     def forward(self, x):
         eng = self.engine()
         eng.ensure_batch(x.shape[0])
         params = self._trainable_params()
         save = torch.is_grad_enabled() and any(p.requires_grad for p in params)   # grad mode is off inside Function.forward
+        if x.dtype == torch.uint8:
+            if getattr(self, "_input_norm", None) is None:
+                raise _lib.PevitError("uint8 images need the preprocessing constants: call visual.set_input_normalization(mean, std)")
+            return _VisualFn.apply(x.contiguous(), self, save, *params)
         return _VisualFn.apply(x.contiguous().float(), self, save, *params)
 
 
@@ -433,6 +446,8 @@ class CLIP(nn.Module):
         return self.visual.conv1.weight.dtype
 
     def encode_image(self, image):
+        if image.dtype == torch.uint8:          # raw pixels: normalised inside the engine (visual.set_input_normalization)
+            return self.visual(image)
         return self.visual(image.type(self.dtype))
 
     def encode_text(self, text):

@@ -6,7 +6,7 @@ TAG=${1:-k}; shift
 O=$R/gpurun_out/kstats_$TAG
 rm -rf $O; mkdir -p $O
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $O -o k -- python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline "$@" > $O/bench.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $O -o k -- python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-harness "$@" > $O/bench.log 2>&1
 cd $R
 K=$(find $O -name "*.db" | head -1)
 python scripts/prof_summary.py $K 55 > $O/kernel_stats.md 2>&1

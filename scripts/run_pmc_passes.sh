@@ -10,10 +10,10 @@ TAG=${1:-r04}
 O=$R/gpurun_out/pmc_$TAG
 rm -rf $O; mkdir -p $O/fetch $O/write $O/ktrace $O/mfma
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o f -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --pmc-calib > $O/fetch.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o w -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --pmc-calib > $O/write.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/mfma -o m -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/mfma.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --stats -d $O/ktrace -o k -- python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline > $O/ktrace.log 2>&1   # 30 timed + 5 warm-up + 2 x 10 event-profiled steps = 55
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o f -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-harness --pmc-calib > $O/fetch.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o w -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-harness --pmc-calib > $O/write.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/mfma -o m -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-harness > $O/mfma.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/ktrace -o k -- python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-harness > $O/ktrace.log 2>&1   # 30 timed + 5 warm-up + 2 x 10 event-profiled steps = 55
 cd $R
 F=$(find $O/fetch -name "*.db" | head -1); W=$(find $O/write -name "*.db" | head -1); K=$(find $O/ktrace -name "*.db" | head -1); M=$(find $O/mfma -name "*.db" | head -1)
 python scripts/pmc_traffic.py $F $W "ViT-B/32|kadaptation|bs128" profiles/hbm_traffic.json > $O/traffic.txt 2>&1

@@ -458,3 +458,44 @@ def test_a_block_forward_between_a_tower_forward_and_its_backward_is_refused(ckp
     model.visual.transformer.resblocks[0](x.clone().requires_grad_(True))
     with pytest.raises(PevitError, match="no longer holds"):
         y1.backward(dy)
+
+
+def test_device_feeder_uploads_host_batches_ahead_and_changes_nothing(ckpt):
+    """train_one / validate pull their batches through _harness.DeviceFeeder: host-resident sets (uint8 pixels or f32) are gathered
+    into pinned staging buffers and uploaded on a side stream one batch ahead (the reference: pinned DataLoader workers +
+    images.cuda(non_blocking=True), kadaptation_clip.py:340); device-resident sets pass through.  Same batches, same order, and a
+    training epoch gives bit-identical parameters whichever way the pixels arrive: resident f32, host f32, host uint8."""
+    from pevit_amd.evaluation import _harness
+    from pevit_amd.evaluation.dataloader import TensorLoader, _Tensors
+    meta, t = load_golden("tiny_kadaptation")
+    R = t["images"].shape[-1]
+    g = torch.Generator().manual_seed(11)
+    n, C_ = 22, meta["classes"]
+    u8 = torch.randint(0, 256, (n, 3, R, R), dtype=torch.uint8, generator=g)
+    labels = torch.arange(n) % C_
+    cfg0 = tiny_config(ckpt, classes=C_)
+    mean, std = torch.tensor(cfg0.INPUT.MEAN).view(1, 3, 1, 1), torch.tensor(cfg0.INPUT.STD).view(1, 3, 1, 1)
+    f32 = (u8.float() / 255.0 - mean) / std
+    # the feeder itself: order and content
+    host_loader = TensorLoader(_Tensors(u8, labels), batch_size=4, shuffle=False)
+    got = [(a.cpu(), b.cpu()) for a, b in _harness.DeviceFeeder(host_loader, 0)]
+    want = list(host_loader)
+    assert len(got) == len(want) == 6 and all(a.is_cuda for a, _ in _harness.DeviceFeeder(host_loader, 0))
+    for (a, b), (c, d) in zip(got, want):
+        assert torch.equal(a, c) and torch.equal(b, d)
+    finals = []
+    for images, dev in ((f32, "cuda"), (f32, "cpu"), (u8, "cpu")):
+        mod, cfg, clf = seeded_classifier("kadaptation", ckpt, meta, t)
+        loader = TensorLoader(_Tensors(images.to(dev), labels.to(dev)), batch_size=4, shuffle=False)
+        crit = torch.nn.CrossEntropyLoss()
+        from pevit_amd.optim import build_optimizer
+        opt = build_optimizer(cfg, clf)
+        assert clf.can_fuse(crit, opt)
+        loss = mod.train_one(loader, clf, crit, opt, 0, cfg)
+        acc = mod.validate(loader, clf, crit, 0, cfg)
+        torch.cuda.synchronize()
+        finals.append((loss, acc, torch.cat([p.detach().flatten().cpu() for p in clf.parameters() if p.requires_grad]),
+                       int(clf.channel_bn.num_batches_tracked)))
+    for other in finals[1:]:
+        assert other[0] == finals[0][0] and other[1] == finals[0][1] and torch.equal(other[2], finals[0][2])
+    assert finals[0][3] == 6

@@ -262,3 +262,51 @@ def test_a_failed_launch_is_reported_not_swallowed(lib):
     g = torch.ones(128, device="cuda")
     ok(lib, lib.pevit_op_ln_fwd(S(), P(y), P(g), P(g), 4, 128, P(yb), None, None, None))      # the error does not stick
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("B,R,Pp", [(3, 48, 16), (2, 224, 32), (2, 224, 14)])
+def test_im2col_from_uint8_pixels_equals_the_host_preprocessing(lib, B, R, Pp):
+    """pevit_op_im2col_u8: ToTensor + Normalize of the reference's dataset transforms (feature.py:537-542, INPUT.MEAN / STD of
+    vitb32_CLIP.yaml) inside the patch gather.  Bit for bit the patches of the f32 images `(x.float() / 255 - mean) / std`
+    computed on the host, for the 8-pixel kernel (patch 16 / 32) and the generic one (patch 14)."""
+    import ctypes as C
+    mean, std = [0.48145466, 0.4578275, 0.40821073], [0.26862954, 0.26130258, 0.27577711]
+    u8 = torch.randint(0, 256, (B, 3, R, R), dtype=torch.uint8, generator=torch.Generator().manual_seed(3))
+    host = (u8.float() / 255.0 - torch.tensor(mean).view(1, 3, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1)
+    K = 3 * Pp * Pp
+    Kp = (K + 63) // 64 * 64
+    G = R // Pp
+    a = torch.full((B * G * G, Kp), float("nan"), dtype=torch.bfloat16, device="cuda"); b = a.clone()
+    ok(lib, lib.pevit_op_im2col(S(), P(host.cuda().contiguous()), P(a), B, R, Pp, Kp))
+    ok(lib, lib.pevit_op_im2col_u8(S(), P(u8.cuda()), (C.c_float * 3)(*mean), (C.c_float * 3)(*std), P(b), B, R, Pp, Kp))
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+
+
+def test_a_step_on_uint8_pixels_equals_the_step_on_the_preprocessed_batch():
+    """Engine level: train_step(uint8 images) after set_input_normalization == train_step(host-normalised f32 images), bit for
+    bit (logits, loss, every gradient); uint8 without the constants is refused."""
+    from pevit_amd._lib import PevitError
+    from pevit_amd.synth import ARCHS, randomize_adapters, synth_state_dict
+    from pevit_amd.engine import adapter_param_spec
+    arch, C_ = ARCHS["tiny-128"], 10
+    mean, std = [0.48145466, 0.4578275, 0.40821073], [0.26862954, 0.26130258, 0.27577711]
+    sd = {k: v for k, v in synth_state_dict(arch, seed=2, text_tower=False).items() if k.startswith("visual.")}
+    ad = [(n, torch.zeros(s)) for n, s, _ in adapter_param_spec("kadaptation", arch.width, arch.layers)]
+    randomize_adapters(ad, seed=3); sd.update(dict(ad))
+    u8 = torch.randint(0, 256, (6, 3, arch.resolution, arch.resolution), dtype=torch.uint8, generator=torch.Generator().manual_seed(5))
+    host = (u8.float() / 255.0 - torch.tensor(mean).view(1, 3, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1)
+    labels = torch.arange(6) % C_
+    res = []
+    for images in (host, u8):
+        eng = _engine(B=6, C=C_); eng.load_state_dict(sd)
+        if images.dtype == torch.uint8:
+            with pytest.raises(PevitError, match="uint8"):
+                eng.forward_backward(images.cuda(), labels.cuda())
+            eng.set_input_normalization(mean, std)
+        logits, loss = eng.forward_backward(images.cuda().contiguous(), labels.cuda())
+        torch.cuda.synchronize()
+        res.append((logits.clone(), loss.clone(), eng.grads.clone()))
+    for x, y in zip(*res):
+        assert torch.equal(x, y)
+    assert float(res[0][2].abs().max()) > 0

@@ -373,3 +373,24 @@ def test_transformer_seam_is_callable_and_train_mode_is_refused():
         tr(torch.zeros(10, 2, 128))                       # CPU tensors: the seam runs only in the HIP engine
     lora = build_peft_model(load_tiny_sd(), "lora")
     lora.train(); lora.eval()                             # no dropout on the other methods' paths
+
+
+def test_tensor_loader_fetch_into_staging_equals_plain_iteration():
+    """TensorLoader.iter_indices / fetch (what _harness.DeviceFeeder drives from its helper thread): gathering a batch straight
+    into caller-owned staging buffers gives the batches plain iteration gives, for views (train / val splits of one set), uint8
+    and f32 images, and a ragged last batch."""
+    from pevit_amd.evaluation.dataloader import TensorLoader, _Tensors, _View
+    g = torch.Generator().manual_seed(0)
+    for dtype in (torch.uint8, torch.float32):
+        imgs = torch.randint(0, 256, (23, 3, 8, 8), generator=g).to(dtype)
+        full = _Tensors(imgs, torch.arange(23) % 5)
+        for ds in (full, _View(full, [1, 3, 4, 9, 10, 11, 17, 20, 22])):
+            loader = TensorLoader(ds, batch_size=4, shuffle=False)
+            plain = list(loader)
+            assert len(plain) == len(loader)
+            out_i, out_l = torch.empty((4, 3, 8, 8), dtype=dtype), torch.empty((4,), dtype=torch.long)
+            for sel, (a, b) in zip(loader.iter_indices(), plain):
+                x, y = loader.fetch(sel, out_i, out_l)
+                assert x.shape == a.shape and torch.equal(x, a) and torch.equal(y, b)
+            spec = loader.sample_spec()
+            assert spec[0] == ((3, 8, 8), dtype) and spec[1] == ((), torch.long) and spec[2].type == "cpu"
