@@ -109,7 +109,7 @@ def head_init(dim, classes, seed=5):
 
 
 def run_case(method, arch_name, batch, classes, lora_r=4, steps=3, lr=0.01, wd=1e-4,
-             store_tensors=True):
+             store_tensors=True, reference_init=False):
     arch = ARCHS[arch_name]
     sd = synth_state_dict(arch, seed=2, text_tower=(arch_name.startswith("tiny")))
     if store_tensors:
@@ -120,7 +120,8 @@ def run_case(method, arch_name, batch, classes, lora_r=4, steps=3, lr=0.01, wd=1
         p.requires_grad = trainable_rule(method, n)
     train_named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
     init_vals = {n: p.detach().clone() for n, p in train_named}   # reference init
-    randomize_adapters(train_named, seed=3)
+    if not reference_init:       # (reference_init: the adapters stay exactly as build_model left them, model.py:533-554,987-999)
+        randomize_adapters(train_named, seed=3)
     adapters = {n: p.detach().clone() for n, p in train_named}
     # tensors the reference adds but never trains (Compacter's shared phm_rule)
     frozen_extra = {n: p.detach().clone() for n, p in model.named_parameters()
@@ -188,6 +189,28 @@ def run_case(method, arch_name, batch, classes, lora_r=4, steps=3, lr=0.01, wd=1
             if g is not None:
                 tensors["grad/" + n] = g.numpy()
         for n, v in final.items():
+            tensors["final/" + n] = v.numpy()
+        tensors["bn_mean"] = clf.channel_bn.running_mean.numpy()
+        tensors["bn_var"] = clf.channel_bn.running_var.numpy()
+    elif reference_init:
+        # full-size at the reference initialisation: the regime every reference run is in (both Kronecker factors
+        # start at zero, so only attn.b and the head ever receive a non-zero gradient).  Stored: the head (seeded), the
+        # reference's own initial values of what it draws from torch's RNG (the shared phm_rule factors), logits / loss /
+        # features of step 0, every NON-ZERO gradient in full, and the trained tensors after `steps` SGD steps.
+        meta["sd_checksum"] = {k: [float(v.double().sum()), float((v.double() ** 2).sum())]
+                               for k, v in list(sd.items())[:12]}
+        tensors["head_w"] = head_w.numpy(); tensors["head_b"] = head_b.numpy()
+        for n, v in adapters.items():
+            if float(v.abs().max()) != 0.0:
+                tensors["adapter/" + n] = v.numpy()
+        tensors["logits0"] = out["logits0"].numpy(); tensors["loss0"] = out["loss0"].numpy(); tensors["feat"] = out["feat"].numpy()
+        meta["zero_grad_tensors"] = [n for n, g in grads.items() if g is not None and float(g.abs().max()) == 0.0]
+        for n, g in grads.items():
+            if g is not None and float(g.abs().max()) != 0.0:
+                tensors["grad/" + n] = g.numpy()
+        for n, v in final.items():
+            if n in adapters and torch.equal(v, adapters[n]) and float(v.abs().max()) == 0.0:
+                continue                                   # still exactly zero: nothing to store
             tensors["final/" + n] = v.numpy()
         tensors["bn_mean"] = clf.channel_bn.running_mean.numpy()
         tensors["bn_var"] = clf.channel_bn.running_var.numpy()
@@ -260,12 +283,23 @@ def main():
     ap.add_argument("--full", action="store_true", help="also run the full-size ViT-B/32 bs=8 cases")
     ap.add_argument("--counts", action="store_true", help="also regenerate the parameter-count table")
     ap.add_argument("--text-only", action="store_true", help="only (re)generate tiny_text.npz")
+    ap.add_argument("--refinit", action="store_true",
+                    help="only generate full_b32_kadaptation_refinit: ViT-B/32 + KAdaptation at the reference initialisation, bs 8, 3 SGD steps")
     ap.add_argument("--other-archs", action="store_true",
                     help="only generate the full-size summaries for the ViT-B/16 and ViT-L/14 configurations of BASELINE.json")
     args = ap.parse_args()
     if args.text_only:
         np.savez_compressed(os.path.join(HERE, "tiny_text.npz"), **text_case())
         print("tiny_text written")
+        return
+    if args.refinit:
+        torch.manual_seed(0)
+        torch.set_num_threads(8)
+        meta, tensors = run_case("kadaptation", "ViT-B/32", batch=8, classes=100, steps=3, store_tensors=False, reference_init=True)
+        np.savez_compressed(os.path.join(HERE, "full_b32_kadaptation_refinit.npz"), **tensors)
+        with open(os.path.join(HERE, "full_b32_kadaptation_refinit.json"), "w") as f:
+            json.dump(meta, f, indent=1)
+        print("full_b32_kadaptation_refinit ok; losses", meta["losses"], "non-zero grads:", sorted(k for k in tensors if k.startswith("grad/"))[:4], "...")
         return
     if args.other_archs:
         for method, arch_name, tag, lora_r in (("compacter", "ViT-B/16", "full_b16_compacter", 4),
