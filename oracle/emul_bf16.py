@@ -40,7 +40,16 @@ import torch.nn.functional as F
 from . import ref_cpu as R
 
 
-def bf(x):
+# Named rounding points: ``POINTS_OFF`` switches single storage points of the emulation off (the value then passes in f32), which
+# is how scripts/r4_rounding_ablation.py attributes the bf16 path's distance from the f32 reference to individual buffers.
+POINTS = ("w", "img", "xn", "qkv", "P", "Q_fwd", "q_delta", "p", "attn_out", "h", "gelu", "cls", "dyb", "dh", "dx", "ds", "dqkv",
+          "p_bwd", "u", "Q_bwd", "t_bwd", "bottleneck")
+POINTS_OFF = set()
+
+
+def bf(x, point=None):
+    if point is not None and point in POINTS_OFF:
+        return x
     return x.to(torch.bfloat16).to(torch.float32)
 
 
@@ -48,12 +57,12 @@ class RoundSTE(torch.autograd.Function):
     """bf16 storage of a forward activation; the gradient passes unchanged."""
 
     @staticmethod
-    def forward(ctx, x):
-        return bf(x)
+    def forward(ctx, x, point=None):
+        return bf(x, point)
 
     @staticmethod
     def backward(ctx, g):
-        return g
+        return g, None
 
 
 class LinearE(torch.autograd.Function):
@@ -62,19 +71,19 @@ class LinearE(torch.autograd.Function):
     dx = bf16(g) W, stored bf16 when ``round_dx``."""
 
     @staticmethod
-    def forward(ctx, x, w_b, b, round_out, round_dx):
+    def forward(ctx, x, w_b, b, round_out, round_dx, out_point="h"):
         ctx.save_for_backward(w_b)
         ctx.round_dx = round_dx
         y = x @ w_b.t()
         if b is not None:
             y = y + b
-        return bf(y) if round_out else y
+        return bf(y, out_point) if round_out else y
 
     @staticmethod
     def backward(ctx, g):
         (w_b,) = ctx.saved_tensors
-        dx = bf(g) @ w_b
-        return (bf(dx) if ctx.round_dx else dx), None, None, None, None
+        dx = bf(g, "dyb") @ w_b
+        return (bf(dx, "dx") if ctx.round_dx else dx), None, None, None, None, None
 
 
 class LinearTrain(torch.autograd.Function):
@@ -83,7 +92,7 @@ class LinearTrain(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, bias_from_f32):
-        w_b = bf(w)
+        w_b = bf(w, "bottleneck")
         ctx.save_for_backward(x, w_b)
         ctx.bias_from_f32 = bias_from_f32
         return x @ w_b.t() + b
@@ -91,7 +100,7 @@ class LinearTrain(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, w_b = ctx.saved_tensors
-        g_b = bf(g)
+        g_b = bf(g, "bottleneck")
         g2, x2 = g_b.reshape(-1, g_b.shape[-1]), x.reshape(-1, x.shape[-1])
         db = (g if ctx.bias_from_f32 else g_b).reshape(-1, g.shape[-1]).sum(0)
         return g_b @ w_b, g2.t() @ x2, db, None
@@ -103,13 +112,13 @@ class QuickGeluE(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h):
         ctx.save_for_backward(h)
-        return bf(h * torch.sigmoid(1.702 * h))
+        return bf(h * torch.sigmoid(1.702 * h), "gelu")
 
     @staticmethod
     def backward(ctx, g):
         (h,) = ctx.saved_tensors
         s = torch.sigmoid(1.702 * h)
-        return bf(g * (s * (1.0 + 1.702 * h * (1.0 - s))))
+        return bf(g * (s * (1.0 + 1.702 * h * (1.0 - s))), "dh")
 
 
 class ReluE(torch.autograd.Function):
@@ -117,14 +126,14 @@ class ReluE(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, pre):
-        act = bf(torch.relu(pre))
+        act = bf(torch.relu(pre), "bottleneck")
         ctx.save_for_backward(act)
         return act
 
     @staticmethod
     def backward(ctx, g):
         (act,) = ctx.saved_tensors
-        return bf(g * (act > 0).float())
+        return bf(g * (act > 0).float(), "bottleneck")
 
 
 def _gelu_new_grad(x):
@@ -139,14 +148,14 @@ class GeluNewE(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, pre):
-        a = bf(pre)
+        a = bf(pre, "bottleneck")
         ctx.save_for_backward(a)
-        return bf(R.gelu_new(a))
+        return bf(R.gelu_new(a), "bottleneck")
 
     @staticmethod
     def backward(ctx, g):
         (a,) = ctx.saved_tensors
-        return bf(g * _gelu_new_grad(a))
+        return bf(g * _gelu_new_grad(a), "bottleneck")
 
 
 class AttnCore(torch.autograd.Function):
@@ -156,9 +165,9 @@ class AttnCore(torch.autograd.Function):
     def forward(ctx, q, k, v):
         s = torch.bmm(q, k.transpose(1, 2))
         m = s.max(dim=-1, keepdim=True).values
-        p_b = bf(torch.exp(s - m))
+        p_b = bf(torch.exp(s - m), "p")
         l = p_b.sum(-1, keepdim=True)                 # row sum of the ROUNDED probabilities
-        o = bf(torch.bmm(p_b, v) * (1.0 / l))
+        o = bf(torch.bmm(p_b, v) * (1.0 / l), "attn_out")
         ctx.save_for_backward(q, k, v, o, m + torch.log(l))
         return o
 
@@ -168,10 +177,10 @@ class AttnCore(torch.autograd.Function):
         p = torch.exp(torch.bmm(q, k.transpose(1, 2)) - lse)      # recomputed, f32
         dp = torch.bmm(go, v.transpose(1, 2))
         delta = (go * o).sum(-1, keepdim=True)                     # from the stored (bf16) output
-        ds = bf(p * (dp - delta))
-        dq = bf(torch.bmm(ds, k))
-        dk = bf(torch.bmm(ds.transpose(1, 2), q))
-        dv = bf(torch.bmm(bf(p).transpose(1, 2), go))
+        ds = bf(p * (dp - delta), "ds")
+        dq = bf(torch.bmm(ds, k), "dqkv")
+        dk = bf(torch.bmm(ds.transpose(1, 2), q), "dqkv")
+        dv = bf(torch.bmm(bf(p, "p_bwd").transpose(1, 2), go), "dqkv")
         return dq, dk, dv
 
 
@@ -184,13 +193,13 @@ class QKVAug(torch.autograd.Function):
     def forward(ctx, xn, w_b, b, P, ascale):
         ctx.save_for_backward(xn, w_b, P)
         ctx.ascale = ascale
-        return bf(xn @ w_b.t() + b), xn @ bf(P)
+        return bf(xn @ w_b.t() + b, "qkv"), xn @ bf(P, "P")
 
     @staticmethod
     def backward(ctx, gqkv, u):
         xn, w_b, P = ctx.saved_tensors
-        u_b = bf(u)
-        dxn = bf(gqkv @ w_b + u_b @ bf(ctx.ascale * P).t())
+        u_b = bf(u, "u")
+        dxn = bf(gqkv @ w_b + u_b @ bf(ctx.ascale * P, "P").t(), "dx")
         dP = ctx.ascale * (xn.t() @ u_b)
         return dxn, None, None, dP, None
 
@@ -204,20 +213,20 @@ class DeltaFromT(torch.autograd.Function):
         ctx.save_for_backward(t, Q)
         ctx.ascale = ascale
         ctx.has_bias = bias is not None
-        d = ascale * (t @ bf(Q).t())        # Q enters the delta product as its bf16 panel (round 4), t in f32 (hi + lo)
+        d = ascale * (t @ bf(Q, "Q_fwd").t())        # Q enters the delta product as its bf16 panel (round 4), t in f32 (hi + lo)
         return d + bias if bias is not None else d
 
     @staticmethod
     def backward(ctx, g):
         t, Q = ctx.saved_tensors
-        u = g @ bf(Q)
-        dQ = ctx.ascale * (g.t() @ bf(t))
+        u = g @ bf(Q, "Q_bwd")
+        dQ = ctx.ascale * (g.t() @ bf(t, "t_bwd"))
         return u, dQ, (g.sum(0) if ctx.has_bias else None), None
 
 
 # --------------------------------------------------------------------------- #
-def _ln_b(x, w, b):
-    return RoundSTE.apply(F.layer_norm(x, (x.shape[-1],), w, b, 1e-5))
+def _ln_b(x, w, b, point="xn"):
+    return RoundSTE.apply(F.layer_norm(x, (x.shape[-1],), w, b, 1e-5), point)
 
 
 def _heads(x, N, B, H, hd):
@@ -262,8 +271,8 @@ def attention_site(xn, p, a, t, heads, method, wcache):
     dq = DeltaFromT.apply(tt[:, :32], Qq, bias, ascale)
     dv = DeltaFromT.apply(tt[:, 32:], Qv, bias, ascale)
     # raw reinterpretation of the (N,B,E)-contiguous delta; read-modify-write of the bf16 q / v buffers
-    q = RoundSTE.apply(q + dq.reshape(B * heads, N, hd))
-    v = RoundSTE.apply(v + dv.reshape(B * heads, N, hd))
+    q = RoundSTE.apply(q + dq.reshape(B * heads, N, hd), "q_delta")
+    v = RoundSTE.apply(v + dv.reshape(B * heads, N, hd), "q_delta")
     o = AttnCore.apply(q, k, v).transpose(0, 1).contiguous().view(N * B, E)
     wo_b, bo = wcache(a + "out_proj")
     return LinearE.apply(o, wo_b, bo, False, True).view(N, B, E)
@@ -273,7 +282,7 @@ def stock_attention(xn, p, a, heads, wcache):
     N, B, E = xn.shape
     hd = E // heads
     w_b, b_s = wcache(a + "in_proj")
-    qkv = LinearE.apply(xn.reshape(N * B, E), w_b, b_s, True, True)
+    qkv = LinearE.apply(xn.reshape(N * B, E), w_b, b_s, True, True, "qkv")
     q, k, v = qkv.view(N, B, 3 * E).chunk(3, dim=-1)
     o = AttnCore.apply(_heads(q, N, B, heads, hd), _heads(k, N, B, heads, hd), _heads(v, N, B, heads, hd))
     wo_b, bo = wcache(a + "out_proj")
@@ -332,7 +341,7 @@ def make_wcache(p):
                 b[:E] *= 0.125
             else:
                 w, b = p[name + ".weight"].detach(), p[name + ".bias"].detach()
-            cache[name] = (bf(w), b.float())
+            cache[name] = (bf(w, "w"), b.float())
         return cache[name]
 
     return get
@@ -341,7 +350,7 @@ def make_wcache(p):
 def visual_forward(images, p, method):
     d = R.visual_dims(p)
     wcache = make_wcache(p)
-    x = F.conv2d(bf(images), bf(p["visual.conv1.weight"]), None, stride=d["patch"])
+    x = F.conv2d(bf(images, "img"), bf(p["visual.conv1.weight"], "w"), None, stride=d["patch"])
     x = x.reshape(x.shape[0], x.shape[1], -1).permute(0, 2, 1)
     cls = p["visual.class_embedding"] + torch.zeros(x.shape[0], 1, x.shape[-1])
     x = torch.cat([cls, x], dim=1) + p["visual.positional_embedding"]
@@ -349,8 +358,8 @@ def visual_forward(images, p, method):
     x = x.permute(1, 0, 2).contiguous()
     for i in range(d["layers"]):
         x = block(x, p, i, d["heads"], method, wcache)
-    xc = _ln_b(x[0], p["visual.ln_post.weight"], p["visual.ln_post.bias"])        # class token of every image
-    return LinearE.apply(xc, bf(p["visual.proj"].detach().t()), None, False, False)
+    xc = _ln_b(x[0], p["visual.ln_post.weight"], p["visual.ln_post.bias"], "cls")        # class token of every image
+    return LinearE.apply(xc, bf(p["visual.proj"].detach().t(), "w"), None, False, False)
 
 
 class EmulTrainer(R.OracleTrainer):

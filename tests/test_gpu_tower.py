@@ -25,6 +25,7 @@ pytestmark = pytest.mark.gpu
 
 LOGIT_TOL, LOSS_TOL, GRAD_TOL = 3e-2, 2e-2, 1.5e-1
 DEEP_LOGIT_TOL, DEEP_GRAD_TOL = 1e-1, 1.5e-1
+TRAJ_LOSS_TOL, TRAJ_NORM_TOL = 1.5e-1, 6e-2     # second SGD step of the full-size fixtures (random x160 adapters): calibrated, see profiles/r04_parity_gates.md
 BUILT = ("kadaptation", "lora")
 
 
@@ -280,6 +281,24 @@ def test_full_size_bs8_matches_reference_fixture(case):
             if abs(got - ref) > DEEP_GRAD_TOL * deep * max(ref, 1e-8):
                 bad.append((name, got, ref))
     assert not bad, bad[:5]
+    # the recorded SGD trajectory (full_b32_*: two steps): loss of the second step and the norm of every trained tensor after it
+    if len(meta["losses"]) > 1:
+        eng.sgd_step(meta["lr"], 0.9, meta["wd"])
+        for _ in range(len(meta["losses"]) - 1):
+            _, loss = eng.forward_backward(images.cuda(), labels.cuda())
+            eng.sgd_step(meta["lr"], 0.9, meta["wd"])
+        torch.cuda.synchronize()
+        dl = abs(float(loss) - meta["losses"][-1])
+        worst = ("", 0.0)
+        for name, p in eng.param_views().items():
+            key = name if name.startswith("layers.") else "backbone." + name
+            ref = meta["final_norms"][key]
+            e = abs(float(p.double().norm()) - ref) / max(ref, 1e-8)
+            if e > worst[1]:
+                worst = (name, e)
+        print(f"trajectory {case}: |loss_{len(meta['losses']) - 1} - ref| = {dl:.3e}, worst final-norm deviation {worst[1]:.3e} ({worst[0]})")
+        assert dl < TRAJ_LOSS_TOL, dl
+        assert worst[1] < TRAJ_NORM_TOL, worst
 
 
 def test_bs128_properties_full_size():
