@@ -210,6 +210,9 @@ def main():
     ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8", "fp8-act"],
                     help="frozen block weights: bf16, or e4m3 codes + per-channel scales (BASELINE config 5 with --arch ViT-L/14)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dp-route", action="store_true",
+                    help="(N = 1) also time the step through engine.forward_backward_dp on a 1-rank RCCL group -- staged backward, "
+                         "stream-K off, three asynchronous bucketed all-reduces -- and report it beside the fused step (dp_route)")
     ap.add_argument("--no-harness", action="store_true", help="skip the reference-API (train_one) throughput measurement")
     ap.add_argument("--cpu-sweep", action="store_true", help="only time the CPU baseline at 8/16/32/64/128 threads and exit")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=INT",
@@ -332,6 +335,35 @@ def main():
                        "achieved_TBps": b / max(m * 1e-3, 1e-12) / 1e12, "frac_of_hbm_peak": b / max(m * 1e-3, 1e-12) / 1e12 / PEAK_HBM_TBS}
                    for k, (c, m, b) in sorted(eng.last_profile_hbm.items(), key=lambda kv: -kv[1][1])}
 
+    dp_route = None
+    if args.dp_route and world == 1:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+        torch.distributed.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+
+        def dp_step():
+            eng.forward_backward_dp(images, labels)
+            eng.sgd_step(0.01, 0.9, 1e-6, 1.0)
+        res = {}
+        for name, fn in (("dp_route", dp_step), ("fused_streamk_off", step)):     # forward_backward_dp has switched stream-K off by now
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
+            mk = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+            mk[0].record()
+            for i in range(args.steps):
+                fn(); mk[i + 1].record()
+            torch.cuda.synchronize()
+            v = sorted(mk[i].elapsed_time(mk[i + 1]) for i in range(args.steps))
+            res[name] = v[len(v) // 2]
+        torch.distributed.destroy_process_group()
+        dp_route = {"median_ms_per_step": res["dp_route"], "fused_step_streamk_off_median_ms": res["fused_streamk_off"],
+                    "fused_step_median_ms": median_ms, "dp_route_over_fused": res["dp_route"] / median_ms,
+                    "how": "engine.forward_backward_dp + SGD on a 1-rank RCCL process group (staged backward in two halves, stream-K "
+                           "off, head / upper-half / lower-half gradient buckets all-reduced asynchronously): the host-side and "
+                           "launch-structure cost of the DP path; N > 1 remains unmeasured"}
+        eng.tune("gemm_streamk", 1); eng._dp_streamk_off = False
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = args.batch * world * args.steps / dt
@@ -405,6 +437,8 @@ def main():
                                         "executed_gemm_tflop_per_step": gemm_flops / prof_steps / 1e12,
                                         "executed_gemm_frac_of_peak": gemm_flops / prof_steps / 1e12 / (ms * 1e-3) / peak}},
         }
+        if dp_route is not None:
+            out["dp_route"] = dp_route
         if world == 1 and not args.no_harness and headline:
             del eng, images, labels
             torch.cuda.empty_cache()

@@ -239,6 +239,9 @@ int pevit_op_attn_delta_hpw(int B, int H, int N);
 /* measurement only: device buffer of 8 uint64 per workgroup that the next pevit_op_attn_fwd_delta launches fill with s_memtime
  * stamps at their phase boundaries (NULL switches it off) */
 int pevit_debug_timeline(void* buf);
+/* measurement only: `workgroups` 256-thread workgroups with `lds_bytes` of LDS each that keep their CU slots for `microseconds`
+ * on `stream` -- what the kernels of an overlapped RCCL all-reduce do to the one-tile-per-CU GEMMs (scripts/r4_coresidency.py) */
+int pevit_debug_occupy(void* stream, int workgroups, int lds_bytes, double microseconds);
 int pevit_op_lowrank_u(void* stream, const void* dqkv, int ld, const void* qT, float* u32, void* u_cols, int B,
                        int H, int N, int E);
 int pevit_op_lowrank_grad(void* stream, const void* xn, int ldx, const float* u32, const void* dqkv, int ld,

@@ -82,6 +82,7 @@ SIGNATURES = {
     "pevit_op_attn_fwd_delta": (c_int, [P, P, P, P, P, P, P, c_float, P, c_int, P, c_int, c_int, c_int]),
     "pevit_op_attn_delta_hpw": (c_int, [c_int, c_int, c_int]),
     "pevit_debug_timeline": (c_int, [P]),
+    "pevit_debug_occupy": (c_int, [P, c_int, c_int, C.c_double]),
     "pevit_op_lowrank_u": (c_int, [P, P, c_int, P, P, P, c_int, c_int, c_int, c_int]),
     "pevit_op_lowrank_grad": (c_int, [P, P, c_int, P, P, c_int, P, P, P, c_int, c_int, c_int, c_int]),
     "pevit_op_lowrank_chunks": (c_int, [c_int]),

@@ -1331,6 +1331,9 @@ extern "C" int pevit_op_attn_fwd_delta(void* stream, void* q, const void* k, voi
     return pevit_launch_attn_fwd_delta((bf16*)q, (const bf16*)k, (bf16*)v, t, (const bf16*)q16, bias, ascale, (bf16*)out, ldo, lse, B, H, N,
                                        (hipStream_t)stream);
 }
+extern "C" int pevit_debug_occupy(void* stream, int workgroups, int lds_bytes, double microseconds) {
+    return pevit_launch_occupy(workgroups, lds_bytes, microseconds, (hipStream_t)stream);
+}
 extern "C" int pevit_debug_timeline(void* buf) { pevit_attn_delta_set_timeline(buf); return 0; }
 extern "C" int pevit_op_attn_delta_hpw(int B, int H, int N) { return pevit_attn_delta_hpw(B, H, N); }
 extern "C" int pevit_op_lowrank_u(void* stream, const void* dqkv, int ld, const void* qT, float* u32, void* u_cols, int B,

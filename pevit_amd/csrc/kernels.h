@@ -156,6 +156,8 @@ int pevit_launch_sgd(float* p, const float* g, float* mom, const unsigned char* 
                      const unsigned* poison = nullptr,    // device word: non-zero = skip the update (stream-K hand-off error)
                      unsigned* skipped = nullptr);        // device counter of the updates skipped that way
 
+int pevit_launch_occupy(int blocks, int lds_bytes, double micros, hipStream_t s);   // measurement only (pevit_debug_occupy)
+
 // ---- fp8.hip (e4m3 codes + power-of-two channel scales of the frozen weights) -----------------
 int pevit_launch_quant_rows_fp8(const float* W, int rows, int cols, unsigned char* out, int ldo, float* scale, int scaled_rows,
                                 float pre, hipStream_t s);

@@ -73,7 +73,34 @@ __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, f
     p[i] -= lr * (nesterov ? d + momentum * buf : buf);      // torch.optim.SGD: grad.add(buf, alpha=momentum)
 }
 
+// measurement only: `blocks` workgroups that hold their CU slots for `micros` microseconds (wall_clock64: 100 MHz), optionally with
+// `lds` bytes of LDS each -- a stand-in for the RCCL kernels of an overlapped all-reduce (scripts/r4_coresidency.py)
+__global__ __launch_bounds__(256) void occupy_kernel(unsigned long long ticks, unsigned* sink) {
+    extern __shared__ char occ_lds[];
+    const unsigned long long t0 = wall_clock64();
+    unsigned acc = 0;
+    while (wall_clock64() - t0 < ticks) {
+        __builtin_amdgcn_s_sleep(32);
+        acc += 1;
+    }
+    if (sink && acc == 0xffffffffu) { occ_lds[threadIdx.x] = 1; sink[0] = acc + occ_lds[0]; }
+}
+
 }  // namespace
+
+int pevit_launch_occupy(int blocks, int lds_bytes, double micros, hipStream_t s) {
+    if (blocks <= 0) return 0;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(occupy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            pevit_set_error("occupy: cannot raise the LDS limit"); return -1;
+        }
+        attr = true;
+    }
+    hipLaunchKernelGGL(occupy_kernel, dim3(blocks), dim3(256), (size_t)lds_bytes, s, (unsigned long long)(micros * 100.0), (unsigned*)nullptr);
+    LAUNCH_OK("occupy_kernel");
+    return 0;
+}
 
 int pevit_launch_cast_bf16(const float* src, bf16* dst, size_t n, float scale, hipStream_t s, int f32) {
     if (n == 0) return 0;
