@@ -217,6 +217,9 @@ def main():
     ap.add_argument("--cpu-sweep", action="store_true", help="only time the CPU baseline at 8/16/32/64/128 threads and exit")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=INT",
                     help="library tuning knob for A/B runs, e.g. gemm_big=0 (see pevit_tune)")
+    ap.add_argument("--exchange", default="rccl", choices=["rccl", "flat"],
+                    help="N > 1: gradient exchange through the process group's all-reduce (RCCL) or through pevit_allreduce_flat "
+                         "(IPC-mapped peer mailboxes + copy engines + deterministic local reduction; csrc/allreduce.hip)")
     ap.add_argument("--dist-backend", default="nccl", help="(tests only) process-group backend; RCCL refuses two ranks on one device, "
                                                             "gloo carries device tensors")
     ap.add_argument("--share-device", action="store_true", help="(tests only) every rank uses cuda:0")
@@ -289,6 +292,8 @@ def main():
         torch.cuda.synchronize()
         del src, dst16
 
+    if world > 1 and args.exchange == "flat":
+        eng.use_flat_allreduce()
     if world > 1:
         eng.sync_replicas()      # parameters, momentum and BatchNorm buffers of rank 0 on every rank, as a real run starts
 
@@ -408,6 +413,7 @@ def main():
                                    f"weights {args.weights}" + (" (e4m3 codes + per-channel scales, bf16 activations, f32 accumulate)"
                                                                  if args.weights == "fp8" else ""),
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                       "gradient_exchange": ("none" if world == 1 else args.exchange),
                        "train_gflop_per_image": gflop, "final_loss": final_loss},
             "roofline": {"bound": "mfma", "kernel": "gemm8_kernel<...> + gemm_kphase_kernel<...> + gemm_kernel<...> + gemm_streamk_kernel<...> (pevit_amd/csrc/gemm.hip: all epilogues / tile shapes)",
                          "achieved": gemm_tflops, "peak": peak, "unit": "TFLOP/s",

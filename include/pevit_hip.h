@@ -299,6 +299,25 @@ int pevit_streamk_error(pevit_ctx* ctx, void* stream);
  * that swallows the error cannot silently train on. */
 int pevit_streamk_status(pevit_ctx* ctx, void* stream, unsigned* error_word, unsigned* skipped_updates);
 
+/* ---- data-parallel gradient exchange without a collective-library kernel (the optional allreduce_flat) ----
+ * The reference has no multi-process path at all (utils/comm.py:62-150 is dormant); `north_star` asks for an all-reduce of the flat
+ * adapter-gradient buffer only.  One pevit_ar per process / GPU: a mailbox in device memory ([2][world][max_floats] + flags,
+ * allocated by pevit_ar_create -- the only allocation), exported as an IPC handle (pevit_ar_handle_bytes() bytes, to be carried to
+ * the peers by whatever the host has: torch.distributed object collectives, a file, MPI) and opened by every peer with
+ * pevit_ar_import.  pevit_allreduce_flat then sums buf[0:n] over the ranks in place: one device-to-device copy of the
+ * contribution into every peer's mailbox + one 4-byte flag copy behind it (copy engines over xGMI; no kernel on the sending GPU),
+ * and a small local kernel that waits for the peers' flags and adds the contributions in RANK ORDER (identical bits on every
+ * rank).  Asynchronous on `stream`; all calls of one pevit_ar must use the same stream, in the same order on every rank.
+ * pevit_ar_error: 1 if a reduction ever gave up waiting for a peer (its buffer is then left unreduced), clears the word. */
+typedef struct pevit_ar pevit_ar;
+int pevit_ar_create(pevit_ar** out, int rank, int world, size_t max_floats);
+void pevit_ar_destroy(pevit_ar* ar);
+int pevit_ar_handle_bytes(void);
+int pevit_ar_export(pevit_ar* ar, void* handle_out);
+int pevit_ar_import(pevit_ar* ar, int peer, const void* handle);
+int pevit_allreduce_flat(pevit_ar* ar, void* stream, float* buf, size_t n);
+int pevit_ar_error(pevit_ar* ar, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -96,6 +96,13 @@ SIGNATURES = {
     "pevit_op_im2col": (c_int, [P, P, P, c_int, c_int, c_int, c_int]),
     "pevit_op_im2col_u8": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int]),
     "pevit_tune": (c_int, [P, c_char_p, c_int]),
+    "pevit_ar_create": (c_int, [C.POINTER(c_void_p), c_int, c_int, c_size_t]),
+    "pevit_ar_destroy": (None, [P]),
+    "pevit_ar_handle_bytes": (c_int, []),
+    "pevit_ar_export": (c_int, [P, P]),
+    "pevit_ar_import": (c_int, [P, c_int, P]),
+    "pevit_allreduce_flat": (c_int, [P, P, P, c_size_t]),
+    "pevit_ar_error": (c_int, [P, P]),
     "pevit_streamk_error": (c_int, [P, P]),
     "pevit_streamk_status": (c_int, [P, P, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
 }

@@ -1,0 +1,177 @@
+// pevit_allreduce_flat: the gradient exchange of data-parallel fine-tuning WITHOUT a collective-library kernel (SURVEY 8b
+// "optional allreduce_flat", SURVEY section 5 "one-shot P2P push + local reduce").
+//
+// The exchanged buffer is tiny (KAdaptation ViT-B/32 + 100-class head: 101,476 floats = 406 KB, in three buckets), so a ring is all
+// latency.  One-shot form, one process per GPU on one node:
+//   * every rank owns a MAILBOX in its HBM: [2 parities][world][capacity] floats + [2][world] flag words, exported once through
+//     hipIpcGetMemHandle and opened by every peer (dmabuf IPC: HSA_ENABLE_IPC_MODE_LEGACY=0);
+//   * all-reduce number e (parity e & 1) of rank r:  for every peer p:  hipMemcpyAsync(p.mail[par][r] <- buf)  then
+//     hipMemcpyAsync(p.flag[par][r] <- e) on the caller's stream -- device-to-device copies into IPC-mapped memory, i.e. the copy
+//     engines over xGMI, no compute unit of either GPU involved; stream order puts the flag behind its data;
+//   * a small local kernel waits (bounded) until flag[par][p] == e for every peer and overwrites buf with
+//     sum_{p = 0 .. world-1} contribution_p  IN RANK ORDER -- the same order on every rank, so the replicas stay bit-identical,
+//     and for world = 2 bit-identical to any other all-reduce (a two-term f32 sum has one value).  Peer data and flags are read
+//     with system-scope loads (they were written by another device; this GPU's L2 may hold lines of the previous use).
+//   * two parities: a rank that is through all-reduce e may push e+1 while a slower peer still reads e; it cannot reach e+2
+//     before that peer has pushed e+1, i.e. after the peer finished reading parity e & 1.
+// What has run: two processes sharing ONE device (tests/test_gpu_allreduce.py) -- IPC export / open, the push, the flag
+// protocol, the reduction order, three buckets per step inside engine.forward_backward_dp.  NOT measured: two GPUs (xGMI).
+#include "../../include/pevit_hip.h"
+#include "common.h"
+#include "kernels.h"
+
+#include <string.h>
+
+#include <new>
+
+namespace {
+constexpr int AR_MAX_WORLD = 16;
+constexpr int AR_STAGE = 8;                 // ring of device words holding the epoch number a flag copy reads from
+}  // namespace
+
+struct pevit_ar {
+    int rank = 0, world = 1;
+    size_t cap = 0;                          // floats per contribution
+    char* base = nullptr;                    // own allocation: mail | flags | stage | err
+    char* peer[AR_MAX_WORLD] = {};           // IPC-opened allocations of the peers (own entry = base)
+    bool opened[AR_MAX_WORLD] = {};
+    unsigned epoch = 0;
+    size_t off_flags = 0, off_stage = 0, off_err = 0, bytes = 0;
+};
+
+namespace {
+
+inline size_t mail_off(const pevit_ar* a, int par, int src) { return ((size_t)par * a->world + src) * a->cap * sizeof(float); }
+inline size_t flag_off(const pevit_ar* a, int par, int src) { return a->off_flags + ((size_t)par * a->world + src) * sizeof(unsigned); }
+
+// buf[i] = sum over ranks (rank order) of: own contribution (buf itself) / the peers' pushed copies in the local mailbox
+__global__ __launch_bounds__(256) void ar_reduce_kernel(float* __restrict__ buf, size_t n, const float* mail, const unsigned* flags,
+                                                        int rank, int world, size_t cap, unsigned epoch, unsigned* err,
+                                                        long long spin_limit) {
+    __shared__ int ok;
+    if (threadIdx.x == 0) {
+        int good = 1;
+        for (int p = 0; p < world && good; ++p) {
+            if (p == rank) continue;
+            long long spins = 0;
+            while (__hip_atomic_load(flags + p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != epoch) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > spin_limit) { good = 0; break; }
+            }
+        }
+        if (!good) atomicExch(err, 1u);      // a peer never arrived: leave buf as it is and raise the error word
+        ok = good;
+    }
+    __syncthreads();
+    if (!ok) return;
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    if (i >= n) return;
+    const bool pair = i + 1 < n;
+    float s0 = 0.f, s1 = 0.f;
+    for (int p = 0; p < world; ++p) {
+        float a, b = 0.f;
+        if (p == rank) {
+            a = buf[i]; if (pair) b = buf[i + 1];
+        } else {
+            const float* src = mail + (size_t)p * cap + i;
+            if (pair && ((reinterpret_cast<uintptr_t>(src) & 7) == 0)) {
+                const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(src), __ATOMIC_RELAXED,
+                                                               __HIP_MEMORY_SCOPE_SYSTEM);
+                a = __uint_as_float((unsigned)(v & 0xffffffffu)); b = __uint_as_float((unsigned)(v >> 32));
+            } else {
+                a = __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(src), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+                if (pair) b = __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(src + 1), __ATOMIC_RELAXED,
+                                                                __HIP_MEMORY_SCOPE_SYSTEM));
+            }
+        }
+        s0 += a; s1 += b;                    // p = 0, 1, ..., world-1: one order everywhere
+    }
+    buf[i] = s0; if (pair) buf[i + 1] = s1;
+}
+
+}  // namespace
+
+extern "C" int pevit_ar_create(pevit_ar** out, int rank, int world, size_t max_floats) {
+    if (!out || world < 1 || world > AR_MAX_WORLD || rank < 0 || rank >= world || max_floats == 0) {
+        pevit_set_error("ar_create: bad argument (rank %d, world %d, capacity %zu; world <= %d)", rank, world, max_floats, AR_MAX_WORLD);
+        return -1;
+    }
+    pevit_ar* a = new (std::nothrow) pevit_ar();
+    if (!a) { pevit_set_error("ar_create: out of host memory"); return -1; }
+    a->rank = rank; a->world = world; a->cap = (max_floats + 63) & ~(size_t)63;
+    a->off_flags = align_up(2 * (size_t)world * a->cap * sizeof(float), 256);
+    a->off_stage = align_up(a->off_flags + 2 * (size_t)world * sizeof(unsigned), 256);
+    a->off_err = a->off_stage + AR_STAGE * 256;
+    a->bytes = a->off_err + 256;
+    if (hipMalloc((void**)&a->base, a->bytes) != hipSuccess) { pevit_set_error("ar_create: hipMalloc of %zu bytes failed", a->bytes); delete a; return -1; }
+    if (hipMemset(a->base, 0, a->bytes) != hipSuccess) { pevit_set_error("ar_create: hipMemset failed"); (void)hipFree(a->base); delete a; return -1; }
+    a->peer[rank] = a->base;
+    *out = a;
+    return 0;
+}
+
+extern "C" void pevit_ar_destroy(pevit_ar* a) {
+    if (!a) return;
+    for (int p = 0; p < a->world; ++p)
+        if (a->opened[p]) (void)hipIpcCloseMemHandle(a->peer[p]);
+    if (a->base) (void)hipFree(a->base);
+    delete a;
+}
+
+extern "C" int pevit_ar_handle_bytes(void) { return (int)sizeof(hipIpcMemHandle_t); }
+
+extern "C" int pevit_ar_export(pevit_ar* a, void* handle_out) {
+    if (!a || !handle_out) { pevit_set_error("ar_export: null argument"); return -1; }
+    hipIpcMemHandle_t h;
+    HIP_OK(hipIpcGetMemHandle(&h, a->base));
+    memcpy(handle_out, &h, sizeof(h));
+    return 0;
+}
+
+extern "C" int pevit_ar_import(pevit_ar* a, int peer, const void* handle) {
+    if (!a || !handle || peer < 0 || peer >= a->world) { pevit_set_error("ar_import: bad argument"); return -1; }
+    if (peer == a->rank) return 0;
+    if (a->opened[peer]) { pevit_set_error("ar_import: peer %d already opened", peer); return -1; }
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle, sizeof(h));
+    void* p = nullptr;
+    HIP_OK(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+    a->peer[peer] = (char*)p; a->opened[peer] = true;
+    return 0;
+}
+
+// in place: buf[0:n] <- sum over the ranks of their buf[0:n], identical bits on every rank.  Asynchronous on `stream`.
+extern "C" int pevit_allreduce_flat(pevit_ar* a, void* stream, float* buf, size_t n) {
+    if (!a || !buf) { pevit_set_error("allreduce_flat: null argument"); return -1; }
+    if (n == 0 || a->world == 1) return 0;
+    if (n > a->cap) { pevit_set_error("allreduce_flat: %zu floats exceed the mailbox capacity %zu", n, a->cap); return -1; }
+    for (int p = 0; p < a->world; ++p)
+        if (!a->peer[p]) { pevit_set_error("allreduce_flat: peer %d has not been imported", p); return -1; }
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned e = ++a->epoch;
+    const int par = (int)(e & 1u);
+    unsigned* stage = reinterpret_cast<unsigned*>(a->base + a->off_stage + (size_t)(e % AR_STAGE) * 256);
+    HIP_OK(hipMemsetD32Async((hipDeviceptr_t)stage, (int)e, 1, s));
+    for (int k = 1; k < a->world; ++k) {                       // start with the right-hand neighbour: the pushes of the ranks spread over the links
+        const int p = (a->rank + k) % a->world;
+        HIP_OK(hipMemcpyAsync(a->peer[p] + mail_off(a, par, a->rank), buf, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+        HIP_OK(hipMemcpyAsync(a->peer[p] + flag_off(a, par, a->rank), stage, sizeof(unsigned), hipMemcpyDeviceToDevice, s));
+    }
+    const unsigned blocks = (unsigned)((n + 511) / 512);
+    hipLaunchKernelGGL(ar_reduce_kernel, dim3(blocks), dim3(256), 0, s, buf, n,
+                       reinterpret_cast<const float*>(a->base + mail_off(a, par, 0)),
+                       reinterpret_cast<const unsigned*>(a->base + flag_off(a, par, 0)), a->rank, a->world, a->cap, e,
+                       reinterpret_cast<unsigned*>(a->base + a->off_err), (long long)8000000);      // a few seconds of polling
+    LAUNCH_OK("ar_reduce_kernel");
+    return 0;
+}
+
+// 1 if a reduction ever gave up waiting for a peer (synchronises the stream), 0 otherwise; clears the word
+extern "C" int pevit_ar_error(pevit_ar* a, void* stream) {
+    if (!a) return -1;
+    unsigned v = 0;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return -1;
+    if (hipMemcpy(&v, a->base + a->off_err, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (v) (void)hipMemset(a->base + a->off_err, 0, 4);
+    return v ? 1 : 0;
+}

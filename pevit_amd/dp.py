@@ -43,6 +43,60 @@ def all_reduce_flat(flat_grads: torch.Tensor, group=None) -> float:
     return 1.0 / world
 
 
+class FlatAllReduce:
+    """pevit_allreduce_flat (include/pevit_hip.h, csrc/allreduce.hip): sum all-reduce of a flat f32 device buffer by one-shot
+    pushes into IPC-mapped peer mailboxes + a deterministic local reduction -- no collective-library kernel competes with the
+    one-tile-per-CU GEMMs of the overlapped backward (profiles/r04_dp_evidence.md).  The IPC handles travel through the
+    process group's object collective once, at construction (any backend: gloo in the tests, nccl in production)."""
+
+    def __init__(self, max_floats: int, group=None, device=None):
+        import ctypes as C
+        from . import _lib
+        self._C, self._lib_mod = C, _lib
+        self.lib = _lib.load()
+        self.group = group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        if device is not None:
+            torch.cuda.set_device(device)
+        self._ar = C.c_void_p()
+        _lib.check(self.lib.pevit_ar_create(C.byref(self._ar), self.rank, self.world, int(max_floats)), "pevit_ar_create")
+        hb = self.lib.pevit_ar_handle_bytes()
+        mine = C.create_string_buffer(hb)
+        _lib.check(self.lib.pevit_ar_export(self._ar, mine), "pevit_ar_export")
+        handles = [None] * self.world
+        dist.all_gather_object(handles, bytes(mine.raw), group=group)
+        for p, h in enumerate(handles):
+            if p != self.rank:
+                _lib.check(self.lib.pevit_ar_import(self._ar, p, C.create_string_buffer(h, hb)), "pevit_ar_import")
+        dist.barrier(group=group)                       # every mailbox is open everywhere before the first push
+
+    def all_reduce(self, buf: torch.Tensor, stream=None):
+        """In place, asynchronous on ``stream`` (default: the current stream).  Same stream, same call order on every rank."""
+        if buf.dtype != torch.float32 or not buf.is_contiguous() or not buf.is_cuda:
+            raise self._lib_mod.PevitError("FlatAllReduce.all_reduce: a contiguous float32 device tensor is required")
+        s = self._C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+        self._lib_mod.check(self.lib.pevit_allreduce_flat(self._ar, s, self._C.c_void_p(buf.data_ptr()), buf.numel()),
+                            "pevit_allreduce_flat")
+
+    def check(self, stream=None):
+        s = self._C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+        rc = self.lib.pevit_ar_error(self._ar, s)
+        if rc != 0:
+            raise self._lib_mod.PevitError("pevit_allreduce_flat: a peer's contribution never arrived (gradients of that step were "
+                                           "left unreduced)" if rc > 0 else "pevit_ar_error failed")
+
+    def close(self):
+        if getattr(self, "_ar", None):
+            self.lib.pevit_ar_destroy(self._ar)
+            self._ar = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def average_bn_buffers(running_mean: torch.Tensor, running_var: torch.Tensor, group=None):
     """BatchNorm running statistics are per-rank; average them before a checkpoint/validation
     (the reference has no opinion: it never runs multi-process)."""

@@ -424,6 +424,31 @@ class HipEngine:
         self.sgd_step(lr, momentum, weight_decay, 1.0 / world_size, nesterov)
         return logits, loss
 
+    def use_flat_allreduce(self, process_group=None):
+        """Exchange the gradient buckets with pevit_allreduce_flat (dp.FlatAllReduce: IPC-mapped peer mailboxes, copy-engine
+        pushes, deterministic local reduction on a side stream) instead of the process group's all-reduce."""
+        from . import dp
+        self._flat_ar = dp.FlatAllReduce(self.n_params, group=process_group, device=self.device)
+        self._flat_ar_stream = torch.cuda.Stream(self.device)
+        return self._flat_ar
+
+    def _exchange(self, view, process_group):
+        """Start the sum all-reduce of one gradient bucket; returns something with .wait()."""
+        import torch.distributed as dist
+        ar = getattr(self, "_flat_ar", None)
+        if ar is None:
+            return dist.all_reduce(view, op=dist.ReduceOp.SUM, group=process_group, async_op=True)
+        cur, side = torch.cuda.current_stream(self.device), self._flat_ar_stream
+        ready = torch.cuda.Event(); ready.record(cur)
+        side.wait_event(ready)                          # the bucket's gradients are final
+        ar.all_reduce(view, stream=side)
+        done = torch.cuda.Event(); done.record(side)
+
+        class _W:
+            def wait(_self):
+                torch.cuda.current_stream(self.device).wait_event(done)
+        return _W()
+
     def forward_backward_dp(self, images, labels, bn_training=True, process_group=None):
         """forward_backward() cut into stages so that the gradient exchange overlaps the backward; leaves the
         SUM over ranks in ``self.grads``.  Three buckets of the flat buffer, each all-reduced asynchronously as soon as its
@@ -447,7 +472,7 @@ class HipEngine:
         L = self.arch.layers
         mid = L // 2
         cut = self.lib.pevit_param_layer_offset(self._ctx, mid)
-        work = [dist.all_reduce(self.grads[self.n_tower:], op=dist.ReduceOp.SUM, group=process_group, async_op=True)]
+        work = [self._exchange(self.grads[self.n_tower:], process_group)]
         if self.n_tower == 0:                                  # frozen tower (linear probe): nothing below the head trains
             work[0].wait()
             return self._logits[:B], self._loss
@@ -455,13 +480,13 @@ class HipEngine:
         if mid > 0:
             _lib.check(self.lib.pevit_visual_backward_part(self._ctx, _lib.stream_ptr(), _lib.ptr(dfeat), B, L, mid),
                        "pevit_visual_backward_part")
-            work.append(dist.all_reduce(self.grads[cut:self.n_tower], op=dist.ReduceOp.SUM, group=process_group, async_op=True))
+            work.append(self._exchange(self.grads[cut:self.n_tower], process_group))
             _lib.check(self.lib.pevit_visual_backward_part(self._ctx, _lib.stream_ptr(), None, B, mid, 0),
                        "pevit_visual_backward_part")
-            work.append(dist.all_reduce(self.grads[:cut], op=dist.ReduceOp.SUM, group=process_group, async_op=True))
+            work.append(self._exchange(self.grads[:cut], process_group))
         else:
             self.visual_backward(dfeat)
-            work.append(dist.all_reduce(self.grads[:self.n_tower], op=dist.ReduceOp.SUM, group=process_group, async_op=True))
+            work.append(self._exchange(self.grads[:self.n_tower], process_group))
         for w in work:
             w.wait()
         return self._logits[:B], self._loss
