@@ -111,6 +111,7 @@ struct pevit_ctx {
     int dx_stored = 1;        // dX GEMMs hand the LN-input gradient to LayerNorm backward in the activation storage type (bf16)
     int fused_bn = 0;         // post-MLP adapters: down -> activation -> up (and its backward) as one launch each (adapter.hip
                               // bottleneck_pair_kernel): 24.4 + 22.1 us against 22.9 + 19.5 us for the four GEMM launches -- opt-in
+    int fp8_tail = 1;         // fp8 weights: t = xn P as the bf16 tail of the QKV launch (0: a separate small product, as before round 4)
     int fused_attn_delta = 1; // delta-add + attention forward as one launch where the geometry allows (attn_delta.hip)
     int lowrank_xcd = 1;      // lowrank_grad: XCD-contiguous workgroup order (+0.2 % per step)
     int side_stream = 0;      // adapter-gradient contractions on a second stream: +0.5 % step throughput, but it slows the GEMMs
@@ -600,12 +601,20 @@ int blocks_forward(pevit_ctx* c, hipStream_t s, int B, bool cls_only, int l_lo =
             p.E = E; p.H = H; p.Ntok = N;
             CHECK(gemm(c, EPI_QKV_HEADS, p, s));
         } else {
-            // fp8 codes for the 3E frozen rows; the 64 trainable adapter rows stay bf16 and get their own small product
+            // fp8 codes for the 3E frozen rows; the 64 trainable adapter rows stay bf16: as the bf16 tail of the same launch where the
+            // product runs on the staggered 8-wave kernel (round 4: the separate t = xn P product was the whole 1-2 % by which
+            // the fp8 format trailed bf16), as a small product of their own otherwise
             GemmParams p = gpw(c, at<bf16>(W, v.xn1), E, b.wqkv, E, 3 * E, T, 3 * E, E, b.sqkv);
             if (a8) { p.A = reinterpret_cast<const bf16*>(a8); p.a_fp8 = 1; }
             p.bias = at<float>(A, b.bqkv); p.outb = qkv; p.head_stride = plane; p.E = E; p.H = H; p.Ntok = N;
+            bool tail = false;
+            if (site && !a8 && c->fp8_tail) {
+                GemmParams m = p;
+                m.N = c->NQ; m.B2 = at<bf16>(A, b.wpan); m.ldb2 = E; m.Nb2 = 128; m.n_fp8 = 3 * E; m.outf = at<float>(W, v.t); m.ldo = 64;
+                if (pevit_gemm_mixed_ok(m, c->tune)) { p = m; tail = true; }
+            }
             CHECK(gemm(c, EPI_QKV_HEADS, p, s));
-            if (site) {
+            if (site && !tail) {
                 GemmParams q = gp(at<bf16>(W, v.xn1), E, at<bf16>(A, b.wpan), E, 128, T, 64, E);
                 q.outf = at<float>(W, v.t); q.ldo = 64;
                 CHECK(gemm(c, EPI_F32, q, s));
@@ -1422,6 +1431,7 @@ extern "C" int pevit_tune(pevit_ctx* c, const char* key, int value) {
     if (key && c && !strcmp(key, "dx_stored")) { c->dx_stored = value; return 0; }
     if (key && c && !strcmp(key, "profile_all")) { c->prof_all = value; return 0; }
     if (key && c && !strcmp(key, "fused_attn_delta")) { c->fused_attn_delta = value; return 0; }
+    if (key && c && !strcmp(key, "fp8_tail")) { c->fp8_tail = value; return 0; }
     if (key && c && !strcmp(key, "lowrank_xcd")) { c->lowrank_xcd = value; return 0; }
     pevit_set_error("tune: unknown key %s", key ? key : "(null)");
     return -1;

@@ -466,10 +466,20 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmParams p, int ntiles)
     // fp8 B (BF8): rows of 128 codes = TWO k-tiles, requested with the even k-tile into B stage (kt >> 1) & 1 (as in gemm_kernel);
     // the conversion to bf16 sits in the LOAD section, i.e. beside the partner wave's MFMA section
     const int a_bytes = ((p.M - 1) * p.lda + p.K) * (F8A ? 1 : 2), b_bytes = ((p.Nb - 1) * p.ldb + p.K) * (BF8 || F8A ? 1 : 2);
+    // fp8 B with a bf16 tail (GemmParams::B2): the column tiles at n0 >= n_fp8 stream bf16 rows of B2, one k-tile per stage like
+    // A and like the bf16 kernel (OPS = 0: same requests, same fragment reads, same MFMA order -- bit-identical to it)
+    // (B2 is addressed through B's descriptor, as the byte offset b2_off from B: a second descriptor selected per tile made hipcc
+    // keep both in scratch memory -- 296 bytes per lane -- and every fp8 product of ViT-L/14 lost 12 %)
+    const int n_fp8 = p.n_fp8, Nb2 = p.Nb2, ldb2 = p.ldb2;
+    const bool mixed = BF8 && EPI == EPI_QKV_HEADS && p.B2 != nullptr;
+    const int b2_off = mixed ? (int)(reinterpret_cast<const char*>(p.B2) - reinterpret_cast<const char*>(p.B)) : 0;
+    const int bdesc_bytes = mixed ? b2_off + ((Nb2 - 1) * ldb2 + p.K) * 2 : b_bytes;
+    bool panel = false;                                       // the tile whose sources are set is a bf16-tail tile (workgroup-uniform)
     // 1 KiB pieces (8 rows x 128 bytes) of a k-tile: [0, PA_T) = A, then B; wave w requests the pieces w, w + 8, ... (a tile
     // whose piece count is no multiple of 8 -- 160x256: 52 -- leaves the last round to the first waves)
     int voff[NP];
     auto set_sources = [&](int m0, int n0) {
+        if constexpr (BF8) panel = mixed && n0 >= n_fp8;
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int q = i * NW + wid;                       // wave-uniform
@@ -481,6 +491,12 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmParams p, int ntiles)
             const int lim = is_a ? p.M : p.Nb;
             r = r < lim ? r : lim - 1;
             voff[i] = r * (is_a ? p.lda * (F8A ? 1 : 2) : p.ldb * (BF8 || F8A ? 1 : 2)) + chunk * 16;
+            if constexpr (BF8) {
+                if (panel && !is_a) {
+                    const int r2 = min(n0 - n_fp8 + row, Nb2 - 1);
+                    voff[i] = b2_off + r2 * ldb2 * 2 + chunk * 16;
+                }
+            }
         }
     };
     auto issue_piece = [&](int kt, int i) {
@@ -490,7 +506,10 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmParams p, int ntiles)
         char* dst = smem + (kt & 1) * STAGE_BYTES + q * 1024;
         if (q < PA_T) buffer_lds16(p.A, a_bytes, dst, voff[i], kt * 128);
         else if constexpr (!BF8) buffer_lds16(p.B, b_bytes, dst, voff[i], kt * 128);
-        else if (!(kt & 1)) buffer_lds16(p.B, b_bytes, smem + ((kt >> 1) & 1) * STAGE_BYTES + q * 1024, voff[i], (kt >> 1) * 128);
+        else {
+            const int kk = panel ? kt : (kt >> 1);          // bf16 tail: a k-tile per stage; fp8 rows: two k-tiles, requested with the even one
+            if (panel || !(kt & 1)) buffer_lds16(p.B, bdesc_bytes, smem + (kk & 1) * STAGE_BYTES + q * 1024, voff[i], kk * 128);
+        }
 #endif
     };
     const int frow = lane & 31, fswz = (frow >> 1) & (CH - 1), fhalf = lane >> 5;
@@ -524,6 +543,11 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmParams p, int ntiles)
         // (Tried: one dword per 128-byte line of the dGELU epilogue's saved-activation block requested here, so that the
         // lines travel to the L2 under the k-loop.  In step the kernel got SLOWER, 42.4 vs 38.4 us: the requests compete
         // with the operand stream and the lines are evicted again before the epilogue; profiles/r03_gemm_epilogues.md.)
+        // the k-loop, instantiated twice for fp8 B: PANEL = this tile streams the bf16 tail (B2) and reads bf16 fragments, exactly
+        // the OPS = 0 loop; otherwise the fp8 loop -- chosen once per tile, no format test inside the loop (with the test inside,
+        // every fp8 product of ViT-L/14 lost 12 %)
+        auto kloop = [&](auto panel_c) __attribute__((always_inline)) {
+        constexpr bool PANEL = decltype(panel_c)::value;
         for (int kt = 0; kt < nk; ++kt) {
             const char* st = smem + (kt & 1) * STAGE_BYTES;
             const bool more = kt + 1 < nk;
@@ -555,7 +579,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmParams p, int ntiles)
                     }
                 } else {
                 if constexpr (BF8) {
-                    if (ph == 0) {
+                    if (ph == 0 && !PANEL) {
                         const char* sb = smem + ((kt >> 1) & 1) * STAGE_BYTES;
                         const int c0 = (kt & 1) * 4 + fhalf * 2;
 #pragma unroll
@@ -570,7 +594,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmParams p, int ntiles)
                     const int ks = ph * KSP + s;
 #pragma unroll
                     for (int j = 0; j < WN; ++j) {
-                        if constexpr (BF8) bfr[s][j] = fp8x8_to_bf16(braw[j][ks >> 1][(ks & 1) * 2], braw[j][ks >> 1][(ks & 1) * 2 + 1]);
+                        if constexpr (BF8 && !PANEL) bfr[s][j] = fp8x8_to_bf16(braw[j][ks >> 1][(ks & 1) * 2], braw[j][ks >> 1][(ks & 1) * 2 + 1]);
                         else bfr[s][j] = *reinterpret_cast<const bf16x8*>(st + b_base + j * 32 * ROWB + coff[ks]);
                     }
 #pragma unroll
@@ -607,10 +631,14 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmParams p, int ntiles)
                 __builtin_amdgcn_s_barrier();
             }
         }
+        };
+        if constexpr (BF8 && EPI == EPI_QKV_HEADS) { if (panel) kloop(std::true_type{}); else kloop(std::false_type{}); }   // only the QKV product has a tail
+        else kloop(std::false_type{});
         if (!grp) __builtin_amdgcn_s_barrier();                     // ... and the lower half waits for it here
         // both stages are idle: stage 0 receives the next tile's first k-tile while the epilogue transposes through
         // (this wave's 8 KiB of) stage 1
         const int cm0 = m0, cn0 = n0;
+        const bool scaled = (BF8 || F8A) && p.bscale && !panel;   // the bf16 tail carries no channel scales (captured before the next tile's sources are set)
         const int next = tile + gridDim.x;
         if (next < ntiles) {
             tile_origin<BM, BN>(p, next, m0, n0);
@@ -662,7 +690,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmParams p, int ntiles)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) bsc[e] = 1.0f;
                 if constexpr (BF8 || F8A) {
-                    if (p.bscale) {
+                    if (scaled) {
                         const float4 b0 = *reinterpret_cast<const float4*>(p.bscale + gc), b1 = *reinterpret_cast<const float4*>(p.bscale + gc + 4);
                         bsc[0] = b0.x; bsc[1] = b0.y; bsc[2] = b0.z; bsc[3] = b0.w; bsc[4] = b1.x; bsc[5] = b1.y; bsc[6] = b1.z; bsc[7] = b1.w;
                     }
@@ -715,7 +743,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmParams p, int ntiles)
                     float v[8];
                     from_lds(ps, v);
                     if (row < p.M && gc < p.N) {
-                        if constexpr (BF8 || F8A) { if (p.bscale) mul8(v, p.bscale + gc); }
+                        if constexpr (BF8 || F8A) { if (scaled) mul8(v, p.bscale + gc); }
                         epilogue_store<EPI, bf16>(p, row, gc, v);
                     }
                 }
@@ -1819,6 +1847,18 @@ int launch_f8a(const GemmParams& p, const GemmTune& t, hipStream_t stream) {
 
 }  // namespace
 
+// the bf16 tail of an fp8-B problem (GemmParams::B2) is implemented by gemm8_kernel<.., OPS = 1> only: true when launch_epi would
+// take one of its 256-column tiles for this problem and the tail starts on a tile boundary
+bool pevit_gemm_mixed_ok(const GemmParams& p, const GemmTune& t) {
+    if (!p.b_fp8 || p.a_fp8 || !p.B2 || p.n_fp8 % 256 || p.K % 128) return false;       // (EPI_QKV_HEADS only: pevit_launch_gemm checks)
+    if (!big8_ok(p, t)) return false;
+    // the tail is addressed through B's buffer descriptor: it must lie behind B, within 31 bits of it
+    const long long off = reinterpret_cast<const char*>(p.B2) - reinterpret_cast<const char*>(p.B);
+    if (off <= 0 || off + ((long long)p.Nb2 * p.ldb2 + p.K) * 2 >= (1LL << 31)) return false;
+    const int cfg = pick_config(p, t, true);
+    return cfg == 5 || cfg == 4 || cfg == CFG_160x256;
+}
+
 int pevit_gemm_sk_slots() { return min(2 * num_cus(), PEVIT_SK_MAX_SLOTS) & ~7; }
 int pevit_gemm_last_path() { return g_last_path; }
 
@@ -1841,6 +1881,7 @@ int pevit_launch_gemm(int epi, const GemmParams& p_in, const GemmTune& t, hipStr
         pevit_set_error("gemm: epilogue %d has no fp8 x fp8 form", epi);
         return -1;
     }
+    if (p.B2 && (epi != EPI_QKV_HEADS || !pevit_gemm_mixed_ok(p, t))) { pevit_set_error("gemm: this problem has no kernel with a bf16 tail (ask pevit_gemm_mixed_ok first)"); return -1; }
     if (p.b_fp8) {
         if (p.K % 128 != 0) { pevit_set_error("gemm: fp8 B needs K=%d to be a multiple of 128", p.K); return -1; }
         // the frozen-weight products of the block and their dX forms

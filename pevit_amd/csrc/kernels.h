@@ -21,6 +21,10 @@ enum GemmEpilogue {
 struct GemmParams {
     const bf16* A; int lda;
     const void* B; int ldb; int Nb;   // Nb = readable rows of B (>= N); ldb in elements (bf16, or fp8 codes)
+    // fp8 B with a bf16 tail (the QKV product of the attention-site adapters with fp8 frozen weights): output columns >= n_fp8 take
+    // their B rows from B2 (bf16, pitch ldb2 elements, Nb2 readable rows) -- the 64 trainable panel rows P_q^T | P_v^T -- inside the
+    // same launch (gemm8_kernel only: pevit_gemm_mixed_ok).  n_fp8 must be a multiple of the tile width.  B2 == nullptr: off.
+    const bf16* B2; int ldb2, Nb2, n_fp8;
     int b_fp8;                        // B holds e4m3 codes, k-permuted per 128 (fp8_kperm), K % 128 == 0
     int a_fp8;                        // A holds e4m3 codes as well (lda in codes): fp8 x fp8 on the MX matrix instruction (needs b_fp8)
     int out2_fp8;                     // EPI_BIAS_GELU: the activation output (outb2, ldob2 in codes) is written as k-permuted e4m3 codes
@@ -72,6 +76,7 @@ int pevit_gemm_last_path();                        // 1 plain tile, 2 staggered 
 int pevit_gemm_sk_slots();                         // residency slots of the stream-K kernel on this device (2 per CU, multiple of 8)
 
 int pevit_launch_gemm(int epi, const GemmParams& p, const GemmTune& t, hipStream_t stream);
+bool pevit_gemm_mixed_ok(const GemmParams& p, const GemmTune& t);   // would this fp8-B problem with a bf16 tail (B2) run on a kernel that supports it?
 
 // ---- norm.hip --------------------------------------------------------------------
 // y = LN(x) * gamma + beta over the last dim (eps 1e-5, f32 statistics: model.py:154-160)
