@@ -177,7 +177,7 @@ int pevit_train_forward_backward(pevit_ctx* ctx, void* stream, const float* imag
 enum pevit_prof_kind {
     PEVIT_PROF_LN_FWD = 0, PEVIT_PROF_LN_BWD = 1, PEVIT_PROF_ATTN_FWD = 2, PEVIT_PROF_ATTN_BWD = 3, PEVIT_PROF_DELTA_ADD = 4,
     PEVIT_PROF_LOWRANK_U = 5, PEVIT_PROF_LOWRANK_GRAD = 6, PEVIT_PROF_IM2COL = 7, PEVIT_PROF_LOWRANK_BWD = 8,
-    PEVIT_PROF_ATTN_FWD_DELTA = 9
+    PEVIT_PROF_ATTN_FWD_DELTA = 9, PEVIT_PROF_ADAPTER_FWD = 10, PEVIT_PROF_ADAPTER_BWD = 11
 };
 int pevit_profile_begin(pevit_ctx* ctx, int max_launches);
 int pevit_profile_end(pevit_ctx* ctx, double* total_ms, double* total_flops, double* total_bytes, int* launches);
@@ -282,7 +282,8 @@ int pevit_op_im2col_u8(void* stream, const uint8_t* images, const float* mean3, 
  * offset), "gemm_ksplit_small", "gemm_ksplit_mink", "gemm_kphase_nl" (requests in the LOAD section: 8, or between the
  * MFMAs: 2), "gemm_stagger" (0 = legacy 8-wave kernel, 1 = staggered, 2 = also the 256x128 tile), "gemm_band",
  * "gemm_skinny" (0 = never use the few-row split-K kernel), "gemm_skinny_maxm" / "_mink" / "_slices", "gemm_sk_share" /
- * "gemm_sk_band" (with gemm_streamk = 2), "lowrank_xcd", "fused_bottleneck", "profile_all", "fused_attn_delta" (0 = delta_add + attn_fwd as two launches), "fp8_tail" (0 = t = xn P as a launch of its own with fp8 weights) and
+ * "gemm_sk_band" (with gemm_streamk = 2), "lowrank_xcd", "fused_bottleneck", "profile_all", "fused_attn_delta" (0 = delta_add + attn_fwd as two launches), "fp8_tail" (0 = t = xn P as a launch of its own with fp8 weights), "adapter_fused" (0 = the post-MLP adapter as separate
+ * LayerNorm / GEMM launches) and
  * "dx_stored" (ctx only);
  * returns 0, or -1 for an unknown key */
 int pevit_tune(pevit_ctx* ctx, const char* key, int value);

@@ -254,7 +254,7 @@ __global__ __launch_bounds__(64 * LNA_WAVES) void ln_bwd_affine_kernel(const flo
                 o.x = rstd * (gd[i].x - m1 - xh[i].x * m2); o.y = rstd * (gd[i].y - m1 - xh[i].y * m2);
                 o.z = rstd * (gd[i].z - m1 - xh[i].z * m2); o.w = rstd * (gd[i].w - m1 - xh[i].w * m2);
                 o.x += cr[i].x; o.y += cr[i].y; o.z += cr[i].z; o.w += cr[i].w;
-                *reinterpret_cast<float4*>(dx + base + c) = o;
+                if (dx) *reinterpret_cast<float4*>(dx + base + c) = o;       // (the engine consumes only the stored-type copy)
                 if (dx_bf16) st_store4<ST>(dx_bf16, base + c, o.x, o.y, o.z, o.w);
             }
         }

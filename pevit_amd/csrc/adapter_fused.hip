@@ -1,0 +1,470 @@
+// Post-MLP bottleneck adapters (Adapter: adapter_model.py:264-282,330-336; Compacter: compacter_model.py:432-448,497-503) as ONE
+// launch per direction (round 4).
+//
+//   forward   x_out = x_mid + h + up(act(down(LN_a(h))))        h = c_proj(gelu(c_fc(ln_2 x))) + b
+//   before:   c_proj GEMM writing TWO f32 tensors (x_mid + h and h), LayerNorm, down GEMM (+ activation), up GEMM (+ residual):
+//             four launches, ~118 MB per layer at B = 128;
+//   here:     the c_proj GEMM writes its accumulators once (f32, bias not yet added), and adapter_fwd_kernel takes 32 token rows
+//             per workgroup through  h = acc + b  ->  LayerNorm statistics  ->  z (bf16, saved; LDS)  ->  down product on the
+//             matrix core (K = E split over the four waves, fixed-order LDS reduction)  ->  activation (saved)  ->  up product
+//             ->  x_out = (x_mid + h) + up + b_up,  reading h and x_mid once: two launches, ~89 MB.
+//   backward  adapter_bwd_kernel, the same skeleton: dyb rows -> LDS, d pre = (dy Wu) * act' (saved, feeds the d W_down contraction),
+//             d z = d pre Wd (f32, stays in LDS), LayerNorm backward with the affine-gradient column sums, d h = dx_out + LN'(d z)
+//             as the bf16 operand of the c_proj backward GEMM -- replaces the dReLU GEMM, the d z GEMM (19.7 MB written and read
+//             back) and ln_bwd_affine.
+// Same rounding points as the separate kernels and as oracle/emul_bf16.py: z, act (and Compacter's pre-activation), d pre in bf16;
+// everything else f32.  The token-contracted weight gradients stay with tn_gemm64 (adapter.hip).
+#include "common.h"
+#include "kernels.h"
+#include "gemm_epilogue.h"
+
+namespace {
+
+constexpr int AF_ROWS = 32;          // token rows per workgroup
+#ifndef AF_WAVES_V
+#define AF_WAVES_V 8
+#endif
+constexpr int AF_WAVES = AF_WAVES_V;      // 8: two waves per SIMD (with 4 every phase of the single resident workgroup ran exposed: 33 us)
+constexpr int AF_MAXV = 4;           // float4 per lane and row: E <= 1024
+constexpr int AF_RPW = AF_ROWS / AF_WAVES;
+constexpr int AF_CPT = AF_ROWS * 64 / (64 * AF_WAVES);      // columns of the 32 x 64 middle operand per thread
+static_assert(AF_RPW % 4 == 0 && (AF_CPT == 8 || AF_CPT == 4), "row batches of four; 4 or 8 middle columns per thread");
+
+struct AfLds {                       // byte offsets inside the dynamic LDS block (E-dependent)
+    int zs, red, as, u, colred, total;
+};
+__host__ __device__ inline AfLds af_layout(int E) {
+    AfLds l;
+    const int zs_bytes = AF_ROWS * (E + 8) * 2;                  // bf16 rows, 16 bytes of padding
+    const int red_bytes = AF_WAVES * AF_ROWS * 64 * 4;           // per-wave partial [32][64] f32 of the K-split product
+    const int u_bytes = AF_ROWS * (E + 4) * 4;                   // f32 result of the second product (aliases zs + red)
+    l.zs = 0; l.red = zs_bytes; l.u = 0;
+    const int front = zs_bytes + red_bytes > u_bytes ? zs_bytes + red_bytes : u_bytes;
+    l.as = (front + 15) & ~15;                                   // [32][72] bf16: the 64-wide middle operand
+    l.colred = l.as + AF_ROWS * 72 * 2;                          // end of the block (the backward column sums alias U)
+    l.total = l.colred;
+    return l;
+}
+
+// first product: P[32][64] = X[32][E] (LDS, bf16) . W[64][E]^T (global, bf16), K = E split over the four waves; the partials meet in
+// LDS and thread t sums row t / 8, columns 8 (t % 8) .. +7 over the waves in a fixed order.  Returns this thread's 8 sums in v.
+__device__ __forceinline__ void af_first_product(const bf16* Xs, int ldx, const bf16* __restrict__ W, int E, float* red, int wid,
+                                                 int lane, int tid, float (&v)[AF_CPT]) {
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const int kw = E / AF_WAVES, k0 = wid * kw;
+    const int frow = lane & 31, fk = 8 * (lane >> 5);
+    for (int ks = 0; ks < kw; ks += 64) {                       // four k-steps per round: the weight fragments of a round requested together
+        bf16x8 b[4][2], a[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int k = min(k0 + ks + 16 * s, E - 16) + fk;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[s][j] = load_bf16x8(W + (size_t)(32 * j + frow) * E + k);
+            a[s] = *reinterpret_cast<const bf16x8*>(Xs + frow * ldx + k);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (ks + 16 * s < kw) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], b[s][j], acc[j], 0, 0, 0);
+            }
+        }
+    }
+    float* mine = red + wid * (AF_ROWS * 64);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            mine[row * 64 + 32 * j + frow] = acc[j][r];
+        }
+    __syncthreads();
+    constexpr int TPR = 64 / AF_CPT;                            // threads per row
+    const int row = tid / TPR, c0 = (tid % TPR) * AF_CPT;
+#pragma unroll
+    for (int i = 0; i < AF_CPT; ++i) v[i] = 0.f;
+#pragma unroll
+    for (int w = 0; w < AF_WAVES; ++w) {
+#pragma unroll
+        for (int q = 0; q < AF_CPT / 4; ++q) {
+            const float4 x0 = *reinterpret_cast<const float4*>(red + w * (AF_ROWS * 64) + row * 64 + c0 + 4 * q);
+            v[4 * q] += x0.x; v[4 * q + 1] += x0.y; v[4 * q + 2] += x0.z; v[4 * q + 3] += x0.w;
+        }
+    }
+}
+// AF_CPT consecutive bf16 of the middle operand: LDS image and (row < T) the saved global copy
+__device__ __forceinline__ void af_store_mid(bf16* lds, bf16* glob, bool to_glob, const bf16 (&o)[AF_CPT]) {
+    if constexpr (AF_CPT == 8) {
+        bf16x8 t;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = o[i];
+        *reinterpret_cast<bf16x8*>(lds) = t;
+        if (to_glob) store_bf16x8(glob, t);
+    } else {
+        bf16x4 t;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[i] = o[i];
+        *reinterpret_cast<bf16x4*>(lds) = t;
+        if (to_glob) *reinterpret_cast<bf16x4*>(glob) = t;
+    }
+}
+
+// second product: U[32][E] (LDS, f32, row stride E + 4) = S[32][64] (LDS, bf16, row stride 72) . W[E][64]^T (global, bf16)
+__device__ __forceinline__ void af_second_product(const bf16* Ss, const bf16* __restrict__ W, int E, float* U, int wid, int lane) {
+    const int frow = lane & 31, fk = 8 * (lane >> 5);
+    bf16x8 a[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) a[s] = *reinterpret_cast<const bf16x8*>(Ss + frow * 72 + 16 * s + fk);
+    const int nfrag = E / 32;
+    for (int f0 = wid; f0 < nfrag; f0 += 2 * AF_WAVES) {        // two fragments per round: 8 weight requests in flight
+        bf16x8 b[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int f = min(f0 + AF_WAVES * u, nfrag - 1);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) b[u][s] = load_bf16x8(W + (size_t)(32 * f + frow) * 64 + 16 * s + fk);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int f = f0 + AF_WAVES * u;
+            if (f < nfrag) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], b[u][s], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    U[row * (E + 4) + 32 * f + frow] = acc[r];
+                }
+            }
+        }
+    }
+}
+
+// ACT: 0 = ReLU (Adapter), 1 = gelu_new on the bf16 pre-activation (Compacter)
+template <int ACT>
+__global__ __launch_bounds__(64 * AF_WAVES) void adapter_fwd_kernel(const float* __restrict__ hraw, const float* __restrict__ bpr,
+                                                                    const float* __restrict__ x_mid, const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta, const bf16* __restrict__ wd,
+                                                                    const float* __restrict__ b_down, const bf16* __restrict__ wu,
+                                                                    const float* __restrict__ b_up, bf16* __restrict__ z,
+                                                                    float* __restrict__ mean_a, float* __restrict__ rstd_a,
+                                                                    bf16* __restrict__ act, bf16* __restrict__ apre,
+                                                                    float* __restrict__ x_out, int T, int E, int rb) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const AfLds L = af_layout(E);
+    bf16* Zs = reinterpret_cast<bf16*>(smem + L.zs);
+    float* red = reinterpret_cast<float*>(smem + L.red);
+    bf16* As = reinterpret_cast<bf16*>(smem + L.as);
+    float* U = reinterpret_cast<float*>(smem + L.u);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int r0 = blockIdx.x * rb, rend = min(r0 + rb, T);    // this workgroup owns rows [r0, rend): rb <= 32 of the 32-row tile
+    const int ldz = E + 8;
+    bool cok[AF_MAXV]; int cc[AF_MAXV];
+    float4 gm[AF_MAXV], bt[AF_MAXV], bp[AF_MAXV];
+#pragma unroll
+    for (int i = 0; i < AF_MAXV; ++i) {
+        const int c = lane * 4 + i * 256;
+        cok[i] = c < E; cc[i] = cok[i] ? c : 0;
+        gm[i] = *reinterpret_cast<const float4*>(gamma + cc[i]);
+        bt[i] = *reinterpret_cast<const float4*>(beta + cc[i]);
+        bp[i] = *reinterpret_cast<const float4*>(bpr + cc[i]);
+    }
+    // ---- phase 1: the wave's 8 rows, 4 at a time (all 8 loads of a batch in flight): h = acc + b, statistics, z, s = x_mid + h
+    float4 s[AF_RPW][AF_MAXV];
+#pragma unroll
+    for (int half = 0; half < AF_RPW / 4; ++half) {
+        float4 hv[4][AF_MAXV], xv[4][AF_MAXV];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int row = min(r0 + wid * AF_RPW + half * 4 + k, T - 1);
+#pragma unroll
+            for (int i = 0; i < AF_MAXV; ++i) {
+                hv[k][i] = *reinterpret_cast<const float4*>(hraw + (size_t)row * E + cc[i]);
+                xv[k][i] = *reinterpret_cast<const float4*>(x_mid + (size_t)row * E + cc[i]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int lr = wid * AF_RPW + half * 4 + k, row = r0 + lr;
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < AF_MAXV; ++i) {
+                hv[k][i].x += bp[i].x; hv[k][i].y += bp[i].y; hv[k][i].z += bp[i].z; hv[k][i].w += bp[i].w;
+                sum += cok[i] ? hv[k][i].x + hv[k][i].y + hv[k][i].z + hv[k][i].w : 0.f;
+            }
+            const float mean = wave_sum(sum) / (float)E;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < AF_MAXV; ++i) {
+                const float a = hv[k][i].x - mean, b = hv[k][i].y - mean, c = hv[k][i].z - mean, d = hv[k][i].w - mean;
+                q += cok[i] ? a * a + b * b + c * c + d * d : 0.f;
+            }
+            const float rstd = rsqrtf(wave_sum(q) / (float)E + 1e-5f);
+            if (lane == 0 && row < rend) { mean_a[row] = mean; rstd_a[row] = rstd; }
+#pragma unroll
+            for (int i = 0; i < AF_MAXV; ++i) {
+                const float4 h4 = hv[k][i];
+                bf16x4 o;
+                o[0] = f2bf((h4.x - mean) * rstd * gm[i].x + bt[i].x); o[1] = f2bf((h4.y - mean) * rstd * gm[i].y + bt[i].y);
+                o[2] = f2bf((h4.z - mean) * rstd * gm[i].z + bt[i].z); o[3] = f2bf((h4.w - mean) * rstd * gm[i].w + bt[i].w);
+                if (cok[i]) {
+                    *reinterpret_cast<bf16x4*>(Zs + lr * ldz + cc[i]) = o;
+                    if (row < rend) *reinterpret_cast<bf16x4*>(z + (size_t)row * E + cc[i]) = o;
+                }
+                s[half * 4 + k][i] = make_float4(h4.x + xv[k][i].x, h4.y + xv[k][i].y, h4.z + xv[k][i].z, h4.w + xv[k][i].w);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: pre = z Wd^T + b_down, activation
+    {
+        float v[AF_CPT];
+        af_first_product(Zs, ldz, wd, E, red, wid, lane, tid, v);
+        constexpr int TPR = 64 / AF_CPT;
+        const int lr = tid / TPR, c0 = (tid % TPR) * AF_CPT, row = r0 + lr;
+        bf16 o[AF_CPT], pre8[AF_CPT];
+#pragma unroll
+        for (int i = 0; i < AF_CPT; ++i) {
+            const float pv = v[i] + b_down[c0 + i];
+            if constexpr (ACT == 0) { o[i] = f2bf(fmaxf(pv, 0.0f)); pre8[i] = o[i]; }
+            else { pre8[i] = f2bf(pv); o[i] = f2bf(gelu_new_f(bf2f(pre8[i]))); }
+        }
+        af_store_mid(As + lr * 72 + c0, act + (size_t)min(row, T - 1) * 64 + c0, row < rend, o);
+        if constexpr (ACT == 1) {
+            if (row < rend) {
+                if constexpr (AF_CPT == 8) { bf16x8 t; for (int i = 0; i < 8; ++i) t[i] = pre8[i]; store_bf16x8(apre + (size_t)row * 64 + c0, t); }
+                else { bf16x4 t; for (int i = 0; i < 4; ++i) t[i] = pre8[i]; *reinterpret_cast<bf16x4*>(apre + (size_t)row * 64 + c0) = t; }
+            }
+        }
+    }
+    __syncthreads();                                            // As complete; Zs / red are dead: U may overwrite them
+    // ---- phase 3: U = act Wu^T
+    af_second_product(As, wu, E, U, wid, lane);
+    __syncthreads();
+    // ---- phase 4: x_out = (x_mid + h) + U + b_up
+#pragma unroll
+    for (int k = 0; k < AF_RPW; ++k) {
+        const int lr = wid * AF_RPW + k, row = r0 + lr;
+#pragma unroll
+        for (int i = 0; i < AF_MAXV; ++i) {
+            if (cok[i] && row < rend) {
+                const float4 u = *reinterpret_cast<const float4*>(U + lr * (E + 4) + cc[i]);
+                const float4 b = *reinterpret_cast<const float4*>(b_up + cc[i]);
+                float4 o;
+                o.x = s[k][i].x + (u.x + b.x); o.y = s[k][i].y + (u.y + b.y); o.z = s[k][i].z + (u.z + b.z); o.w = s[k][i].w + (u.w + b.w);
+                *reinterpret_cast<float4*>(x_out + (size_t)row * E + cc[i]) = o;
+            }
+        }
+    }
+}
+
+// backward.  dyb: bf16 copy of dx_out (the operand of the products), dres: dx_out itself (f32).  Outputs: dpre (bf16 [T][64], feeds
+// the d W_down contraction), dh_bf16 = bf16(dres + LN_a'(d z)) (operand of the c_proj backward GEMM), partial[block][3][E] =
+// column sums of dz*xhat (d gamma), dz (d beta), dres (d b_up) over the block's rows (layout of ln_bwd_affine_kernel).
+template <int ACT>
+__global__ __launch_bounds__(64 * AF_WAVES) void adapter_bwd_kernel(const bf16* __restrict__ dyb, const float* __restrict__ dres,
+                                                                    const bf16* __restrict__ wuT, const bf16* __restrict__ saved,
+                                                                    const bf16* __restrict__ wdT, const float* __restrict__ hraw,
+                                                                    const float* __restrict__ bpr, const float* __restrict__ mean_a,
+                                                                    const float* __restrict__ rstd_a, const float* __restrict__ gamma,
+                                                                    bf16* __restrict__ dpre, bf16* __restrict__ dh_bf16,
+                                                                    float* __restrict__ partial, int T, int E, int rb) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const AfLds L = af_layout(E);
+    bf16* Ys = reinterpret_cast<bf16*>(smem + L.zs);
+    float* red = reinterpret_cast<float*>(smem + L.red);
+    bf16* Ds = reinterpret_cast<bf16*>(smem + L.as);
+    float* U = reinterpret_cast<float*>(smem + L.u);
+    float* colred = reinterpret_cast<float*>(smem + L.u);       // aliases U after the row walk
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int r0 = blockIdx.x * rb, rend = min(r0 + rb, T);    // this workgroup owns rows [r0, rend): rb <= 32 of the 32-row tile
+    const int ldz = E + 8;
+    // ---- phase 1: dyb rows -> LDS (16-byte pieces; rows beyond T read row T - 1, their results are never stored)
+    {
+        const int ppr = E / 8;
+        for (int idx = tid; idx < AF_ROWS * ppr; idx += 64 * AF_WAVES) {
+            const int lr = idx / ppr, c = idx - lr * ppr;
+            const int row = min(r0 + lr, T - 1);
+            *reinterpret_cast<bf16x8*>(Ys + lr * ldz + 8 * c) = load_bf16x8(dyb + (size_t)row * E + 8 * c);
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: d pre = (dy Wu) * act'
+    {
+        float v[AF_CPT];
+        af_first_product(Ys, ldz, wuT, E, red, wid, lane, tid, v);
+        constexpr int TPR = 64 / AF_CPT;
+        const int lr = tid / TPR, c0 = (tid % TPR) * AF_CPT, row = r0 + lr;
+        bf16 sv[AF_CPT], o[AF_CPT];
+        if constexpr (AF_CPT == 8) { const bf16x8 t = load_bf16x8(saved + (size_t)min(row, T - 1) * 64 + c0); for (int i = 0; i < 8; ++i) sv[i] = t[i]; }
+        else { const bf16x4 t = *reinterpret_cast<const bf16x4*>(saved + (size_t)min(row, T - 1) * 64 + c0); for (int i = 0; i < 4; ++i) sv[i] = t[i]; }
+#pragma unroll
+        for (int i = 0; i < AF_CPT; ++i) {
+            const float h = bf2f(sv[i]);
+            o[i] = f2bf(ACT == 0 ? (h > 0.f ? v[i] : 0.f) : v[i] * gelu_new_grad_f(h));
+        }
+        af_store_mid(Ds + lr * 72 + c0, dpre + (size_t)min(row, T - 1) * 64 + c0, row < rend, o);
+    }
+    __syncthreads();
+    // ---- phase 3: d z = d pre Wd
+    af_second_product(Ds, wdT, E, U, wid, lane);
+    __syncthreads();
+    // ---- phase 4: LayerNorm backward of the wave's rows; column sums
+    bool cok[AF_MAXV]; int cc[AF_MAXV];
+    float4 gv[AF_MAXV], bp[AF_MAXV], ag[AF_MAXV], ab[AF_MAXV], ar[AF_MAXV];
+#pragma unroll
+    for (int i = 0; i < AF_MAXV; ++i) {
+        const int c = lane * 4 + i * 256;
+        cok[i] = c < E; cc[i] = cok[i] ? c : 0;
+        gv[i] = *reinterpret_cast<const float4*>(gamma + cc[i]);
+        bp[i] = *reinterpret_cast<const float4*>(bpr + cc[i]);
+        ag[i] = make_float4(0.f, 0.f, 0.f, 0.f); ab[i] = ag[i]; ar[i] = ag[i];
+    }
+#pragma unroll
+    for (int half = 0; half < AF_RPW / 4; ++half) {
+        float4 xv[4][AF_MAXV], rv[4][AF_MAXV];
+        float mu[4], rs[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int row = min(r0 + wid * AF_RPW + half * 4 + k, T - 1);
+#pragma unroll
+            for (int i = 0; i < AF_MAXV; ++i) {
+                xv[k][i] = *reinterpret_cast<const float4*>(hraw + (size_t)row * E + cc[i]);
+                rv[k][i] = *reinterpret_cast<const float4*>(dres + (size_t)row * E + cc[i]);
+            }
+            mu[k] = mean_a[row]; rs[k] = rstd_a[row];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int lr = wid * AF_RPW + half * 4 + k, row = r0 + lr;
+            const bool rok = row < rend;
+            const float mean = mu[k], rstd = rs[k];
+            float4 d[AF_MAXV], xh[AF_MAXV], gd[AF_MAXV];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < AF_MAXV; ++i) {
+                d[i] = *reinterpret_cast<const float4*>(U + lr * (E + 4) + cc[i]);
+                const float4 x4 = make_float4(xv[k][i].x + bp[i].x, xv[k][i].y + bp[i].y, xv[k][i].z + bp[i].z, xv[k][i].w + bp[i].w);
+                xh[i] = make_float4((x4.x - mean) * rstd, (x4.y - mean) * rstd, (x4.z - mean) * rstd, (x4.w - mean) * rstd);
+                if (rok && cok[i]) {
+                    ag[i].x += d[i].x * xh[i].x; ag[i].y += d[i].y * xh[i].y; ag[i].z += d[i].z * xh[i].z; ag[i].w += d[i].w * xh[i].w;
+                    ab[i].x += d[i].x; ab[i].y += d[i].y; ab[i].z += d[i].z; ab[i].w += d[i].w;
+                    ar[i].x += rv[k][i].x; ar[i].y += rv[k][i].y; ar[i].z += rv[k][i].z; ar[i].w += rv[k][i].w;
+                }
+                gd[i] = make_float4(d[i].x * gv[i].x, d[i].y * gv[i].y, d[i].z * gv[i].z, d[i].w * gv[i].w);
+                s1 += cok[i] ? gd[i].x + gd[i].y + gd[i].z + gd[i].w : 0.f;
+                s2 += cok[i] ? gd[i].x * xh[i].x + gd[i].y * xh[i].y + gd[i].z * xh[i].z + gd[i].w * xh[i].w : 0.f;
+            }
+            const float m1 = wave_sum(s1) / (float)E, m2 = wave_sum(s2) / (float)E;
+#pragma unroll
+            for (int i = 0; i < AF_MAXV; ++i) {
+                if (rok && cok[i]) {
+                    bf16x4 o;
+                    o[0] = f2bf(rstd * (gd[i].x - m1 - xh[i].x * m2) + rv[k][i].x); o[1] = f2bf(rstd * (gd[i].y - m1 - xh[i].y * m2) + rv[k][i].y);
+                    o[2] = f2bf(rstd * (gd[i].z - m1 - xh[i].z * m2) + rv[k][i].z); o[3] = f2bf(rstd * (gd[i].w - m1 - xh[i].w * m2) + rv[k][i].w);
+                    *reinterpret_cast<bf16x4*>(dh_bf16 + (size_t)row * E + cc[i]) = o;
+                }
+            }
+        }
+    }
+    // column sums of the block: waves 1..3 through LDS (over U, which every wave has finished reading), wave 0 adds them in order
+    __syncthreads();
+    if (wid > 0) {
+#pragma unroll
+        for (int i = 0; i < AF_MAXV; ++i) {
+            if (cok[i]) {
+                *reinterpret_cast<float4*>(colred + ((size_t)(wid - 1) * 3 + 0) * E + cc[i]) = ag[i];
+                *reinterpret_cast<float4*>(colred + ((size_t)(wid - 1) * 3 + 1) * E + cc[i]) = ab[i];
+                *reinterpret_cast<float4*>(colred + ((size_t)(wid - 1) * 3 + 2) * E + cc[i]) = ar[i];
+            }
+        }
+    }
+    __syncthreads();
+    if (wid == 0) {
+#pragma unroll
+        for (int i = 0; i < AF_MAXV; ++i) {
+            if (cok[i]) {
+                float4 g = ag[i], b = ab[i], r = ar[i];
+                for (int w = 0; w < AF_WAVES - 1; ++w) {
+                    const float4 g2 = *reinterpret_cast<const float4*>(colred + ((size_t)w * 3 + 0) * E + cc[i]);
+                    const float4 b2 = *reinterpret_cast<const float4*>(colred + ((size_t)w * 3 + 1) * E + cc[i]);
+                    const float4 r2 = *reinterpret_cast<const float4*>(colred + ((size_t)w * 3 + 2) * E + cc[i]);
+                    g.x += g2.x; g.y += g2.y; g.z += g2.z; g.w += g2.w;
+                    b.x += b2.x; b.y += b2.y; b.z += b2.z; b.w += b2.w;
+                    r.x += r2.x; r.y += r2.y; r.z += r2.z; r.w += r2.w;
+                }
+                *reinterpret_cast<float4*>(partial + ((size_t)blockIdx.x * 3 + 0) * E + cc[i]) = g;
+                *reinterpret_cast<float4*>(partial + ((size_t)blockIdx.x * 3 + 1) * E + cc[i]) = b;
+                *reinterpret_cast<float4*>(partial + ((size_t)blockIdx.x * 3 + 2) * E + cc[i]) = r;
+            }
+        }
+    }
+}
+
+int af_check(int T, int E, const char* who) {
+    if (T <= 0 || E % 256 || E > 256 * AF_MAXV || (E / AF_WAVES) % 16) { pevit_set_error("%s: unsupported shape T=%d E=%d (E a multiple of 256, <= 1024)", who, T, E); return -1; }
+    return 0;
+}
+template <typename K>
+int af_attr(K kern, int bytes, const char* who) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+        pevit_set_error("%s: cannot reserve %d bytes of LDS", who, bytes); return -1;
+    }
+    return 0;
+}
+
+}  // namespace
+
+bool pevit_adapter_fused_ok(int E) { return E % 256 == 0 && E <= 256 * AF_MAXV && (E / AF_WAVES) % 16 == 0; }
+
+// rows per workgroup.  (Measured and not kept: 25 valid rows per 32-row tile, which spreads T = 6400 over 256 workgroups instead of
+// 200 -- 31.1 / 31.8 us against 29.2 / 30.4: the kernels are bound by their chain of phases, not by bytes per CU.)
+static int af_rows_per_wg(int T) { (void)T; return AF_ROWS; }
+int pevit_adapter_blocks(int T) { return ceil_div(T, af_rows_per_wg(T)); }
+
+int pevit_launch_adapter_fwd(int act_kind, const float* hraw, const float* bpr, const float* x_mid, const float* gamma, const float* beta,
+                             const bf16* wd, const float* b_down, const bf16* wu, const float* b_up, bf16* z, float* mean_a,
+                             float* rstd_a, bf16* act, bf16* apre, float* x_out, int T, int E, hipStream_t s) {
+    if (af_check(T, E, "adapter_fwd")) return -1;
+    const AfLds L = af_layout(E);
+    const int lds = L.colred;
+    const int rb = af_rows_per_wg(T);
+    const dim3 grid(ceil_div(T, rb)), block(64 * AF_WAVES);
+    static bool attr[2] = {false, false};
+    if (act_kind == 0) {
+        if (!attr[0]) { if (af_attr(adapter_fwd_kernel<0>, 160 * 1024, "adapter_fwd")) return -1; attr[0] = true; }
+        hipLaunchKernelGGL(adapter_fwd_kernel<0>, grid, block, lds, s, hraw, bpr, x_mid, gamma, beta, wd, b_down, wu, b_up, z, mean_a, rstd_a, act, apre, x_out, T, E, rb);
+    } else {
+        if (!attr[1]) { if (af_attr(adapter_fwd_kernel<1>, 160 * 1024, "adapter_fwd")) return -1; attr[1] = true; }
+        hipLaunchKernelGGL(adapter_fwd_kernel<1>, grid, block, lds, s, hraw, bpr, x_mid, gamma, beta, wd, b_down, wu, b_up, z, mean_a, rstd_a, act, apre, x_out, T, E, rb);
+    }
+    LAUNCH_OK("adapter_fwd_kernel");
+    return 0;
+}
+
+int pevit_launch_adapter_bwd(int act_kind, const bf16* dyb, const float* dres, const bf16* wuT, const bf16* saved, const bf16* wdT,
+                             const float* hraw, const float* bpr, const float* mean_a, const float* rstd_a, const float* gamma,
+                             bf16* dpre, bf16* dh_bf16, float* partial, int T, int E, hipStream_t s) {
+    if (af_check(T, E, "adapter_bwd")) return -1;
+    const AfLds L = af_layout(E);
+    const int lds = L.colred;
+    const int rb = af_rows_per_wg(T);
+    const dim3 grid(ceil_div(T, rb)), block(64 * AF_WAVES);
+    static bool attr[2] = {false, false};
+    if (act_kind == 0) {
+        if (!attr[0]) { if (af_attr(adapter_bwd_kernel<0>, 160 * 1024, "adapter_bwd")) return -1; attr[0] = true; }
+        hipLaunchKernelGGL(adapter_bwd_kernel<0>, grid, block, lds, s, dyb, dres, wuT, saved, wdT, hraw, bpr, mean_a, rstd_a, gamma, dpre, dh_bf16, partial, T, E, rb);
+    } else {
+        if (!attr[1]) { if (af_attr(adapter_bwd_kernel<1>, 160 * 1024, "adapter_bwd")) return -1; attr[1] = true; }
+        hipLaunchKernelGGL(adapter_bwd_kernel<1>, grid, block, lds, s, dyb, dres, wuT, saved, wdT, hraw, bpr, mean_a, rstd_a, gamma, dpre, dh_bf16, partial, T, E, rb);
+    }
+    LAUNCH_OK("adapter_bwd_kernel");
+    return 0;
+}

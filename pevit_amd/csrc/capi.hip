@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <new>
 
 #include "../../include/pevit_hip.h"
@@ -111,6 +112,7 @@ struct pevit_ctx {
     int dx_stored = 1;        // dX GEMMs hand the LN-input gradient to LayerNorm backward in the activation storage type (bf16)
     int fused_bn = 0;         // post-MLP adapters: down -> activation -> up (and its backward) as one launch each (adapter.hip
                               // bottleneck_pair_kernel): 24.4 + 22.1 us against 22.9 + 19.5 us for the four GEMM launches -- opt-in
+    int adapter_fused = 1;    // post-MLP adapters: LayerNorm -> down -> activation -> up -> residual (and its backward) as one launch each
     int fp8_tail = 1;         // fp8 weights: t = xn P as the bf16 tail of the QKV launch (0: a separate small product, as before round 4)
     int fused_attn_delta = 1; // delta-add + attention forward as one launch where the geometry allows (attn_delta.hip)
     int lowrank_xcd = 1;      // lowrank_grad: XCD-contiguous workgroup order (+0.2 % per step)
@@ -174,7 +176,7 @@ void layout_workspace(pevit_ctx* c, int B, LayerSaved* sav, size_t* total, pevit
     o = cv.take((size_t)c->L * 4 * E * 32 * 4);          if (fill) fill->w_G = o;
     o = cv.take((size_t)c->L * 4096 * 4);                if (fill) fill->w_rule = o;
     if (post_mlp(c)) {
-        const int tch = pevit_tn_chunks((int)T), lnb = pevit_lna_blocks((int)T);
+        const int tch = pevit_tn_chunks((int)T), lnb = std::max(pevit_lna_blocks((int)T), pevit_adapter_blocks((int)T));
         const size_t tn_layer = (size_t)tch * E * 64 * 4, csx_layer = (size_t)tch * E * 4, csy_layer = (size_t)tch * 64 * 4,
                      lnp_layer = (size_t)lnb * 3 * E * 4;
         o = cv.take(T * 64 * es);            if (fill) fill->w_dpre = o;
@@ -680,6 +682,19 @@ int blocks_forward(pevit_ctx* c, hipStream_t s, int B, bool cls_only, int l_lo =
         } else {
             // x = x + [h + up(act(down(LN_a(h))))]         adapter_model.py:330-336 / compacter_model.py:497-503
             const float* lp = c->params + c->p_layer0 + c->p_layer_stride * l;
+            if (c->adapter_fused && !c->f32 && !c->fused_bn && pevit_adapter_fused_ok(E)) {
+                // two launches (adapter_fused.hip): c_proj writes its accumulators once (the bias joins in the adapter kernel), then
+                // LayerNorm -> down -> activation -> up -> residual for 32 rows per workgroup
+                GemmParams p = gp(at<bf16>(W, c->w_g), 4 * E, at<bf16>(A, b.wpr), 4 * E, E, T, E, 4 * E);
+                p.outf = at<float>(W, v.hf32); p.ldo = E;
+                CHECK(gemm(c, EPI_F32, p, s));
+                PROF(c, s, PEVIT_PROF_ADAPTER_FWD, T, (double)T * E * (4 + 4 + 4 + 2) + (double)T * 64 * 4,
+                     pevit_launch_adapter_fwd(c->d.method == PEVIT_ADAPTER ? 0 : 1, at<float>(W, v.hf32), at<float>(A, b.bpr), x_mid, lp + c->o_nw,
+                                              lp + c->o_nb, at<bf16>(A, b.wd), lp + c->o_db, at<bf16>(A, b.wu), lp + c->o_ub, at<bf16>(W, v.z),
+                                              at<float>(W, v.mean_a), at<float>(W, v.rstd_a), at<bf16>(W, v.act), at<bf16>(W, v.apre), x_out,
+                                              T, E, s));
+                continue;
+            }
             float* ytmp = at<float>(W, c->w_dxn);           // x_mid + h ; scratch that is free during the forward pass
             {
                 GemmParams p = gp(at<bf16>(W, c->w_g), 4 * E, at<bf16>(A, b.wpr), 4 * E, E, T, E, 4 * E);
@@ -759,7 +774,16 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0, bool cls_
             else
                 CHECK(pevit_launch_tn_gemm64(dyb, E, at<bf16>(W, v.act), 64, at<float>(W, c->w_tnU + (size_t)l * c->tn_layer),
                                              nullptr, nullptr, T, E, s));
-            if (c->fused_bn && !c->f32) {
+            const bool fused_ad = c->adapter_fused && !c->f32 && !c->fused_bn && pevit_adapter_fused_ok(E);
+            if (fused_ad) {
+                // d pre, d z and the LayerNorm backward with its affine-gradient column sums in one launch (adapter_fused.hip); the
+                // forward pass left the c_proj accumulators WITHOUT their bias in hf32
+                PROF(c, s, PEVIT_PROF_ADAPTER_BWD, T, (double)T * E * (2 + 4 + 4 + 2) + (double)T * 64 * 4,
+                     pevit_launch_adapter_bwd(c->d.method == PEVIT_ADAPTER ? 0 : 1, dyb, dxa, at<bf16>(A, b.wuT),
+                                              c->d.method == PEVIT_ADAPTER ? at<bf16>(W, v.act) : at<bf16>(W, v.apre), at<bf16>(A, b.wdT),
+                                              at<float>(W, v.hf32), at<float>(A, b.bpr), at<float>(W, v.mean_a), at<float>(W, v.rstd_a),
+                                              lp + c->o_nw, dpre, at<bf16>(W, c->w_dhb), at<float>(W, c->w_lnp + (size_t)l * c->lnp_layer), T, E, s));
+            } else if (c->fused_bn && !c->f32) {
                 // d pre = (dx_out W_up) * act'(saved) ; d z = d pre W_down, one launch
                 CHECK(pevit_launch_bottleneck_pair(c->d.method == PEVIT_ADAPTER ? 2 : 3, dyb, E, at<bf16>(A, b.wuT), nullptr,
                                                    c->d.method == PEVIT_ADAPTER ? at<bf16>(W, v.act) : at<bf16>(W, v.apre), dpre, nullptr,
@@ -785,9 +809,10 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0, bool cls_
                 CHECK(pevit_launch_tn_gemm64(at<bf16>(W, v.z), E, dpre, 64, at<float>(W, c->w_tnD + (size_t)l * c->tn_layer), nullptr,
                                              at<float>(W, c->w_csy + (size_t)l * c->csy_layer), T, E, s));
             // d h = dx_out + LN_a-backward(d z) ; partial sums for d gamma_a, d beta_a
-            CHECK(pevit_launch_ln_bwd_affine(dxn, at<float>(W, v.hf32), at<float>(W, v.mean_a), at<float>(W, v.rstd_a), lp + c->o_nw,
-                                             dxa, at<float>(W, c->w_dht), at<bf16>(W, c->w_dhb),
-                                             at<float>(W, c->w_lnp + (size_t)l * c->lnp_layer), T, E, s, c->f32));
+            if (!fused_ad)
+                CHECK(pevit_launch_ln_bwd_affine(dxn, at<float>(W, v.hf32), at<float>(W, v.mean_a), at<float>(W, v.rstd_a), lp + c->o_nw,
+                                                 dxa, nullptr, at<bf16>(W, c->w_dhb),
+                                                 at<float>(W, c->w_lnp + (size_t)l * c->lnp_layer), T, E, s, c->f32));
             mlp_dy = at<bf16>(W, c->w_dhb);
             if (l == 0 && !need_dx0) break;     // nothing trainable below the first block's adapter
         }
@@ -886,7 +911,8 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0, bool cls_
                                       c->ascale, c->d.lora_rank, nl, at<float>(W, c->w_G) + (size_t)l_lo * 4 * E * 32, c->grads, pl0,
                                       c->p_layer_stride, E, s));
     } else if (post_mlp(c)) {
-        const int tch = pevit_tn_chunks(T), lnb = pevit_lna_blocks(T);
+        const bool fused_lnp = c->adapter_fused && !c->f32 && !c->fused_bn && pevit_adapter_fused_ok(E);
+        const int tch = pevit_tn_chunks(T), lnb = fused_lnp ? pevit_adapter_blocks(T) : pevit_lna_blocks(T);
         const size_t ps = c->p_layer_stride, gl = (size_t)E * 64;
         float* g0 = c->grads + pl0;
         float* Gd = at<float>(W, c->w_Gd) + (size_t)l_lo * gl;
@@ -1432,6 +1458,7 @@ extern "C" int pevit_tune(pevit_ctx* c, const char* key, int value) {
     if (key && c && !strcmp(key, "profile_all")) { c->prof_all = value; return 0; }
     if (key && c && !strcmp(key, "fused_attn_delta")) { c->fused_attn_delta = value; return 0; }
     if (key && c && !strcmp(key, "fp8_tail")) { c->fp8_tail = value; return 0; }
+    if (key && c && !strcmp(key, "adapter_fused")) { c->adapter_fused = value; return 0; }
     if (key && c && !strcmp(key, "lowrank_xcd")) { c->lowrank_xcd = value; return 0; }
     pevit_set_error("tune: unknown key %s", key ? key : "(null)");
     return -1;

@@ -216,6 +216,17 @@ int pevit_launch_bottleneck_pair(int mode, const bf16* X, int ldx, const bf16* W
                                  hipStream_t s);
 int pevit_launch_ln_bwd_affine(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                                const float* dres, float* dx, bf16* dx_bf16, float* partial, int rows, int E, hipStream_t s, int f32 = 0);
+// ---- adapter_fused.hip: the post-MLP adapter as one launch per direction (bf16 storage, E a multiple of 256) ----
+bool pevit_adapter_fused_ok(int E);
+int pevit_adapter_blocks(int T);     // workgroups (= blocks of LayerNorm-affine partials) of the fused backward
+// act_kind 0 = ReLU (Adapter), 1 = gelu_new (Compacter).  hraw = c_proj accumulators WITHOUT their bias (f32), bpr = that bias.
+int pevit_launch_adapter_fwd(int act_kind, const float* hraw, const float* bpr, const float* x_mid, const float* gamma, const float* beta,
+                             const bf16* wd, const float* b_down, const bf16* wu, const float* b_up, bf16* z, float* mean_a,
+                             float* rstd_a, bf16* act, bf16* apre, float* x_out, int T, int E, hipStream_t s);
+// saved = act (ReLU) / apre (gelu_new); partial: [pevit_lna_blocks(T)][3][E] like ln_bwd_affine
+int pevit_launch_adapter_bwd(int act_kind, const bf16* dyb, const float* dres, const bf16* wuT, const bf16* saved, const bf16* wdT,
+                             const float* hraw, const float* bpr, const float* mean_a, const float* rstd_a, const float* gamma,
+                             bf16* dpre, bf16* dh_bf16, float* partial, int T, int E, hipStream_t s);
 int pevit_launch_colsum_reduce(const float* partial, int chunks, int n, float* out, int layers, size_t partial_layer,
                                size_t out_layer, hipStream_t s);
 int pevit_launch_colsum_reduce3(const float* partial, int chunks, int n, float* o0, float* o1, float* o2, int layers,

@@ -360,7 +360,7 @@ class HipEngine:
         return rc > 0
 
     PROF_KINDS = {0: "ln_fwd", 1: "ln_bwd", 2: "attn_fwd", 3: "attn_bwd", 4: "delta_add", 5: "lowrank_u", 6: "lowrank_grad",
-                  7: "im2col", 8: "lowrank_bwd", 9: "attn_fwd_delta"}     # include/pevit_hip.h: enum pevit_prof_kind
+                  7: "im2col", 8: "lowrank_bwd", 9: "attn_fwd_delta", 10: "adapter_fwd", 11: "adapter_bwd"}     # include/pevit_hip.h: enum pevit_prof_kind
 
     def profile_gemms(self, fn, max_launches=8192, all_kernels=False):
         """Run ``fn()`` with HIP events around every GEMM launch; returns (ms, flops, launches) of the GEMM family; the
