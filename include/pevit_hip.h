@@ -283,7 +283,7 @@ int pevit_op_im2col_u8(void* stream, const uint8_t* images, const float* mean3, 
  * MFMAs: 2), "gemm_stagger" (0 = legacy 8-wave kernel, 1 = staggered, 2 = also the 256x128 tile), "gemm_band",
  * "gemm_skinny" (0 = never use the few-row split-K kernel), "gemm_skinny_maxm" / "_mink" / "_slices", "gemm_sk_share" /
  * "gemm_sk_band" (with gemm_streamk = 2), "lowrank_xcd", "fused_bottleneck", "profile_all", "fused_attn_delta" (0 = delta_add + attn_fwd as two launches), "fp8_tail" (0 = t = xn P as a launch of its own with fp8 weights), "adapter_fused" (0 = the post-MLP adapter as separate
- * LayerNorm / GEMM launches) and
+ * LayerNorm / GEMM launches), "lowrank_combo" (0 = lowrank_u and lowrank_grad as two launches per layer) and
  * "dx_stored" (ctx only);
  * returns 0, or -1 for an unknown key */
 int pevit_tune(pevit_ctx* ctx, const char* key, int value);

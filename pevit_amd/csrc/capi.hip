@@ -74,7 +74,7 @@ struct pevit_ctx {
     // workspace
     LayerSaved* sav = nullptr;
     size_t w_skflag = 0, w_skslab = 0; int sk_slots = 0;   // stream-K workspace (gemm.hip), sk_slots = 0: disabled
-    size_t w_xfinal, w_xn2, w_g, w_dqkv, w_u32, w_dO, w_dh, w_dxn, w_dxa, w_dxb, w_dyb, w_partial, w_dbias;
+    size_t w_xfinal, w_xn2, w_g, w_dqkv, w_u32, w_u32b, w_dO, w_dh, w_dxn, w_dxa, w_dxb, w_dyb, w_partial, w_dbias;
     size_t w_G, w_rule, partial_layer, dbias_layer;
     size_t w_dpre, w_dht, w_dhb, w_tnU, w_tnD, w_csx, w_csy, w_lnp, w_Gd, w_Gu, tn_layer, csx_layer, csy_layer, lnp_layer;
     // post-MLP adapter parameter offsets inside one layer's block of the flat buffer (floats)
@@ -112,6 +112,7 @@ struct pevit_ctx {
     int dx_stored = 1;        // dX GEMMs hand the LN-input gradient to LayerNorm backward in the activation storage type (bf16)
     int fused_bn = 0;         // post-MLP adapters: down -> activation -> up (and its backward) as one launch each (adapter.hip
                               // bottleneck_pair_kernel): 24.4 + 22.1 us against 22.9 + 19.5 us for the four GEMM launches -- opt-in
+    int lowrank_combo = 1;    // attention-site adapters: u + dQ + d bias of a layer and the dP of the layer before it as one launch
     int adapter_fused = 1;    // post-MLP adapters: LayerNorm -> down -> activation -> up -> residual (and its backward) as one launch each
     int fp8_tail = 1;         // fp8 weights: t = xn P as the bf16 tail of the QKV launch (0: a separate small product, as before round 4)
     int fused_attn_delta = 1; // delta-add + attention forward as one launch where the geometry allows (attn_delta.hip)
@@ -163,6 +164,7 @@ void layout_workspace(pevit_ctx* c, int B, LayerSaved* sav, size_t* total, pevit
     }
     o = cv.take(T * (size_t)c->NQ * es);     if (fill) fill->w_dqkv = o;
     o = cv.take(T * 64 * 4);                if (fill) fill->w_u32 = o;
+    o = cv.take(T * 64 * 4);                if (fill) fill->w_u32b = o;      // second u buffer: dP of a layer is taken one launch later (lowrank_combo)
     o = cv.take(T * E * es);                 if (fill) fill->w_dO = o;
     o = cv.take(T * 4 * E * es);             if (fill) fill->w_dh = o;
     o = cv.take(T * E * 4);                 if (fill) fill->w_dxn = o;
@@ -752,6 +754,9 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0, bool cls_
     bf16* dqkv = at<bf16>(W, c->w_dqkv);
     const bool use_side = c->side_stream && site;
     bool side_pending = false;
+    const bool combo = c->lowrank_combo && site && !c->f32 && !use_side;
+    int prev_layer = -1, u_par = 0;
+    float* u_last = nullptr;
     if (use_side && !c->side) {
         HIP_OK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
         HIP_OK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -856,7 +861,18 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0, bool cls_
             PROF(c, s, PEVIT_PROF_ATTN_BWD, T, (double)T * E * 8 * 2 + (double)B * H * N * 4,     // q, k, v, out, dout in; dq, dk, dv out
                  pevit_launch_attn_bwd(qkv, qkv + plane, qkv + 2 * plane, at<bf16>(W, v.attn_out), E, at<bf16>(W, c->w_dO), E,
                                        at<float>(W, v.lse), dqkv, c->NQ, B, H, N, s));
-        if (site) {
+        if (site && combo) {
+            // u, dQ_q, dQ_v, d bias of this layer and the dP of the layer before it in ONE launch (lowrank.hip lowrank_combo_kernel)
+            float* u_cur = at<float>(W, u_par ? c->w_u32b : c->w_u32);
+            const LayerSaved* pv = prev_layer >= 0 ? &c->sav[prev_layer] : nullptr;
+            PROF(c, s, PEVIT_PROF_LOWRANK_BWD, T, (double)T * E * 3 * 2 + (double)T * 64 * 14 + (double)chunks * 4 * E * 32 * 4,
+                 pevit_launch_lowrank_combo(1, pv ? 1 : 0, dqkv, c->NQ, at<bf16>(A, b.qT), u_cur, dqkv + 3 * E, at<float>(W, v.t),
+                                            at<float>(W, c->w_partial + (size_t)l * c->partial_layer),
+                                            at<float>(W, c->w_dbias + (size_t)l * c->dbias_layer),
+                                            pv ? at<bf16>(W, pv->xn1) : nullptr, E, u_last,
+                                            pv ? at<float>(W, c->w_partial + (size_t)prev_layer * c->partial_layer) : nullptr, B, H, N, E, s));
+            u_last = u_cur; prev_layer = l; u_par ^= 1;
+        } else if (site) {
             if (c->f32)
                 CHECK(pevit_launch_lowrank_u_f32((const float*)dqkv, c->NQ, at<float>(A, b.q32), at<float>(W, c->w_u32),
                                                  (float*)eadv(c, dqkv, 3 * (size_t)E), B, H, N, E, s));
@@ -894,6 +910,10 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0, bool cls_
         }
     }
     if (side_pending) HIP_OK(hipStreamWaitEvent(s, c->ev_join, 0));
+    if (combo && prev_layer >= 0)       // the dP of the last layer walked
+        PROF(c, s, PEVIT_PROF_LOWRANK_BWD, T, (double)T * E * 2 + (double)T * 64 * 4,
+             pevit_launch_lowrank_combo(0, 1, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, at<bf16>(W, c->sav[prev_layer].xn1), E,
+                                        u_last, at<float>(W, c->w_partial + (size_t)prev_layer * c->partial_layer), B, H, N, E, s));
     // adapter gradients of layers [l_lo, l_hi): reduce the partials and chain onto the reference's tensors
     const int nl = l_hi - l_lo;
     const size_t pl0 = c->p_layer0 + c->p_layer_stride * l_lo;          // first float of layer l_lo's parameters
@@ -1459,6 +1479,7 @@ extern "C" int pevit_tune(pevit_ctx* c, const char* key, int value) {
     if (key && c && !strcmp(key, "fused_attn_delta")) { c->fused_attn_delta = value; return 0; }
     if (key && c && !strcmp(key, "fp8_tail")) { c->fp8_tail = value; return 0; }
     if (key && c && !strcmp(key, "adapter_fused")) { c->adapter_fused = value; return 0; }
+    if (key && c && !strcmp(key, "lowrank_combo")) { c->lowrank_combo = value; return 0; }
     if (key && c && !strcmp(key, "lowrank_xcd")) { c->lowrank_xcd = value; return 0; }
     pevit_set_error("tune: unknown key %s", key ? key : "(null)");
     return -1;

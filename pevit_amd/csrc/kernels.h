@@ -139,6 +139,10 @@ int pevit_launch_lowrank_grad(const bf16* xn, int ldx, const float* u32, const b
                               const float* t, float* partial, float* dbias_partial, int chunks,
                               int B, int H, int N, int E, hipStream_t s, int xcd_order = 1);   // xcd_order: XCD-contiguous workgroup order (measurement knob)
 int pevit_lowrank_chunks(int T);
+// u + dQ / d bias of this layer and the deferred dP of the previously processed layer in ONE launch (lowrank_combo_kernel)
+int pevit_launch_lowrank_combo(int this_layer, int prev, const bf16* dqkv, int ld, const bf16* qT, float* u32, bf16* ucols, const float* t,
+                               float* partial, float* dbias_partial, const bf16* xn_prev, int ldx, const float* u32_prev,
+                               float* partial_prev, int B, int H, int N, int E, hipStream_t s);
 // reduce the per-chunk partials of all layers and apply the chain rule onto the reference's
 // parameter tensors (flat gradient buffer, accumulating)
 int pevit_launch_chain_kadapt(const float* partial, size_t partial_layer, const float* dbias_partial, size_t dbias_layer,

@@ -38,6 +38,9 @@ __device__ __forceinline__ AdapterPanels layer_panels(AdapterPanels pan, LayerSt
     return pan;
 }
 
+// Two index orders in one launch (blockIdx.z): z = 0 walks (j, e) with e fastest and writes the panels whose rows run along e
+// (P^T rows of Wqkv_aug, Q^T); z = 1 walks (e, j) with j fastest and writes the panels whose rows run along j (the 64 adapter columns
+// of Wqkv^T_aug, Q as f32 and bf16).  Written from one order, half of the stores were 2-byte writes 4.7 KB apart (15 us per step).
 template <typename ST>
 __global__ void prep_kadapt_kernel(const float* __restrict__ rule1_l, const float* __restrict__ rule1_r,
                                    const float* __restrict__ rule2_l, const float* __restrict__ rule2_r,
@@ -47,23 +50,27 @@ __global__ void prep_kadapt_kernel(const float* __restrict__ rule1_l, const floa
     if (idx >= E * 32) return;
     pan = layer_panels(pan, st, blockIdx.y);
     q_left += (size_t)blockIdx.y * st.param_floats; q_right += (size_t)blockIdx.y * st.param_floats;
-    const int j = idx / E, e = idx - j * E;     // e fastest: coalesced row writes
+    const bool by_e = blockIdx.z == 0;
+    const int j = by_e ? idx / E : idx & 31, e = by_e ? idx - j * E : idx >> 5;
     const int F = E / 32, a = e / F, kk = e - a * F;
     const float l = q_left[j * F + kk], r = q_right[j * F + kk];
     const float pq = rule1_l[j * 32 + a] * l, pv = rule2_l[j * 32 + a] * l;
     const float qq = rule1_r[j * 32 + a] * r, qv = rule2_r[j * 32 + a] * r;
-    st_store<ST>(pan.w_aug_rows, (size_t)j * pan.ldw + e, pq);
-    st_store<ST>(pan.w_aug_rows, (size_t)(32 + j) * pan.ldw + e, pv);
-    st_store<ST>(pan.wT_aug_cols, (size_t)e * pan.ldwT + j, ascale * pq);
-    st_store<ST>(pan.wT_aug_cols, (size_t)e * pan.ldwT + 32 + j, ascale * pv);
-    pan.q32[(size_t)e * 64 + j] = qq;
-    pan.q32[(size_t)e * 64 + 32 + j] = qv;
-    if constexpr (sizeof(ST) == 2) {           // the forward delta's operand: Q rounded to bf16 like P (rows of Wqkv_aug) and Q^T
-        pan.q16[(size_t)e * 64 + j] = f2bf(qq);
-        pan.q16[(size_t)e * 64 + 32 + j] = f2bf(qv);
+    if (by_e) {
+        st_store<ST>(pan.w_aug_rows, (size_t)j * pan.ldw + e, pq);
+        st_store<ST>(pan.w_aug_rows, (size_t)(32 + j) * pan.ldw + e, pv);
+        st_store<ST>(pan.qT, (size_t)j * E + e, qq);
+        st_store<ST>(pan.qT, (size_t)(32 + j) * E + e, qv);
+    } else {
+        st_store<ST>(pan.wT_aug_cols, (size_t)e * pan.ldwT + j, ascale * pq);
+        st_store<ST>(pan.wT_aug_cols, (size_t)e * pan.ldwT + 32 + j, ascale * pv);
+        pan.q32[(size_t)e * 64 + j] = qq;
+        pan.q32[(size_t)e * 64 + 32 + j] = qv;
+        if constexpr (sizeof(ST) == 2) {       // the forward delta's operand: Q rounded to bf16 like P (rows of Wqkv_aug) and Q^T
+            pan.q16[(size_t)e * 64 + j] = f2bf(qq);
+            pan.q16[(size_t)e * 64 + 32 + j] = f2bf(qv);
+        }
     }
-    st_store<ST>(pan.qT, (size_t)j * E + e, qq);
-    st_store<ST>(pan.qT, (size_t)(32 + j) * E + e, qv);
 }
 
 template <typename ST>
@@ -249,38 +256,41 @@ __device__ __forceinline__ const bf16* ddelta_slab(const bf16* dqkv, int ld, int
 #ifndef LU_WAVES
 #define LU_WAVES 8
 #endif
-__global__ __launch_bounds__(64 * LU_WAVES) void lowrank_u_kernel(const bf16* __restrict__ dqkv, int ld,
-                                                        const bf16* __restrict__ qT, float* __restrict__ u32,
-                                                        bf16* __restrict__ ucols, int B, int H, int N, int E) {
-    __shared__ float red[LU_WAVES][LU_RG][4][64][4];
+// body: W waves split E (contraction), RG groups of 16 reference rows; red = W * RG * 4 * 64 * 4 floats of LDS
+template <int W, int RG>
+__device__ __forceinline__ void lowrank_u_body(float* red_raw, int blk, const bf16* __restrict__ dqkv, int ld,
+                                               const bf16* __restrict__ qT, float* __restrict__ u32,
+                                               bf16* __restrict__ ucols, int B, int H, int N, int E) {
+    float (*red)[RG][4][64][4] = reinterpret_cast<float (*)[RG][4][64][4]>(red_raw);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, g = lane >> 4, c16 = lane & 15;
     const int T = B * N;
-    const int rr0 = blockIdx.x * 16 * LU_RG;
-    int rr[LU_RG];
+    const int rr0 = blk * 16 * RG;
+    int rr[RG];
 #pragma unroll
-    for (int k = 0; k < LU_RG; ++k) { rr[k] = rr0 + 16 * k + c16; rr[k] = rr[k] < T ? rr[k] : T - 1; }
-    f32x4 acc[LU_RG][4];
+    for (int k = 0; k < RG; ++k) { rr[k] = rr0 + 16 * k + c16; rr[k] = rr[k] < T ? rr[k] : T - 1; }
+    f32x4 acc[RG][4];
 #pragma unroll
-    for (int k = 0; k < LU_RG; ++k)
+    for (int k = 0; k < RG; ++k)
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[k][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     constexpr int LU_UNROLL = 3;
     const int steps = E / 32;
-    for (int sb = wid; sb < steps; sb += LU_WAVES * LU_UNROLL) {
-        bf16x8 aq[LU_UNROLL][LU_RG], av[LU_UNROLL][LU_RG];
+    if (wid < W) {
+    for (int sb = wid; sb < steps; sb += W * LU_UNROLL) {
+        bf16x8 aq[LU_UNROLL][RG], av[LU_UNROLL][RG];
 #pragma unroll
         for (int i = 0; i < LU_UNROLL; ++i) {
-            const int s = min(sb + LU_WAVES * i, steps - 1);
+            const int s = min(sb + W * i, steps - 1);
             const int e0 = (s >> 1) * 64, doff = (s & 1) * 32 + 8 * g;
 #pragma unroll
-            for (int k = 0; k < LU_RG; ++k) {
+            for (int k = 0; k < RG; ++k) {
                 aq[i][k] = load_bf16x8(ddelta_slab(dqkv, ld, 0, rr[k], e0, E, H, N) + doff);
                 av[i][k] = load_bf16x8(ddelta_slab(dqkv, ld, 2 * E, rr[k], e0, E, H, N) + doff);
             }
         }
 #pragma unroll
         for (int i = 0; i < LU_UNROLL; ++i) {
-            const int s = sb + LU_WAVES * i;
+            const int s = sb + W * i;
             if (s < steps) {
                 const int ke = 32 * s + 8 * g;
 #pragma unroll
@@ -288,7 +298,7 @@ __global__ __launch_bounds__(64 * LU_WAVES) void lowrank_u_kernel(const bf16* __
                     const bf16x8 bq = load_bf16x8(qT + (size_t)(16 * nt + c16) * E + ke);
                     const bf16x8 bv = load_bf16x8(qT + (size_t)(32 + 16 * nt + c16) * E + ke);
 #pragma unroll
-                    for (int k = 0; k < LU_RG; ++k) {
+                    for (int k = 0; k < RG; ++k) {
                         acc[k][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[i][k], bq, acc[k][nt], 0, 0, 0);
                         acc[k][2 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[i][k], bv, acc[k][2 + nt], 0, 0, 0);
                     }
@@ -297,20 +307,22 @@ __global__ __launch_bounds__(64 * LU_WAVES) void lowrank_u_kernel(const bf16* __
         }
     }
 #pragma unroll
-    for (int k = 0; k < LU_RG; ++k)
+    for (int k = 0; k < RG; ++k)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) red[wid][k][i][lane][r] = acc[k][i][r];
+    }
     __syncthreads();
-    // wave w sums (row group k, tile i) pairs w, w + LU_WAVES, ... in a fixed order
-    for (int pi = wid; pi < LU_RG * 4; pi += LU_WAVES) {
+    if (wid >= W) return;
+    // wave w sums (row group k, tile i) pairs w, w + W, ... in a fixed order
+    for (int pi = wid; pi < RG * 4; pi += W) {
         const int k = pi >> 2, i = pi & 3;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float v = 0.f;
 #pragma unroll
-            for (int w = 0; w < LU_WAVES; ++w) v += red[w][k][i][lane][r];
+            for (int w = 0; w < W; ++w) v += red[w][k][i][lane][r];
             const int rro = rr0 + 16 * k + 4 * g + r;
             if (rro < T) {
                 const int row = row_of_ref(rro, B, N);
@@ -320,6 +332,13 @@ __global__ __launch_bounds__(64 * LU_WAVES) void lowrank_u_kernel(const bf16* __
             }
         }
     }
+}
+
+__global__ __launch_bounds__(64 * LU_WAVES) void lowrank_u_kernel(const bf16* __restrict__ dqkv, int ld,
+                                                        const bf16* __restrict__ qT, float* __restrict__ u32,
+                                                        bf16* __restrict__ ucols, int B, int H, int N, int E) {
+    __shared__ float red[LU_WAVES * LU_RG * 4 * 64 * 4];
+    lowrank_u_body<LU_WAVES, LU_RG>(red, blockIdx.x, dqkv, ld, qT, u32, ucols, B, H, N, E);
 }
 
 // ---------------------------------------------------------------------------------
@@ -354,23 +373,24 @@ __device__ __forceinline__ bf16x8 lg_trfrag(const bf16* tile, int ks, int col0, 
     return o;
 }
 
-__global__ __launch_bounds__(256, 2) void lowrank_grad_kernel(const bf16* __restrict__ xn, int ldx,
-                                                              const float* __restrict__ u32,
-                                                              const bf16* __restrict__ dqkv, int ld,
-                                                              const float* __restrict__ t, float* __restrict__ partial,
-                                                              float* __restrict__ dbias_partial, int B, int H, int N,
-                                                              int E, int remap) {
-    __shared__ __attribute__((aligned(16))) bf16 Xs[LG_ROWS * LG_LD];
-    __shared__ __attribute__((aligned(16))) bf16 Ys[LG_ROWS * LG_LD];
-    __shared__ float cs[4][64];
+// LDS of the body: Xs, Ys (LG_ROWS x LG_LD bf16 each) + 4 x 64 floats
+constexpr int LG_LDS_BYTES = 2 * LG_ROWS * LG_LD * 2 + 4 * 64 * 4;
+// One (chunk, kind, slab group) workgroup of 256 threads.  kind_lo / nkinds select which kinds a launch (or a block range of the
+// combined launch) covers: {0, 3} everything, {1, 2} the two dQ products, {0, 1} dP alone.
+__device__ __forceinline__ void lowrank_grad_body(char* smem, int bid, int kind_lo, int nkinds, const bf16* __restrict__ xn, int ldx,
+                                                  const float* __restrict__ u32, const bf16* __restrict__ dqkv, int ld,
+                                                  const float* __restrict__ t, float* __restrict__ partial,
+                                                  float* __restrict__ dbias_partial, int B, int H, int N, int E) {
+    bf16* Xs = reinterpret_cast<bf16*>(smem);
+    bf16* Ys = Xs + LG_ROWS * LG_LD;
+    float (*cs)[64] = reinterpret_cast<float (*)[64]>(smem + 2 * LG_ROWS * LG_LD * 2);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, c16 = lane & 15;
     const int groups = E / 64 / LG_ES;
-    const int per_chunk = groups * 3;
-    // the `groups` workgroups of a (chunk, kind) read the same Y rows (64 KB of u / 32 KB of t): consecutive LOGICAL ids on one
-    // XCD (workgroup b runs on XCD b % 8), so that its L2 fetches them once instead of up to six L2s once each
-    const int bid = remap ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int per_chunk = groups * nkinds;
+    // the `groups` workgroups of a (chunk, kind) read the same Y rows (64 KB of u / 32 KB of t): the caller hands out consecutive
+    // LOGICAL ids on one XCD (workgroup b runs on XCD b % 8), so that its L2 fetches them once instead of up to six L2s once each
     const int chunk = bid / per_chunk, rem = bid - chunk * per_chunk;
-    const int kind = rem / groups, eg = rem - kind * groups;
+    const int kind = kind_lo + rem / groups, eg = rem % groups;
     const int T = B * N;
     const int r0 = chunk * LG_ROWS;
     const int col0 = (kind == 1) ? 0 : 2 * E;
@@ -488,6 +508,50 @@ __global__ __launch_bounds__(256, 2) void lowrank_grad_kernel(const bf16* __rest
     }
 }
 
+__global__ __launch_bounds__(256, 2) void lowrank_grad_kernel(const bf16* __restrict__ xn, int ldx,
+                                                              const float* __restrict__ u32,
+                                                              const bf16* __restrict__ dqkv, int ld,
+                                                              const float* __restrict__ t, float* __restrict__ partial,
+                                                              float* __restrict__ dbias_partial, int B, int H, int N,
+                                                              int E, int remap) {
+    __shared__ __attribute__((aligned(16))) char smem[LG_LDS_BYTES];
+    const int bid = remap ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    lowrank_grad_body(smem, bid, 0, 3, xn, ldx, u32, dqkv, ld, t, partial, dbias_partial, B, H, N, E);
+}
+
+// ONE launch per layer for the whole low-rank backward (round 4): block ranges, each padded to a multiple of 8 so that a range's
+// logical ids keep their XCD (block b runs on XCD b % 8):
+//   [0, nu)            u = dDelta Q of THIS layer (four waves, 16 reference rows per block; the other threads leave)
+//   [nu, nu + n12)     dQ_q, dQ_v (+ bias column sums) of THIS layer
+//   [.., + n0)         dP = xn^T u of the layer processed BEFORE this one (its u is complete: it was written by the previous launch)
+// u and the dQ products both read dq / dv while they are hot; dP needs the finished u, hence its one-launch delay (the last layer's
+// dP gets a launch of its own).  Replaces lowrank_u + lowrank_grad (24.4 us, two dispatches) per layer.
+constexpr int LC_UW = 4;             // waves of a u block
+__global__ __launch_bounds__(256, 2) void lowrank_combo_kernel(const bf16* __restrict__ dqkv, int ld, const bf16* __restrict__ qT,
+                                                               float* __restrict__ u32, bf16* __restrict__ ucols,
+                                                               const float* __restrict__ t, float* __restrict__ partial,
+                                                               float* __restrict__ dbias_partial,
+                                                               const bf16* __restrict__ xn_prev, int ldx, const float* __restrict__ u32_prev,
+                                                               float* __restrict__ partial_prev, int nu, int nu_pad, int n12, int n12_pad,
+                                                               int n0, int B, int H, int N, int E) {
+    __shared__ __attribute__((aligned(16))) char smem[LG_LDS_BYTES];
+    static_assert(LC_UW * 1 * 4 * 64 * 4 * 4 <= LG_LDS_BYTES, "the u reduction fits the gradient body's LDS");
+    int b = blockIdx.x;
+    if (b < nu_pad) {
+        if (b < nu) lowrank_u_body<LC_UW, 1>(reinterpret_cast<float*>(smem), b, dqkv, ld, qT, u32, ucols, B, H, N, E);
+        return;
+    }
+    b -= nu_pad;
+    // (one call site for both gradient ranges: three inlined copies of the body crash hipcc's inliner)
+    const bool this_layer = b < n12_pad;
+    const int local = this_layer ? b : b - n12_pad;
+    const int n0_pad = (n0 + 7) & ~7;
+    const int bid = xcd_remap(local, this_layer ? n12_pad : n0_pad);
+    if (bid >= (this_layer ? n12 : n0)) return;
+    lowrank_grad_body(smem, bid, this_layer ? 1 : 0, this_layer ? 2 : 1, xn_prev, ldx, u32_prev, dqkv, ld, t,
+                      this_layer ? partial : partial_prev, dbias_partial, B, H, N, E);
+}
+
 // sum the per-chunk partials of every layer (blockIdx.y): G[l][4][E][32], and the bias gradient
 __global__ void lowrank_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ dbias_partial,
                                       int chunks, float* __restrict__ G, float* g_b, int E, size_t partial_layer,
@@ -601,9 +665,9 @@ int pevit_launch_prep_kadapt(const float* rule1_l, const float* rule1_r, const f
                              const float* q_left, const float* q_right, AdapterPanels pan, int E, float ascale,
                              int layers, LayerStrides st, hipStream_t s, int f32) {
     if (E % 32) { pevit_set_error("prep_kadapt: width %d not divisible by phm_dim 32", E); return -1; }
-    if (f32) hipLaunchKernelGGL(prep_kadapt_kernel<float>, dim3(ceil_div(E * 32, 256), layers), dim3(256), 0, s, rule1_l, rule1_r,
+    if (f32) hipLaunchKernelGGL(prep_kadapt_kernel<float>, dim3(ceil_div(E * 32, 256), layers, 2), dim3(256), 0, s, rule1_l, rule1_r,
                                 rule2_l, rule2_r, q_left, q_right, pan, E, ascale, st);
-    else hipLaunchKernelGGL(prep_kadapt_kernel<bf16>, dim3(ceil_div(E * 32, 256), layers), dim3(256), 0, s, rule1_l, rule1_r,
+    else hipLaunchKernelGGL(prep_kadapt_kernel<bf16>, dim3(ceil_div(E * 32, 256), layers, 2), dim3(256), 0, s, rule1_l, rule1_r,
                             rule2_l, rule2_r, q_left, q_right, pan, E, ascale, st);
     LAUNCH_OK("prep_kadapt_kernel");
     return 0;
@@ -643,6 +707,22 @@ int pevit_launch_lowrank_u(const bf16* dqkv, int ld, const bf16* qT, float* u32,
 }
 
 int pevit_lowrank_chunks(int T) { return ceil_div(T, LG_ROWS); }
+
+// see lowrank_combo_kernel.  this_layer = 0: only the deferred dP of the previous layer (end of the layer loop); prev = 0: no deferred work.
+int pevit_launch_lowrank_combo(int this_layer, int prev, const bf16* dqkv, int ld, const bf16* qT, float* u32, bf16* ucols, const float* t,
+                               float* partial, float* dbias_partial, const bf16* xn_prev, int ldx, const float* u32_prev,
+                               float* partial_prev, int B, int H, int N, int E, hipStream_t s) {
+    const int T = B * N, chunks = ceil_div(T, LG_ROWS);
+    if (E % (64 * LG_ES)) { pevit_set_error("lowrank_combo: width %d must be a multiple of %d", E, 64 * LG_ES); return -1; }
+    const int groups = E / 64 / LG_ES;
+    const int nu = this_layer ? ceil_div(T, 16) : 0, n12 = this_layer ? chunks * groups * 2 : 0, n0 = prev ? chunks * groups : 0;
+    const int nu_pad = (nu + 7) & ~7, n12_pad = (n12 + 7) & ~7, n0_pad = (n0 + 7) & ~7;
+    if (nu_pad + n12_pad + n0_pad == 0) return 0;
+    hipLaunchKernelGGL(lowrank_combo_kernel, dim3(nu_pad + n12_pad + n0_pad), dim3(256), 0, s, dqkv, ld, qT, u32, ucols, t, partial,
+                       dbias_partial, xn_prev, ldx, u32_prev, partial_prev, nu, nu_pad, n12, n12_pad, n0, B, H, N, E);
+    LAUNCH_OK("lowrank_combo_kernel");
+    return 0;
+}
 
 int pevit_launch_lowrank_grad(const bf16* xn, int ldx, const float* u32, const bf16* dqkv, int ld, const float* t,
                               float* partial, float* dbias_partial, int chunks, int B, int H, int N, int E,

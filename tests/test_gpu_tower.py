@@ -590,3 +590,32 @@ def test_fused_post_mlp_adapter_equals_the_separate_launches(method, arch_name, 
     for k in g0:
         if float(g0[k].norm()) > 0:
             assert rel_err(g1[k], g0[k]) < 2e-2, (k, rel_err(g1[k], g0[k]))
+
+
+@pytest.mark.parametrize("method,arch_name,B", [("kadaptation", "ViT-B/32-2L", 24), ("lora", "tiny-256", 7), ("kadaptation", "tiny-n197", 3)])
+def test_combined_lowrank_backward_equals_the_two_launches(method, arch_name, B):
+    """lowrank_combo_kernel (u + dQ + d bias of a layer and the dP of the layer walked before it in one launch, the last layer's dP
+    in a launch of its own) against lowrank_u + lowrank_grad per layer (`lowrank_combo` = 0): same products on the same bf16
+    operands, u summed over E in a different split -> every gradient agrees to f32 summation order; logits are untouched."""
+    from pevit_amd.engine import HipEngine, adapter_param_spec
+    from pevit_amd.synth import ARCHS, randomize_adapters, synth_batch, synth_state_dict
+    arch, C = ARCHS[arch_name], 10
+    sd = {k: v for k, v in synth_state_dict(arch, seed=2, text_tower=False).items() if k.startswith("visual.")}
+    ad = [(n, torch.zeros(s)) for n, s, _ in adapter_param_spec(method, arch.width, arch.layers, 8)]
+    randomize_adapters(ad, seed=3); sd.update(dict(ad))
+    images, labels = synth_batch(B, arch.resolution, C, seed_img=3, seed_lbl=4)
+    res = []
+    for combo in (1, 0):
+        eng = HipEngine(arch, method, C, B, lora_rank=8)
+        eng.load_state_dict(sd)
+        assert eng.tune("lowrank_combo", combo) == 0
+        logits, loss = eng.forward_backward(images.cuda(), labels.cuda())
+        torch.cuda.synchronize()
+        res.append((logits.cpu().clone(), {k: v.cpu().clone() for k, v in eng.grad_views().items()}))
+    (l1, g1), (l0, g0) = res
+    assert torch.equal(l1, l0)
+    for k in g0:
+        if float(g0[k].norm()) > 0:
+            assert rel_err(g1[k], g0[k]) < 2e-3, (k, rel_err(g1[k], g0[k]))
+        else:
+            assert float(g1[k].abs().max()) == 0.0, k
