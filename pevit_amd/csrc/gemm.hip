@@ -1333,7 +1333,7 @@ __global__ __launch_bounds__(2 * WGM * WGN * 64, 1) void gemm_ksplit_kernel(Gemm
 // gemm8_kernel (round 3).  gemm_ksplit_kernel gives each group whole k-tiles and lets hipcc schedule the k-tile: a wave requests
 // its 9 pieces (~100 cycles of issue each), then reads and multiplies fragment by fragment behind lgkmcnt(0) waits, then waits
 // for its requests with vmcnt(0): an iteration is ~3,900 cycles for 1,280 cycles of MFMAs per SIMD (matrix pipe 19-21 % busy by
-// the counters, profiles/r03_mfma_utilisation.md), and at most one k-tile per group is in flight.  Here
+// the counters, profiles/archive/r03_mfma_utilisation.md), and at most one k-tile per group is in flight.  Here
 //   * the groups split every k-tile: group g multiplies its k-steps 2g, 2g+1 (both groups read the same LDS stage);
 //   * a wave's k-tile is ONE phase: LOAD (all 2*(WM+1) fragments, its share of the k-tile S-1 ahead by LDS-DMA, lgkmcnt(0))
 //     -> barrier -> MFMA (2*WM back to back at raised priority) -> barrier, group 1 one barrier behind group 0, so that on
