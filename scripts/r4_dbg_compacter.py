@@ -1,3 +1,5 @@
+"""ViT-B/16 + Compacter at bs 8 against the f32 oracle with the fused and with the separate post-MLP kernels: the worst gradient
+tensors relative to the bf16-operand noise (how the LayerNorm-affine gradients straddle the 2.5x gate, tests/test_gpu_tower.py)."""
 import sys, os
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 import torch
