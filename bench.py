@@ -448,9 +448,17 @@ def main():
         if world == 1 and not args.no_harness and headline:
             del eng, images, labels
             torch.cuda.empty_cache()
-            out["harness_images_per_sec"] = harness_throughput(dev)
+            try:
+                out["harness_images_per_sec"] = harness_throughput(dev)
+            except Exception as e:           # a side measurement must never cost the headline line
+                out["harness_images_per_sec"] = {"error": f"{type(e).__name__}: {e}"}
+                print(f"[bench] harness measurement failed: {e}", file=sys.stderr, flush=True)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            try:
+                out["cpu_baseline"] = cpu_baseline()
+            except Exception as e:
+                out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}", "kind": "port"}
+                print(f"[bench] CPU baseline failed: {e}", file=sys.stderr, flush=True)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
