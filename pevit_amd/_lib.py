@@ -123,6 +123,13 @@ def load():
         raise PevitError(
             f"{LIB_PATH} not found: the gfx950 HIP library has not been built. "
             "Run `python -c 'import __graft_entry__ as g; g.build()'`. There is no CPU fallback.")
+    # torch first: its wheel carries its own libamdhip64; loaded AFTER this library (which would then pull the system runtime in)
+    # the process holds two HIP runtimes, and the second one finds "no ROCm-capable device" (seen with `python __graft_entry__.py
+    # smoke`, where build() loads the library before smoke() imports torch)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol

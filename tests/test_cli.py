@@ -36,8 +36,18 @@ def test_loaders_from_tensor_archive(tmp_path):
     assert len(train.dataset) + len(val.dataset) == 20 and len(val.dataset) == 4 and len(test.dataset) == 6
     assert train.batch_size == 64 and train.dataset.dataset is val.dataset.dataset
     x, y = next(iter(val))
-    assert x.dtype == torch.float32 and y.dtype == torch.int64 and x.shape == (4, 3, 8, 8)
-    assert float(x.max()) < 3.0 and float(x.min()) > -2.5          # uint8 -> CLIP mean/std normalisation
+    # uint8 archives stay uint8 (round 4): the Classifier hands INPUT.MEAN / STD to the engine, which applies ToTensor + Normalize in
+    # its patch gather; DATASET.NORMALIZE_ON_HOST restores the float tensors of the reference's loaders
+    assert x.dtype == torch.uint8 and y.dtype == torch.int64 and x.shape == (4, 3, 8, 8)
+    assert next(iter(test))[0].dtype == torch.float32
+    cfg.DATASET.NORMALIZE_ON_HOST = True
+    _, val_f, _ = construct_dataloader(cfg)
+    xf, yf = next(iter(val_f))
+    assert xf.dtype == torch.float32 and torch.equal(yf, y)
+    assert float(xf.max()) < 3.0 and float(xf.min()) > -2.5          # uint8 -> CLIP mean/std normalisation
+    mean, std = torch.tensor(cfg.INPUT.MEAN).view(1, 3, 1, 1), torch.tensor(cfg.INPUT.STD).view(1, 3, 1, 1)
+    assert torch.equal(xf, (x.float() / 255.0 - mean) / std)
+    cfg.DATASET.NORMALIZE_ON_HOST = False
     merged = _harness.merge_trainval_loader(train, val)
     assert len(merged.dataset) == 20
     cfg.DATASET.DATASET = "missing"
