@@ -521,12 +521,15 @@ __global__ __launch_bounds__(256, 2) void lowrank_grad_kernel(const bf16* __rest
 
 // ONE launch per layer for the whole low-rank backward (round 4): block ranges, each padded to a multiple of 8 so that a range's
 // logical ids keep their XCD (block b runs on XCD b % 8):
-//   [0, nu)            u = dDelta Q of THIS layer (four waves, 16 reference rows per block; the other threads leave)
+//   [0, nu)            u = dDelta Q of THIS layer (four waves, 16 * LC_URG reference rows per block)
 //   [nu, nu + n12)     dQ_q, dQ_v (+ bias column sums) of THIS layer
 //   [.., + n0)         dP = xn^T u of the layer processed BEFORE this one (its u is complete: it was written by the previous launch)
 // u and the dQ products both read dq / dv while they are hot; dP needs the finished u, hence its one-launch delay (the last layer's
 // dP gets a launch of its own).  Replaces lowrank_u + lowrank_grad (24.4 us, two dispatches) per layer.
-constexpr int LC_UW = 4;             // waves of a u block
+#ifndef LC_URG_V
+#define LC_URG_V 2
+#endif
+constexpr int LC_UW = 4, LC_URG = LC_URG_V;      // waves and 16-row groups of a u block
 __global__ __launch_bounds__(256, 2) void lowrank_combo_kernel(const bf16* __restrict__ dqkv, int ld, const bf16* __restrict__ qT,
                                                                float* __restrict__ u32, bf16* __restrict__ ucols,
                                                                const float* __restrict__ t, float* __restrict__ partial,
@@ -535,10 +538,10 @@ __global__ __launch_bounds__(256, 2) void lowrank_combo_kernel(const bf16* __res
                                                                float* __restrict__ partial_prev, int nu, int nu_pad, int n12, int n12_pad,
                                                                int n0, int B, int H, int N, int E) {
     __shared__ __attribute__((aligned(16))) char smem[LG_LDS_BYTES];
-    static_assert(LC_UW * 1 * 4 * 64 * 4 * 4 <= LG_LDS_BYTES, "the u reduction fits the gradient body's LDS");
+    static_assert(LC_UW * LC_URG * 4 * 64 * 4 * 4 <= LG_LDS_BYTES, "the u reduction fits the gradient body's LDS");
     int b = blockIdx.x;
     if (b < nu_pad) {
-        if (b < nu) lowrank_u_body<LC_UW, 1>(reinterpret_cast<float*>(smem), b, dqkv, ld, qT, u32, ucols, B, H, N, E);
+        if (b < nu) lowrank_u_body<LC_UW, LC_URG>(reinterpret_cast<float*>(smem), b, dqkv, ld, qT, u32, ucols, B, H, N, E);
         return;
     }
     b -= nu_pad;
@@ -715,7 +718,7 @@ int pevit_launch_lowrank_combo(int this_layer, int prev, const bf16* dqkv, int l
     const int T = B * N, chunks = ceil_div(T, LG_ROWS);
     if (E % (64 * LG_ES)) { pevit_set_error("lowrank_combo: width %d must be a multiple of %d", E, 64 * LG_ES); return -1; }
     const int groups = E / 64 / LG_ES;
-    const int nu = this_layer ? ceil_div(T, 16) : 0, n12 = this_layer ? chunks * groups * 2 : 0, n0 = prev ? chunks * groups : 0;
+    const int nu = this_layer ? ceil_div(T, 16 * LC_URG) : 0, n12 = this_layer ? chunks * groups * 2 : 0, n0 = prev ? chunks * groups : 0;
     const int nu_pad = (nu + 7) & ~7, n12_pad = (n12 + 7) & ~7, n0_pad = (n0 + 7) & ~7;
     if (nu_pad + n12_pad + n0_pad == 0) return 0;
     hipLaunchKernelGGL(lowrank_combo_kernel, dim3(nu_pad + n12_pad + n0_pad), dim3(256), 0, s, dqkv, ld, qT, u32, ucols, t, partial,

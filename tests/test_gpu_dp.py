@@ -94,7 +94,8 @@ def test_two_rank_hip_step_equals_mean_of_shard_steps(case, tmp_path):
     assert float((r0["p"] - p_init.cpu()).abs().max()) > 0
 
 
-def test_bench_multi_rank_launch_contract(tmp_path):
+@pytest.mark.parametrize("exchange", ["rccl", "flat"])
+def test_bench_multi_rank_launch_contract(tmp_path, exchange):
     """bench.py exactly as the driver launches it for N > 1 (python -m torch.distributed.run --nnodes=1 --nproc-per-node N
     --master-addr 127.0.0.1 ... bench.py --gpus N --steps K --warmup W), two ranks on the one GPU of the test box (gloo
     instead of RCCL, both ranks on cuda:0): rank 0 prints ONE JSON line whose value is the whole-job aggregate."""
@@ -102,17 +103,17 @@ def test_bench_multi_rank_launch_contract(tmp_path):
     import subprocess
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    port = 29700 + (os.getpid() % 2000)
+    port = 29700 + (os.getpid() % 2000) + (7 if exchange == "flat" else 0)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--arch", "tiny-256", "--batch", "16", "--dist-backend", "gloo", "--share-device"]
+           "--arch", "tiny-256", "--batch", "16", "--dist-backend", "gloo", "--share-device", "--exchange", exchange]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
-    assert d["config"]["global_batch"] == 32 and d["config"]["parallelism"] == "dp2"
+    assert d["config"]["global_batch"] == 32 and d["config"]["parallelism"] == "dp2" and d["config"]["gradient_exchange"] == exchange
     assert abs(d["value"] - 32 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]      # whole job: all ranks' images / time
     assert "cpu_baseline" not in d                                                          # rank 0 at N = 1 only
     assert d["roofline"]["achieved"] > 0
