@@ -343,67 +343,92 @@ __global__ void chain_adapter_kernel(const float* __restrict__ Gd, const float* 
     g_up[l * param_layer + idx] += Gu[l * g_layer + idx];
 }
 
-// Compacter chain: dH -> d W_left / d W_right of both PHM layers.  One block per (which of the 4 small
-// tensors, layer, PHM slice i); every output element is a deterministic sum (fixed per-thread order, then a
-// fixed-order combine of 16 partials through LDS for the two tensors that contract the long dimension).
+// Compacter chain: dH -> d W_left / d W_right of both PHM layers (compacter_model.py:302-308 differentiated).
 //   dH_down[e][j] = Gd[e][j]  (e = a*Fi+k, j = c*16+p) ; dH_up[j][e] = Gu[e][j] (j = a*16+k, e = c*Fi+p)
-__global__ __launch_bounds__(256) void chain_compacter_kernel(const float* __restrict__ Gd, const float* __restrict__ Gu,
+//   0: d dWl[i][k] = sum_{a,c,p} Gd[a*Fi+k][c*16+p] rule[i][a][c] dWr[i][p]      3: d uWr[i][p] = sum_{a,c,k} Gu[c*Fi+p][a*16+k] rule[i][a][c] uWl[i][k]
+//   1: d dWr[i][o] = sum_{a,c,k} Gd[a*Fi+k][c*16+o] rule[i][a][c] dWl[i][k]      2: d uWl[i][o] = sum_{a,c,p} Gu[c*Fi+p][a*16+o] rule[i][a][c] uWr[i][p]
+// One 16-wave block per (tensor, layer), all four PHM slices i at once.  A wave reads whole 64-float rows of G (lane = column:
+// 256 coalesced bytes per request, every row fetched once per block) -- tensors 0 / 3 contract a row against a per-lane
+// coefficient and reduce it over the wave; tensors 1 / 2 accumulate per lane over the rows and meet through LDS.  Every output is
+// a fixed-order sum: deterministic.  (Round 4; the one-thread-per-output form walked 256 strided loads in sequence: 43 us.)
+constexpr int CC_WAVES = 16;
+__global__ __launch_bounds__(64 * CC_WAVES) void chain_compacter_kernel(const float* __restrict__ Gd, const float* __restrict__ Gu,
                                                               const float* __restrict__ rule, const float* __restrict__ params,
                                                               float* grads, int E, size_t g_layer, size_t param_layer,
                                                               size_t off_dWl, size_t off_dWr, size_t off_uWl, size_t off_uWr) {
-    __shared__ float part[16][17];
+    __shared__ float part[CC_WAVES][4][16];
     const size_t l = blockIdx.y;
-    const int which = blockIdx.x;          // 0: d down.W_left, 1: d down.W_right, 2: d up.W_left, 3: d up.W_right
-    const int i = blockIdx.z;              // PHM slice
+    const int which = blockIdx.x;
     const int Fi = E / 4;
-    const float* gd = Gd + l * g_layer; const float* gu = Gu + l * g_layer;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, hi = lane >> 4, lo = lane & 15;
     const float* P = params + l * param_layer; float* Gp = grads + l * param_layer;
-    const float* dWl = P + off_dWl; const float* dWr = P + off_dWr; const float* uWl = P + off_uWl; const float* uWr = P + off_uWr;
-    const float* rl = rule + i * 16;       // rule[i][a][c]
-    if (which == 0) {            // d dWl[i][k] = sum_{a,c,p} dHd[a*Fi+k][c*16+p] rule[i][a][c] dWr[i][p]
-        for (int k = threadIdx.x; k < Fi; k += blockDim.x) {
-            float s = 0.f;
-            for (int a = 0; a < 4; ++a)
-                for (int c = 0; c < 4; ++c) {
-                    const float r = rl[a * 4 + c];
-                    const float* row = gd + (size_t)(a * Fi + k) * 64 + c * 16;
-                    for (int pp = 0; pp < 16; ++pp) s += row[pp] * r * dWr[i * 16 + pp];
-                }
-            Gp[off_dWl + (size_t)i * Fi + k] += s;
-        }
-    } else if (which == 3) {     // d uWr[i][p] = sum_{a,c,k} dHu[a*16+k][c*Fi+p] rule[i][a][c] uWl[i][k]
-        for (int pp = threadIdx.x; pp < Fi; pp += blockDim.x) {
-            float s = 0.f;
-            for (int a = 0; a < 4; ++a)
-                for (int c = 0; c < 4; ++c) {
-                    const float r = rl[a * 4 + c];
-                    const float* row = gu + (size_t)(c * Fi + pp) * 64 + a * 16;
-                    for (int k = 0; k < 16; ++k) s += row[k] * r * uWl[i * 16 + k];
-                }
-            Gp[off_uWr + (size_t)i * Fi + pp] += s;
-        }
-    } else {
-        // 16 outputs, each a contraction over (a, c) and the long index (Fi): thread = (output o, group g of the
-        // long index); which 1: d dWr[i][o] = sum dHd[a*Fi+k][c*16+o] rule dWl[i][k]
-        //                which 2: d uWl[i][o] = sum dHu[a*16+o][c*Fi+p] rule uWr[i][p]
-        const int o = threadIdx.x & 15, g = threadIdx.x >> 4;
-        const float* src = (which == 1) ? gd : gu;
-        const float* vec = (which == 1) ? dWl + (size_t)i * Fi : uWr + (size_t)i * Fi;
-        float s = 0.f;
-        for (int a = 0; a < 4; ++a)
-            for (int c = 0; c < 4; ++c) {
-                const float r = rl[a * 4 + c];
-                for (int q = g; q < Fi; q += 16) {
-                    const size_t idx = (which == 1) ? (size_t)(a * Fi + q) * 64 + c * 16 + o : (size_t)(c * Fi + q) * 64 + a * 16 + o;
-                    s += src[idx] * r * vec[q];
+    const bool down = which < 2;
+    const float* G = (down ? Gd : Gu) + l * g_layer;
+    if (which == 0 || which == 3) {
+        // long output index q (k resp. p), short contracted index lo (p resp. k), rule index pair (x, hi): rows x*Fi + q, x = 0..3
+        const float* vshort = P + (which == 0 ? off_dWr : off_uWl);            // [i][16]
+        float m[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const float r = (which == 0) ? rule[i * 16 + x * 4 + hi] : rule[i * 16 + hi * 4 + x];      // rule[i][a][c]
+                m[i][x] = r * vshort[i * 16 + lo];
+            }
+        float* out = Gp + (which == 0 ? off_dWl : off_uWr);
+        for (int q0 = w; q0 < Fi; q0 += 2 * CC_WAVES) {
+            float xr[2][4];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int q = min(q0 + u * CC_WAVES, Fi - 1);
+#pragma unroll
+                for (int x = 0; x < 4; ++x) xr[u][x] = G[(size_t)(x * Fi + q) * 64 + lane];
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int q = q0 + u * CC_WAVES;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v = xr[u][0] * m[i][0] + xr[u][1] * m[i][1] + xr[u][2] * m[i][2] + xr[u][3] * m[i][3];
+                    v = wave_sum(v);
+                    if (lane == 0 && q < Fi) out[(size_t)i * Fi + q] += v;
                 }
             }
-        part[g][o] = s;
+        }
+    } else {
+        // 16 outputs lo per slice; lane column = (hi, lo); rows x*Fi + q contracted with rule[i][.][.] (pair (x, hi)) and vlong[i][q]
+        const float* vlong = P + (which == 1 ? off_dWl : off_uWr);             // [i][Fi]
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int x = 0; x < 4; ++x) {
+            float r[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r[i] = (which == 1) ? rule[i * 16 + x * 4 + hi] : rule[i * 16 + hi * 4 + x];
+            for (int q0 = w; q0 < Fi; q0 += 4 * CC_WAVES) {
+                float xr[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) xr[u] = G[(size_t)(x * Fi + min(q0 + u * CC_WAVES, Fi - 1)) * 64 + lane];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int q = q0 + u * CC_WAVES;
+                    if (q < Fi) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[i] += xr[u] * r[i] * vlong[(size_t)i * Fi + q];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v = acc[i];
+            v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+            if (lane < 16) part[w][i][lane] = v;
+        }
         __syncthreads();
-        if (threadIdx.x < 16) {
+        if (threadIdx.x < 64) {
+            const int i = threadIdx.x >> 4, o = threadIdx.x & 15;
             float t = 0.f;
-            for (int gg = 0; gg < 16; ++gg) t += part[gg][threadIdx.x];
-            Gp[((which == 1) ? off_dWr : off_uWl) + (size_t)i * 16 + threadIdx.x] += t;
+            for (int ww = 0; ww < CC_WAVES; ++ww) t += part[ww][i][o];
+            Gp[(which == 1 ? off_dWr : off_uWl) + (size_t)i * 16 + o] += t;
         }
     }
 }
@@ -595,7 +620,7 @@ int pevit_launch_chain_adapter(const float* Gd, const float* Gu, float* g_down, 
 int pevit_launch_chain_compacter(const float* Gd, const float* Gu, const float* rule, const float* params, float* grads, int E,
                                  int layers, size_t g_layer, size_t param_layer, size_t off_dWl, size_t off_dWr, size_t off_uWl,
                                  size_t off_uWr, hipStream_t s) {
-    hipLaunchKernelGGL(chain_compacter_kernel, dim3(4, layers, 4), dim3(256), 0, s, Gd, Gu, rule, params, grads, E, g_layer,
+    hipLaunchKernelGGL(chain_compacter_kernel, dim3(4, layers), dim3(64 * CC_WAVES), 0, s, Gd, Gu, rule, params, grads, E, g_layer,
                        param_layer, off_dWl, off_dWr, off_uWl, off_uWr);
     LAUNCH_OK("chain_compacter_kernel");
     return 0;

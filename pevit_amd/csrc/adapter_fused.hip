@@ -265,6 +265,137 @@ __global__ __launch_bounds__(64 * AF_WAVES) void adapter_fwd_kernel(const float*
     }
 }
 
+// ---- the token-contracted weight gradients in the shadow of the backward workgroups -------------------------------------------
+// adapter_bwd_kernel keeps ONE workgroup on 200 of the 256 CUs for ~27 us (T = 6400; its LDS block admits no second one); the two
+// G[e][j] = sum_r X[r][e] Y[r][j] products of an adapter (d W_up = dx_out^T act, d W_down = z^T d pre: tn_gemm64_kernel, 8.5 us
+// per launch, 24 launches per step) are independent small jobs, so they ride in the SAME launch as extra workgroups, which the
+// dispatcher places on the idle CUs:
+//   d W_up   of THIS layer (its operands exist before the launch), and
+//   d W_down of the layer processed BEFORE this one (its d pre was written by the previous launch; d pre alternates between two
+//            buffers so that this launch's backward workgroups do not overwrite it; the last layer's product gets a launch of its own).
+// A workgroup of the range takes two (256-row chunk, 64-column slab) units at a time, one per half of its eight waves.  The arithmetic and
+// its ORDER are those of tn_gemm64_kernel (adapter.hip) -- MFMA k-steps 0..7 of the chunk in sequence into one accumulator, column
+// sums per thread over the eight row batches in sequence, then the same shuffles -- hence the same bits; the chunk passes through
+// LDS as two 128-row halves so that both units fit the block.
+constexpr int TNH_ROWS = 128, TNH_LD = 72, TN_CHUNK = 256;
+constexpr int TNH_BYTES = 2 * TNH_ROWS * TNH_LD * 2 + 4 * 64 * 4;
+static_assert(AF_WAVES == 8, "two four-wave halves per workgroup of the contraction range");
+
+struct AfTn {
+    const bf16* X1; const bf16* Y1; float* P1; int n1;                     // this layer: X = dx_out (bf16), Y = saved activation
+    const bf16* X2; const bf16* Y2; float* P2; float* csy2; int n2;        // previous launch's layer: X = z, Y = d pre (+ its column sums)
+};
+
+__device__ __forceinline__ bf16x8 af_trfrag(const bf16* tile, int ks, int col0, int lane) {
+    typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+    const int m = lane & 15, g = lane >> 4;
+    const bf16* src = tile + (32 * ks + 4 * g + (m >> 2)) * TNH_LD + col0 + 4 * (m & 3);
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(src));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(src + 16 * TNH_LD));
+    bf16x8 o;
+    o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
+    o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
+    return o;
+}
+
+// The contraction range: workgroup blk of nblk walks the unit pairs blk, blk + nblk, ... (its two halves take one unit each), with
+// the NEXT unit's sixteen 16-byte requests per thread in flight while the current one goes through LDS and the matrix core.  The
+// launcher's default is one workgroup per pair (a single trip); fewer, walking workgroups measured slower (see the launcher).
+// Every thread of the workgroup executes the same barriers (the trip count is the workgroup's; a half without a unit left works
+// on a clamped one and stores nothing).
+__device__ __forceinline__ void af_tn_range(char* smem, int blk, int nblk, const AfTn& tn, int T, int E) {
+    const int half = threadIdx.x >> 8, t = threadIdx.x & 255;
+    char* lds = smem + half * TNH_BYTES;
+    bf16* Xs = reinterpret_cast<bf16*>(lds);
+    bf16* Ys = Xs + TNH_ROWS * TNH_LD;
+    float (*cs)[64] = reinterpret_cast<float (*)[64]>(lds + 2 * TNH_ROWS * TNH_LD * 2);
+    const int lane = t & 63, w = t >> 6, g = lane >> 4, c16 = lane & 15, c = t & 7;
+    const int eslabs = E / 64, nu = tn.n1 + tn.n2;
+    const int trips = (nu - 2 * blk + 2 * nblk - 1) / (2 * nblk);
+    bf16x8 xv[8], yv[8], xn[8], yn[8];
+    // rows beyond T read row T - 1 (zeroed when used): no load sits inside a bounds branch
+    auto request = [&](int u, bf16x8 (&x)[8], bf16x8 (&y)[8]) {
+        const int uc = min(u, nu - 1);
+        const bool first = uc < tn.n1;
+        const int unit = first ? uc : uc - tn.n1;
+        const bf16* X = first ? tn.X1 : tn.X2;
+        const bf16* Y = first ? tn.Y1 : tn.Y2;
+        const int chunk = unit / eslabs, e0 = (unit - chunk * eslabs) * 64, r0 = chunk * TN_CHUNK;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int r = min(r0 + (t >> 3) + 32 * it, T - 1);
+            x[it] = load_bf16x8(X + (size_t)r * E + e0 + 8 * c);
+            y[it] = load_bf16x8(Y + (size_t)r * 64 + 8 * c);
+        }
+    };
+    request(2 * blk + half, xv, yv);
+    for (int k = 0; k < trips; ++k) {
+        const int u = 2 * (blk + k * nblk) + half;
+        const bool valid = u < nu;
+        const int uc = min(u, nu - 1);
+        const bool first = uc < tn.n1;
+        const int unit = first ? uc : uc - tn.n1;
+        float* partial = first ? tn.P1 : tn.P2;
+        float* csy = first ? nullptr : tn.csy2;
+        const int chunk = unit / eslabs, e0 = (unit - chunk * eslabs) * 64, r0 = chunk * TN_CHUNK;
+        if (k + 1 < trips) request(u + 2 * nblk, xn, yn);
+        if (k) __syncthreads();                              // the previous unit's fragments and column sums have been read
+        float sy[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sy[i] = 0.f;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            if (r0 + (t >> 3) + 32 * it >= T) { xv[it] = zero_bf16x8(); yv[it] = zero_bf16x8(); }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sy[i] += bf2f(yv[it][i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float b = sy[i];
+            b += __shfl_xor(b, 8, 64); b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+            if ((lane >> 3) == 0) cs[w][8 * c + i] = b;
+        }
+        f32x4 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+            if (ph) __syncthreads();                         // the first half's fragments have been read
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int y = (t >> 3) + 32 * it;
+                *reinterpret_cast<bf16x8*>(Xs + y * TNH_LD + 8 * c) = xv[4 * ph + it];
+                *reinterpret_cast<bf16x8*>(Ys + y * TNH_LD + 8 * c) = yv[4 * ph + it];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 a = af_trfrag(Xs, ks, 16 * w, lane);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, af_trfrag(Ys, ks, 16 * nt, lane), acc[nt], 0, 0, 0);
+            }
+        }
+        // the next unit's operands are taken over BEFORE this unit's stores go out: waiting for them afterwards would also wait for
+        // the stores (vmcnt counts both on gfx950), a memory round trip per unit
+        float csv = 0.f;
+        if (t < 64) csv = cs[0][t] + cs[1][t] + cs[2][t] + cs[3][t];
+        if (k + 1 < trips) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) { xv[it] = xn[it]; yv[it] = yn[it]; }
+        }
+        if (valid) {
+            float* out = partial + (size_t)chunk * E * 64;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[(size_t)(e0 + 16 * w + 4 * g + r) * 64 + 16 * nt + c16] = acc[nt][r];
+            if (csy && e0 == 0 && t < 64) csy[(size_t)chunk * 64 + t] = csv;
+        }
+    }
+}
+
+
 // backward.  dyb: bf16 copy of dx_out (the operand of the products), dres: dx_out itself (f32).  Outputs: dpre (bf16 [T][64], feeds
 // the d W_down contraction), dh_bf16 = bf16(dres + LN_a'(d z)) (operand of the c_proj backward GEMM), partial[block][3][E] =
 // column sums of dz*xhat (d gamma), dz (d beta), dres (d b_up) over the block's rows (layout of ln_bwd_affine_kernel).
@@ -275,8 +406,13 @@ __global__ __launch_bounds__(64 * AF_WAVES) void adapter_bwd_kernel(const bf16* 
                                                                     const float* __restrict__ bpr, const float* __restrict__ mean_a,
                                                                     const float* __restrict__ rstd_a, const float* __restrict__ gamma,
                                                                     bf16* __restrict__ dpre, bf16* __restrict__ dh_bf16,
-                                                                    float* __restrict__ partial, int T, int E, int rb) {
+                                                                    float* __restrict__ partial, int T, int E, int rb, int nb,
+                                                                    AfTn tn) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((int)blockIdx.x >= nb) {                                 // the contraction range (see af_tn_range)
+        af_tn_range(smem, (int)blockIdx.x - nb, (int)gridDim.x - nb, tn, T, E);
+        return;
+    }
     const AfLds L = af_layout(E);
     bf16* Ys = reinterpret_cast<bf16*>(smem + L.zs);
     float* red = reinterpret_cast<float*>(smem + L.red);
@@ -449,21 +585,35 @@ int pevit_launch_adapter_fwd(int act_kind, const float* hraw, const float* bpr, 
     return 0;
 }
 
+// tn_*: the contraction range of the launch (see af_tn_range); tn_x1 = nullptr / tn_x2 = nullptr leave a product out.
+//   product 1: partial1[chunk][E][64] = sum over the chunk's rows of x1[r][e] y1[r][j]             (x1: [T][E] bf16, y1: [T][64] bf16)
+//   product 2: the same for x2, y2 -> partial2, and csy2[chunk][64] = column sums of y2
 int pevit_launch_adapter_bwd(int act_kind, const bf16* dyb, const float* dres, const bf16* wuT, const bf16* saved, const bf16* wdT,
                              const float* hraw, const float* bpr, const float* mean_a, const float* rstd_a, const float* gamma,
-                             bf16* dpre, bf16* dh_bf16, float* partial, int T, int E, hipStream_t s) {
+                             bf16* dpre, bf16* dh_bf16, float* partial, int T, int E, hipStream_t s, const bf16* tn_x1,
+                             const bf16* tn_y1, float* tn_partial1, const bf16* tn_x2, const bf16* tn_y2, float* tn_partial2,
+                             float* tn_csy2, int tn_blocks) {
     if (af_check(T, E, "adapter_bwd")) return -1;
+    if (tn_x2 && tn_y2 == dpre) { pevit_set_error("adapter_bwd: the deferred contraction reads the d pre buffer this launch writes"); return -1; }
     const AfLds L = af_layout(E);
-    const int lds = L.colred;
     const int rb = af_rows_per_wg(T);
-    const dim3 grid(ceil_div(T, rb)), block(64 * AF_WAVES);
+    const int nb = ceil_div(T, rb), units = ceil_div(T, TN_CHUNK) * (E / 64);
+    AfTn tn;
+    tn.X1 = tn_x1; tn.Y1 = tn_y1; tn.P1 = tn_partial1; tn.n1 = tn_x1 ? units : 0;
+    tn.X2 = tn_x2; tn.Y2 = tn_y2; tn.P2 = tn_partial2; tn.csy2 = tn_csy2; tn.n2 = tn_x2 ? units : 0;
+    // workgroups of the contraction range: one per unit pair.  (Measured, Adapter ViT-B/32 batch 128, same box: no folding 4.92 ms per
+    // step; 40 / 80 persistent workgroups walking the pairs 4.96; 112: 4.78; one per pair (300): 4.72 -- a unit is a latency chain
+    // (requests -> LDS -> matrix core -> stores), so more of them in flight beats fewer, longer-lived ones.)
+    const int ntn = min(ceil_div(tn.n1 + tn.n2, 2), tn_blocks > 0 ? tn_blocks : (1 << 30));
+    const int lds = ntn ? max(L.colred, 2 * TNH_BYTES) : L.colred;
+    const dim3 grid(nb + ntn), block(64 * AF_WAVES);
     static bool attr[2] = {false, false};
     if (act_kind == 0) {
         if (!attr[0]) { if (af_attr(adapter_bwd_kernel<0>, 160 * 1024, "adapter_bwd")) return -1; attr[0] = true; }
-        hipLaunchKernelGGL(adapter_bwd_kernel<0>, grid, block, lds, s, dyb, dres, wuT, saved, wdT, hraw, bpr, mean_a, rstd_a, gamma, dpre, dh_bf16, partial, T, E, rb);
+        hipLaunchKernelGGL(adapter_bwd_kernel<0>, grid, block, lds, s, dyb, dres, wuT, saved, wdT, hraw, bpr, mean_a, rstd_a, gamma, dpre, dh_bf16, partial, T, E, rb, nb, tn);
     } else {
         if (!attr[1]) { if (af_attr(adapter_bwd_kernel<1>, 160 * 1024, "adapter_bwd")) return -1; attr[1] = true; }
-        hipLaunchKernelGGL(adapter_bwd_kernel<1>, grid, block, lds, s, dyb, dres, wuT, saved, wdT, hraw, bpr, mean_a, rstd_a, gamma, dpre, dh_bf16, partial, T, E, rb);
+        hipLaunchKernelGGL(adapter_bwd_kernel<1>, grid, block, lds, s, dyb, dres, wuT, saved, wdT, hraw, bpr, mean_a, rstd_a, gamma, dpre, dh_bf16, partial, T, E, rb, nb, tn);
     }
     LAUNCH_OK("adapter_bwd_kernel");
     return 0;

@@ -76,7 +76,7 @@ struct pevit_ctx {
     size_t w_skflag = 0, w_skslab = 0; int sk_slots = 0;   // stream-K workspace (gemm.hip), sk_slots = 0: disabled
     size_t w_xfinal, w_xn2, w_g, w_dqkv, w_u32, w_u32b, w_dO, w_dh, w_dxn, w_dxa, w_dxb, w_dyb, w_partial, w_dbias;
     size_t w_G, w_rule, partial_layer, dbias_layer;
-    size_t w_dpre, w_dht, w_dhb, w_tnU, w_tnD, w_csx, w_csy, w_lnp, w_Gd, w_Gu, tn_layer, csx_layer, csy_layer, lnp_layer;
+    size_t w_dpre, w_dpre2, w_dht, w_dhb, w_tnU, w_tnD, w_csx, w_csy, w_lnp, w_Gd, w_Gu, tn_layer, csx_layer, csy_layer, lnp_layer;
     // post-MLP adapter parameter offsets inside one layer's block of the flat buffer (floats)
     size_t o_nw, o_nb, o_dw, o_db, o_uw, o_ub, o_dWl, o_dWr, o_uWl, o_uWr;
     size_t w_patches, w_xpost, w_feat, w_pmean, w_prstd, w_ybn, w_bnrstd, w_logits, w_dlogits, w_dybn, w_dfeat,
@@ -113,6 +113,7 @@ struct pevit_ctx {
     int fused_bn = 0;         // post-MLP adapters: down -> activation -> up (and its backward) as one launch each (adapter.hip
                               // bottleneck_pair_kernel): 24.4 + 22.1 us against 22.9 + 19.5 us for the four GEMM launches -- opt-in
     int lowrank_combo = 1;    // attention-site adapters: u + dQ + d bias of a layer and the dP of the layer before it as one launch
+    int adapter_tn_fold = 1;  // ... and the two token-contracted weight-gradient products ride in the backward launch (adapter_fused.hip: af_tn_range; > 1: that many workgroups for them)
     int adapter_fused = 1;    // post-MLP adapters: LayerNorm -> down -> activation -> up -> residual (and its backward) as one launch each
     int fp8_tail = 1;         // fp8 weights: t = xn P as the bf16 tail of the QKV launch (0: a separate small product, as before round 4)
     int fused_attn_delta = 1; // delta-add + attention forward as one launch where the geometry allows (attn_delta.hip)
@@ -182,6 +183,7 @@ void layout_workspace(pevit_ctx* c, int B, LayerSaved* sav, size_t* total, pevit
         const size_t tn_layer = (size_t)tch * E * 64 * 4, csx_layer = (size_t)tch * E * 4, csy_layer = (size_t)tch * 64 * 4,
                      lnp_layer = (size_t)lnb * 3 * E * 4;
         o = cv.take(T * 64 * es);            if (fill) fill->w_dpre = o;
+        o = cv.take(T * 64 * es);            if (fill) fill->w_dpre2 = o;     // d pre alternates: the deferred d W_down product reads the previous one
         o = cv.take(T * E * 4);             if (fill) fill->w_dht = o;
         o = cv.take(T * E * es);             if (fill) fill->w_dhb = o;
         o = cv.take(tn_layer * c->L);       if (fill) { fill->w_tnU = o; fill->tn_layer = tn_layer; }
@@ -757,6 +759,8 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0, bool cls_
     const bool combo = c->lowrank_combo && site && !c->f32 && !use_side;
     int prev_layer = -1, u_par = 0;
     float* u_last = nullptr;
+    int tn_pend = -1, tn_par = 0;          // post-MLP adapters: layer whose d W_down product is still owed, and the d pre buffer in turn
+    const bf16* tn_pend_dpre = nullptr;
     if (use_side && !c->side) {
         HIP_OK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
         HIP_OK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -771,23 +775,31 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0, bool cls_
         if (post_mlp(c)) {
             // out = x_mid + h + up(act(down(LN_a(h)))) :  dx_out (dxa, dyb) flows to x_mid, to h, and into the adapter
             const float* lp = c->params + c->p_layer0 + c->p_layer_stride * l;
-            bf16* dpre = at<bf16>(W, c->w_dpre);
+            const bool fused_ad = c->adapter_fused && !c->f32 && !c->fused_bn && pevit_adapter_fused_ok(E);
+            const bool fold = fused_ad && c->adapter_tn_fold;      // both weight-gradient products inside the backward launch
+            bf16* dpre = at<bf16>(W, (fold && tn_par) ? c->w_dpre2 : c->w_dpre);
             // d W_up[e][j] = sum_r dx_out[r][e] act[r][j] ; d b_up = colsum(dx_out)
-            if (c->f32)
+            if (fold) {}
+            else if (c->f32)
                 CHECK(pevit_launch_tn_gemm64_f32((const float*)dyb, E, at<float>(W, v.act), 64, at<float>(W, c->w_tnU + (size_t)l * c->tn_layer),
                                                  nullptr, nullptr, T, E, s));
             else
                 CHECK(pevit_launch_tn_gemm64(dyb, E, at<bf16>(W, v.act), 64, at<float>(W, c->w_tnU + (size_t)l * c->tn_layer),
                                              nullptr, nullptr, T, E, s));
-            const bool fused_ad = c->adapter_fused && !c->f32 && !c->fused_bn && pevit_adapter_fused_ok(E);
             if (fused_ad) {
+                const int pl = tn_pend >= 0 ? tn_pend : l;       // the layer whose d W_down product this launch carries (if any)
                 // d pre, d z and the LayerNorm backward with its affine-gradient column sums in one launch (adapter_fused.hip); the
                 // forward pass left the c_proj accumulators WITHOUT their bias in hf32
                 PROF(c, s, PEVIT_PROF_ADAPTER_BWD, T, (double)T * E * (2 + 4 + 4 + 2) + (double)T * 64 * 4,
                      pevit_launch_adapter_bwd(c->d.method == PEVIT_ADAPTER ? 0 : 1, dyb, dxa, at<bf16>(A, b.wuT),
                                               c->d.method == PEVIT_ADAPTER ? at<bf16>(W, v.act) : at<bf16>(W, v.apre), at<bf16>(A, b.wdT),
                                               at<float>(W, v.hf32), at<float>(A, b.bpr), at<float>(W, v.mean_a), at<float>(W, v.rstd_a),
-                                              lp + c->o_nw, dpre, at<bf16>(W, c->w_dhb), at<float>(W, c->w_lnp + (size_t)l * c->lnp_layer), T, E, s));
+                                              lp + c->o_nw, dpre, at<bf16>(W, c->w_dhb), at<float>(W, c->w_lnp + (size_t)l * c->lnp_layer), T, E, s,
+                                              fold ? dyb : nullptr, at<bf16>(W, v.act), at<float>(W, c->w_tnU + (size_t)l * c->tn_layer),
+                                              (fold && tn_pend >= 0) ? at<bf16>(W, c->sav[pl].z) : nullptr, tn_pend_dpre,
+                                              at<float>(W, c->w_tnD + (size_t)pl * c->tn_layer), at<float>(W, c->w_csy + (size_t)pl * c->csy_layer),
+                                              c->adapter_tn_fold > 1 ? c->adapter_tn_fold : 0));
+                if (fold) { tn_pend = l; tn_pend_dpre = dpre; tn_par ^= 1; }
             } else if (c->fused_bn && !c->f32) {
                 // d pre = (dx_out W_up) * act'(saved) ; d z = d pre W_down, one launch
                 CHECK(pevit_launch_bottleneck_pair(c->d.method == PEVIT_ADAPTER ? 2 : 3, dyb, E, at<bf16>(A, b.wuT), nullptr,
@@ -807,7 +819,8 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0, bool cls_
             }
             }
             // d W_down[j][e] = sum_r d pre[r][j] z[r][e] ; d b_down = colsum(d pre)
-            if (c->f32)
+            if (fold) {}
+            else if (c->f32)
                 CHECK(pevit_launch_tn_gemm64_f32(at<float>(W, v.z), E, (const float*)dpre, 64, at<float>(W, c->w_tnD + (size_t)l * c->tn_layer),
                                                  nullptr, at<float>(W, c->w_csy + (size_t)l * c->csy_layer), T, E, s));
             else
@@ -910,6 +923,9 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0, bool cls_
         }
     }
     if (side_pending) HIP_OK(hipStreamWaitEvent(s, c->ev_join, 0));
+    if (tn_pend >= 0)                   // the d W_down product of the last adapter walked
+        CHECK(pevit_launch_tn_gemm64(at<bf16>(W, c->sav[tn_pend].z), E, tn_pend_dpre, 64, at<float>(W, c->w_tnD + (size_t)tn_pend * c->tn_layer),
+                                     nullptr, at<float>(W, c->w_csy + (size_t)tn_pend * c->csy_layer), T, E, s));
     if (combo && prev_layer >= 0)       // the dP of the last layer walked
         PROF(c, s, PEVIT_PROF_LOWRANK_BWD, T, (double)T * E * 2 + (double)T * 64 * 4,
              pevit_launch_lowrank_combo(0, 1, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, at<bf16>(W, c->sav[prev_layer].xn1), E,
@@ -1479,6 +1495,7 @@ extern "C" int pevit_tune(pevit_ctx* c, const char* key, int value) {
     if (key && c && !strcmp(key, "fused_attn_delta")) { c->fused_attn_delta = value; return 0; }
     if (key && c && !strcmp(key, "fp8_tail")) { c->fp8_tail = value; return 0; }
     if (key && c && !strcmp(key, "adapter_fused")) { c->adapter_fused = value; return 0; }
+    if (key && c && !strcmp(key, "adapter_tn_fold")) { c->adapter_tn_fold = value; return 0; }
     if (key && c && !strcmp(key, "lowrank_combo")) { c->lowrank_combo = value; return 0; }
     if (key && c && !strcmp(key, "lowrank_xcd")) { c->lowrank_xcd = value; return 0; }
     pevit_set_error("tune: unknown key %s", key ? key : "(null)");

@@ -1859,6 +1859,7 @@ bool pevit_gemm_mixed_ok(const GemmParams& p, const GemmTune& t) {
     return cfg == 5 || cfg == 4 || cfg == CFG_160x256;
 }
 
+int pevit_num_cus() { return num_cus(); }
 int pevit_gemm_sk_slots() { return min(2 * num_cus(), PEVIT_SK_MAX_SLOTS) & ~7; }
 int pevit_gemm_last_path() { return g_last_path; }
 

@@ -222,6 +222,7 @@ int pevit_launch_ln_bwd_affine(const float* dy, const float* x, const float* mea
                                const float* dres, float* dx, bf16* dx_bf16, float* partial, int rows, int E, hipStream_t s, int f32 = 0);
 // ---- adapter_fused.hip: the post-MLP adapter as one launch per direction (bf16 storage, E a multiple of 256) ----
 bool pevit_adapter_fused_ok(int E);
+int pevit_num_cus();                 // compute units of the current device (cached)
 int pevit_adapter_blocks(int T);     // workgroups (= blocks of LayerNorm-affine partials) of the fused backward
 // act_kind 0 = ReLU (Adapter), 1 = gelu_new (Compacter).  hraw = c_proj accumulators WITHOUT their bias (f32), bpr = that bias.
 int pevit_launch_adapter_fwd(int act_kind, const float* hraw, const float* bpr, const float* x_mid, const float* gamma, const float* beta,
@@ -230,7 +231,10 @@ int pevit_launch_adapter_fwd(int act_kind, const float* hraw, const float* bpr, 
 // saved = act (ReLU) / apre (gelu_new); partial: [pevit_lna_blocks(T)][3][E] like ln_bwd_affine
 int pevit_launch_adapter_bwd(int act_kind, const bf16* dyb, const float* dres, const bf16* wuT, const bf16* saved, const bf16* wdT,
                              const float* hraw, const float* bpr, const float* mean_a, const float* rstd_a, const float* gamma,
-                             bf16* dpre, bf16* dh_bf16, float* partial, int T, int E, hipStream_t s);
+                             bf16* dpre, bf16* dh_bf16, float* partial, int T, int E, hipStream_t s, const bf16* tn_x1 = nullptr,
+                             const bf16* tn_y1 = nullptr, float* tn_partial1 = nullptr, const bf16* tn_x2 = nullptr,
+                             const bf16* tn_y2 = nullptr, float* tn_partial2 = nullptr, float* tn_csy2 = nullptr,
+                             int tn_blocks = 0);      // workgroups of the contraction range, 0 = one per unit pair
 int pevit_launch_colsum_reduce(const float* partial, int chunks, int n, float* out, int layers, size_t partial_layer,
                                size_t out_layer, hipStream_t s);
 int pevit_launch_colsum_reduce3(const float* partial, int chunks, int n, float* o0, float* o1, float* o2, int layers,

@@ -347,7 +347,7 @@ __global__ __launch_bounds__(64 * LU_WAVES) void lowrank_u_kernel(const bf16* __
 //   kind 1: X = dDelta_q (flat view), Y = t_q  -> G2 = dQ_q  (+ column sums -> d bias)
 //   kind 2: X = dDelta_v,             Y = t_v  -> G3 = dQ_v  (+ column sums)
 // The MFMA wants the contraction index contiguous per lane, but both operands are stored
-// token-major.  One workgroup = (chunk of LG_ROWS tokens, kind, LG_ES slabs of 64 columns e).  Both panels go to LDS
+// token-major.  One workgroup = (chunk of LG_ROWS tokens, kind, es slabs of 64 columns e).  Both panels go to LDS
 // ROW-major (X: 16-byte writes as loaded; Y: f32 -> bf16, 8-byte writes) and every MFMA fragment is a pair of
 // ds_read_b64_tr_b16 (the gfx950 transposing read: in a 16-lane group lane 4j+q passes the address of 4 consecutive
 // columns of token-row j and lane i receives column i of that 4 x 16 block; scripts/probe_tr_b16.hip), k-slot idx of
@@ -355,11 +355,10 @@ __global__ __launch_bounds__(64 * LU_WAVES) void lowrank_u_kernel(const bf16* __
 // slab: they are read once into registers, and the X panel of the next slab is in flight (registers) while the current
 // one is multiplied.  One deterministic partial per chunk goes to HBM.
 #ifndef LG_ES_V
-#define LG_ES_V 2
+#define LG_ES_V 0        // 0: the launcher picks the slabs per workgroup (lg_pick_es); > 0 pins it (measurement builds)
 #endif
 constexpr int LG_ROWS = 256;
 constexpr int LG_LD = 72;          // row stride (elements) of the LDS tiles: 36 dwords, 8 consecutive rows cover all banks
-constexpr int LG_ES = LG_ES_V;           // 64-column slabs per workgroup
 
 __device__ __forceinline__ bf16x8 lg_trfrag(const bf16* tile, int ks, int col0, int lane) {
     typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
@@ -380,12 +379,12 @@ constexpr int LG_LDS_BYTES = 2 * LG_ROWS * LG_LD * 2 + 4 * 64 * 4;
 __device__ __forceinline__ void lowrank_grad_body(char* smem, int bid, int kind_lo, int nkinds, const bf16* __restrict__ xn, int ldx,
                                                   const float* __restrict__ u32, const bf16* __restrict__ dqkv, int ld,
                                                   const float* __restrict__ t, float* __restrict__ partial,
-                                                  float* __restrict__ dbias_partial, int B, int H, int N, int E) {
+                                                  float* __restrict__ dbias_partial, int B, int H, int N, int E, int es) {
     bf16* Xs = reinterpret_cast<bf16*>(smem);
     bf16* Ys = Xs + LG_ROWS * LG_LD;
     float (*cs)[64] = reinterpret_cast<float (*)[64]>(smem + 2 * LG_ROWS * LG_LD * 2);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, c16 = lane & 15;
-    const int groups = E / 64 / LG_ES;
+    const int groups = E / 64 / es;                         // es = 64-column slabs per workgroup
     const int per_chunk = groups * nkinds;
     // the `groups` workgroups of a (chunk, kind) read the same Y rows (64 KB of u / 32 KB of t): the caller hands out consecutive
     // LOGICAL ids on one XCD (workgroup b runs on XCD b % 8), so that its L2 fetches them once instead of up to six L2s once each
@@ -415,7 +414,7 @@ __device__ __forceinline__ void lowrank_grad_body(char* smem, int bid, int kind_
         for (int it = 0; it < LG_ROWS / 32; ++it)
             if (r0 + (tid >> 3) + 32 * it >= T) xv[it] = zero_bf16x8();
     };
-    load_x(eg * LG_ES * 64);
+    load_x(eg * es * 64);
     // Y (f32): kind 0 -> 64 columns of u (16 float4 per row); else 32 columns of t (8 float4 per row)
     const int sh = (kind == 0) ? 4 : 3;                     // log2(float4 groups per row)
     const int nY = (kind == 0) ? 16 : 8;                    // loads per thread
@@ -454,8 +453,8 @@ __device__ __forceinline__ void lowrank_grad_body(char* smem, int bid, int kind_
 
     const size_t plane = (size_t)E * 32;
     float* base = partial + ((size_t)chunk * 4 + (kind == 0 ? 0 : kind + 1)) * plane;
-    for (int sl = 0; sl < LG_ES; ++sl) {
-        const int e0 = (eg * LG_ES + sl) * 64;
+    for (int sl = 0; sl < es; ++sl) {
+        const int e0 = (eg * es + sl) * 64;
         // ---- this slab's X panel: registers -> LDS (row-major), column sums on the way ----
         float colsum[8];
 #pragma unroll
@@ -477,7 +476,7 @@ __device__ __forceinline__ void lowrank_grad_body(char* smem, int bid, int kind_
             }
         }
         __syncthreads();
-        if (sl + 1 < LG_ES) load_x(e0 + 64);               // in flight during the MFMAs below
+        if (sl + 1 < es) load_x(e0 + 64);                   // in flight during the MFMAs below
         // ---- MFMA: wave w owns rows e = 16w..16w+15 of the 64 x (64|32) tile ----
         f32x4 acc[4];
 #pragma unroll
@@ -513,10 +512,10 @@ __global__ __launch_bounds__(256, 2) void lowrank_grad_kernel(const bf16* __rest
                                                               const bf16* __restrict__ dqkv, int ld,
                                                               const float* __restrict__ t, float* __restrict__ partial,
                                                               float* __restrict__ dbias_partial, int B, int H, int N,
-                                                              int E, int remap) {
+                                                              int E, int remap, int es) {
     __shared__ __attribute__((aligned(16))) char smem[LG_LDS_BYTES];
     const int bid = remap ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
-    lowrank_grad_body(smem, bid, 0, 3, xn, ldx, u32, dqkv, ld, t, partial, dbias_partial, B, H, N, E);
+    lowrank_grad_body(smem, bid, 0, 3, xn, ldx, u32, dqkv, ld, t, partial, dbias_partial, B, H, N, E, es);
 }
 
 // ONE launch per layer for the whole low-rank backward (round 4): block ranges, each padded to a multiple of 8 so that a range's
@@ -536,7 +535,7 @@ __global__ __launch_bounds__(256, 2) void lowrank_combo_kernel(const bf16* __res
                                                                float* __restrict__ dbias_partial,
                                                                const bf16* __restrict__ xn_prev, int ldx, const float* __restrict__ u32_prev,
                                                                float* __restrict__ partial_prev, int nu, int nu_pad, int n12, int n12_pad,
-                                                               int n0, int B, int H, int N, int E) {
+                                                               int n0, int B, int H, int N, int E, int es) {
     __shared__ __attribute__((aligned(16))) char smem[LG_LDS_BYTES];
     static_assert(LC_UW * LC_URG * 4 * 64 * 4 * 4 <= LG_LDS_BYTES, "the u reduction fits the gradient body's LDS");
     int b = blockIdx.x;
@@ -552,7 +551,7 @@ __global__ __launch_bounds__(256, 2) void lowrank_combo_kernel(const bf16* __res
     const int bid = xcd_remap(local, this_layer ? n12_pad : n0_pad);
     if (bid >= (this_layer ? n12 : n0)) return;
     lowrank_grad_body(smem, bid, this_layer ? 1 : 0, this_layer ? 2 : 1, xn_prev, ldx, u32_prev, dqkv, ld, t,
-                      this_layer ? partial : partial_prev, dbias_partial, B, H, N, E);
+                      this_layer ? partial : partial_prev, dbias_partial, B, H, N, E, es);
 }
 
 // sum the per-chunk partials of every layer (blockIdx.y): G[l][4][E][32], and the bias gradient
@@ -711,18 +710,39 @@ int pevit_launch_lowrank_u(const bf16* dqkv, int ld, const bf16* qT, float* u32,
 
 int pevit_lowrank_chunks(int T) { return ceil_div(T, LG_ROWS); }
 
+// 64-column slabs per gradient workgroup.  Two workgroups fit a CU (LDS), so a launch of <= 2 * CUs blocks runs as ONE wave of
+// workgroups; a block costs about (2 + es) slab times (its Y panel and B fragments are loaded once, then es slabs of X), so the
+// launch costs  waves * (2 + es).  ViT-B/32, batch 128 (25 chunks, 12 slabs, 200 u blocks): es = 2 -> 650 blocks, two waves,
+// 21.4 us;  es = 3 -> 500 blocks, one wave, 17.8 us;  es = 4 -> 425 blocks, one wave of longer blocks, 20.7 us (measured, round 4).
+static int lg_pick_es(int E, int chunks, int kinds, int other_blocks) {
+    const int slabs = E / 64;
+    if (LG_ES_V > 0) return (slabs % LG_ES_V == 0) ? LG_ES_V : 0;
+    const int slots = 2 * pevit_num_cus();
+    int best = 0, best_cost = 0;
+    for (int es = 1; es <= 8; ++es) {
+        if (slabs % es) continue;
+        const int total = other_blocks + chunks * (slabs / es) * kinds;
+        const int cost = ceil_div(total, slots) * (2 + es);
+        if (!best || cost < best_cost) { best = es; best_cost = cost; }
+    }
+    return best;
+}
+
 // see lowrank_combo_kernel.  this_layer = 0: only the deferred dP of the previous layer (end of the layer loop); prev = 0: no deferred work.
 int pevit_launch_lowrank_combo(int this_layer, int prev, const bf16* dqkv, int ld, const bf16* qT, float* u32, bf16* ucols, const float* t,
                                float* partial, float* dbias_partial, const bf16* xn_prev, int ldx, const float* u32_prev,
                                float* partial_prev, int B, int H, int N, int E, hipStream_t s) {
     const int T = B * N, chunks = ceil_div(T, LG_ROWS);
-    if (E % (64 * LG_ES)) { pevit_set_error("lowrank_combo: width %d must be a multiple of %d", E, 64 * LG_ES); return -1; }
-    const int groups = E / 64 / LG_ES;
-    const int nu = this_layer ? ceil_div(T, 16 * LC_URG) : 0, n12 = this_layer ? chunks * groups * 2 : 0, n0 = prev ? chunks * groups : 0;
+    if (E % 64) { pevit_set_error("lowrank_combo: width %d must be a multiple of 64", E); return -1; }
+    const int nu = this_layer ? ceil_div(T, 16 * LC_URG) : 0;
+    const int es = lg_pick_es(E, chunks, (this_layer ? 2 : 0) + (prev ? 1 : 0), nu);
+    if (!es) { pevit_set_error("lowrank_combo: no slab grouping for width %d", E); return -1; }
+    const int groups = E / 64 / es;
+    const int n12 = this_layer ? chunks * groups * 2 : 0, n0 = prev ? chunks * groups : 0;
     const int nu_pad = (nu + 7) & ~7, n12_pad = (n12 + 7) & ~7, n0_pad = (n0 + 7) & ~7;
     if (nu_pad + n12_pad + n0_pad == 0) return 0;
     hipLaunchKernelGGL(lowrank_combo_kernel, dim3(nu_pad + n12_pad + n0_pad), dim3(256), 0, s, dqkv, ld, qT, u32, ucols, t, partial,
-                       dbias_partial, xn_prev, ldx, u32_prev, partial_prev, nu, nu_pad, n12, n12_pad, n0, B, H, N, E);
+                       dbias_partial, xn_prev, ldx, u32_prev, partial_prev, nu, nu_pad, n12, n12_pad, n0, B, H, N, E, es);
     LAUNCH_OK("lowrank_combo_kernel");
     return 0;
 }
@@ -732,9 +752,11 @@ int pevit_launch_lowrank_grad(const bf16* xn, int ldx, const float* u32, const b
                               hipStream_t s, int xcd_order) {
     const int T = B * N;
     if (chunks != ceil_div(T, LG_ROWS)) { pevit_set_error("lowrank_grad: chunks mismatch"); return -1; }
-    if (E % (64 * LG_ES)) { pevit_set_error("lowrank_grad: width %d must be a multiple of %d", E, 64 * LG_ES); return -1; }
-    hipLaunchKernelGGL(lowrank_grad_kernel, dim3(chunks * (E / 64 / LG_ES) * 3), dim3(256), 0, s, xn, ldx, u32, dqkv, ld, t,
-                       partial, dbias_partial, B, H, N, E, xcd_order);
+    if (E % 64) { pevit_set_error("lowrank_grad: width %d must be a multiple of 64", E); return -1; }
+    const int es = lg_pick_es(E, chunks, 3, 0);
+    if (!es) { pevit_set_error("lowrank_grad: no slab grouping for width %d", E); return -1; }
+    hipLaunchKernelGGL(lowrank_grad_kernel, dim3(chunks * (E / 64 / es) * 3), dim3(256), 0, s, xn, ldx, u32, dqkv, ld, t,
+                       partial, dbias_partial, B, H, N, E, xcd_order, es);
     LAUNCH_OK("lowrank_grad_kernel");
     return 0;
 }

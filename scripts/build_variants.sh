@@ -10,7 +10,7 @@ for spec in "$@"; do
   tag=${spec%%:*}; rest=${spec#*:}; file=${rest%%:*}; defs=${rest#*:}
   /opt/rocm/bin/hipcc $FLAGS $defs -c $file -o /tmp/variant_$tag.o
   objs=""
-  for o in capi gemm norm attention lowrank misc stem_head adapter fp8 verify; do
+  for o in $(sed -n "s/^SRCS = //p" Makefile | sed "s/\.hip//g"); do
     if [ "$o.hip" == "$file" ]; then objs="$objs /tmp/variant_$tag.o"; else objs="$objs $o.o"; fi
   done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs -o ../variants/libpevit_hip_$tag.so

@@ -592,6 +592,39 @@ def test_fused_post_mlp_adapter_equals_the_separate_launches(method, arch_name, 
             assert rel_err(g1[k], g0[k]) < 2e-2, (k, rel_err(g1[k], g0[k]))
 
 
+@pytest.mark.parametrize("arch_name,B", [("tiny-256", 7), ("ViT-B/32-2L", 24), ("ViT-B/32", 13)])
+@pytest.mark.parametrize("method", ["adapter", "compacter"])
+def test_weight_gradient_products_inside_the_adapter_backward_launch_are_bit_identical(method, arch_name, B):
+    """`adapter_tn_fold` (the d W_up product of a layer and the d W_down product of the layer walked before it as extra workgroups
+    of adapter_bwd_kernel; the last one in a launch of its own) against one tn_gemm64 launch per product: the same arithmetic
+    in the same order, so every gradient -- and the loss -- has the same bits.  Ragged last chunk (B * N not a multiple of 256) and
+    an odd unit count (tiny-256: 4 slabs x 1 chunk) included."""
+    from pevit_amd.engine import HipEngine, adapter_param_spec
+    from pevit_amd.synth import ARCHS, randomize_adapters, synth_batch, synth_state_dict
+    arch, C = ARCHS[arch_name], 10
+    sd = {k: v for k, v in synth_state_dict(arch, seed=2, text_tower=False).items() if k.startswith("visual.")}
+    ad = [(n, torch.zeros(s)) for n, s, _ in adapter_param_spec(method, arch.width, arch.layers)]
+    randomize_adapters(ad, seed=3)
+    for n, v in ad:
+        if n.endswith("phm_rule"):
+            v.copy_(torch.rand(v.shape, generator=torch.Generator().manual_seed(8)) * 2 - 1)
+    sd.update(dict(ad))
+    images, labels = synth_batch(B, arch.resolution, C, seed_img=3, seed_lbl=4)
+    res = []
+    for fold in (1, 0):
+        eng = HipEngine(arch, method, C, B)
+        eng.load_state_dict(sd)
+        assert eng.tune("adapter_tn_fold", fold) == 0
+        for _ in range(2):      # twice: the d pre buffers alternate, the second pass starts on the other one
+            logits, loss = eng.forward_backward(images.cuda(), labels.cuda())
+        torch.cuda.synchronize()
+        res.append((logits.cpu().clone(), float(loss), {k: v.cpu().clone() for k, v in eng.grad_views().items()}))
+    (l1, s1, g1), (l0, s0, g0) = res
+    assert torch.equal(l1, l0) and s1 == s0
+    for k in g0:
+        assert torch.equal(g1[k], g0[k]), (k, rel_err(g1[k], g0[k]))
+
+
 @pytest.mark.parametrize("method,arch_name,B", [("kadaptation", "ViT-B/32-2L", 24), ("lora", "tiny-256", 7), ("kadaptation", "tiny-n197", 3)])
 def test_combined_lowrank_backward_equals_the_two_launches(method, arch_name, B):
     """lowrank_combo_kernel (u + dQ + d bias of a layer and the dP of the layer walked before it in one launch, the last layer's dP
