@@ -630,7 +630,12 @@ int blocks_forward(pevit_ctx* c, hipStream_t s, int B, bool cls_only, int l_lo =
         if (c->d.method == PEVIT_KADAPTATION) dbias = c->params + c->p_layer0 + c->p_layer_stride * l + 4 * (size_t)E;
         // delta-add and the attention core as ONE launch where a run of heads owns whole reference rows of the raw reshape
         // (attn_delta.hip: N <= 64; ViT-B/32), otherwise delta_add + attn_fwd
-        const bool fused_ad = site && c->fused_attn_delta && !c->f32 && !attn8 && pevit_attn_delta_hpw(B, H, N) > 0;
+        // ... unless its one-workgroup-per-CU runs leave between a quarter and three quarters of the chip empty (measured at batch
+        // 64: 128 runs for 256 CUs, the two kernels are 0.6 % of the step faster; fused_attn_delta = 2 forces the fused form)
+        const int ad_hpw = pevit_attn_delta_hpw(B, H, N);
+        const int ad_runs = ad_hpw > 0 ? (B * H + ad_hpw - 1) / ad_hpw : 0;
+        const bool ad_fill = ad_hpw > 0 && (c->fused_attn_delta > 1 || 4 * ad_runs >= 3 * pevit_num_cus() || 4 * ad_runs <= pevit_num_cus());
+        const bool fused_ad = site && c->fused_attn_delta && !c->f32 && !attn8 && ad_fill;
         if (fused_ad) {
             PROF(c, s, PEVIT_PROF_ATTN_FWD_DELTA, T, (double)T * E * (3 + 2 + 1) * 2 + (double)T * 64 * 4 + (double)B * H * N * 4,   // q, k, v in; q', v', out
                  pevit_launch_attn_fwd_delta(qkv, qkv + plane, qkv + 2 * plane, at<float>(W, v.t), at<bf16>(A, b.q16), dbias, c->ascale,
