@@ -1,0 +1,210 @@
+// LayerNorm forward / backward of ONE row by one 64-lane wavefront (the row lives in registers, E <= 1024; reductions are wave
+// shuffles; every global access is a 16-byte-per-lane coalesced segment).  Shared by the stand-alone kernels of norm.hip and by the
+// LayerNorm tail of gemm_kphase_kernel (gemm.hip: the workgroups of a row band normalise the band they have just written), so that
+// both give the same bits.
+#pragma once
+#include <type_traits>
+#include "common.h"
+
+constexpr int LN_MAXV = 4;   // float4 per lane -> E <= 1024
+
+template <typename ST>
+__device__ __forceinline__ void ln_fwd_row(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                           int row, int E, size_t xstride, bf16* __restrict__ yb, float* __restrict__ yf,
+                                           float* __restrict__ mean_out, float* __restrict__ rstd_out, unsigned char* __restrict__ y8,
+                                           int lane) {
+    constexpr int MAXV = LN_MAXV;
+    const float* xr = x + (size_t)row * xstride;
+    // Every load of the row -- x, gamma, beta -- is requested before the first reduction, and none of them sits inside a bounds
+    // branch (columns beyond E read column 0 and are masked): a value loaded inside a branch makes hipcc wait with vmcnt(0) at its
+    // first use after the join, and on gfx950 that also waits for the STORES issued so far -- the store loop below then paid one
+    // store latency per 256 columns (profiles/r03_gemm_experiments.md section 3 has the same finding for the GEMM epilogues).
+    float4 v[MAXV], gm[MAXV], bt[MAXV];
+    bool ok[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane * 4 + i * 256;
+        ok[i] = c < E;
+        const int cc = ok[i] ? c : 0;
+        v[i] = *reinterpret_cast<const float4*>(xr + cc);
+        gm[i] = *reinterpret_cast<const float4*>(gamma + cc);
+        bt[i] = *reinterpret_cast<const float4*>(beta + cc);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) s += ok[i] ? v[i].x + v[i].y + v[i].z + v[i].w : 0.f;
+    const float mean = wave_sum(s) / (float)E;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+        q += ok[i] ? a * a + b * b + cc * cc + d * d : 0.f;
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)E + 1e-5f);
+    __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0), visible to the compiler: every load is in before the first (conditional) store
+    if (lane == 0) {
+        if (mean_out) mean_out[row] = mean;
+        if (rstd_out) rstd_out[row] = rstd;
+    }
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane * 4 + i * 256;
+        if (ok[i]) {
+            const float4 g = gm[i], b = bt[i];
+            float4 o;
+            o.x = (v[i].x - mean) * rstd * g.x + b.x;
+            o.y = (v[i].y - mean) * rstd * g.y + b.y;
+            o.z = (v[i].z - mean) * rstd * g.z + b.z;
+            o.w = (v[i].w - mean) * rstd * g.w + b.w;
+            if (yb) st_store4<ST>(yb, (size_t)row * E + c, o.x, o.y, o.z, o.w);
+            if (yf) *reinterpret_cast<float4*>(yf + (size_t)row * E + c) = o;
+            if (y8) {       // e4m3 copy for the fp8 x fp8 products: 4 consecutive channels stay contiguous under fp8_kperm
+                int w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(o.x, -448.f), 448.f), fminf(fmaxf(o.y, -448.f), 448.f), 0, false);
+                w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(o.z, -448.f), 448.f), fminf(fmaxf(o.w, -448.f), 448.f), w, true);
+                *reinterpret_cast<int*>(y8 + (size_t)row * E + fp8_kperm(c)) = w;
+            }
+        }
+    }
+}
+
+// R rows of one wave at once (the LayerNorm tail of gemm.hip: a workgroup has 8 waves for ~27 rows, and one row after the other was
+// four dependent memory round trips): every row's loads are requested before the first reduction; per row the arithmetic and its
+// order are those of ln_fwd_row.  rows[r] < 0: no such row (a valid row is read instead and nothing is stored).
+template <typename ST, int R>
+__device__ __forceinline__ void ln_fwd_rows(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                            const int (&rows)[R], int E, size_t xstride, bf16* __restrict__ yb,
+                                            float* __restrict__ mean_out, float* __restrict__ rstd_out, unsigned char* __restrict__ y8,
+                                            int lane) {
+    constexpr int MAXV = LN_MAXV;
+    float4 v[R][MAXV], gm[MAXV], bt[MAXV];
+    bool ok[MAXV];
+    int first = 0;
+#pragma unroll
+    for (int r = R - 1; r >= 0; --r) if (rows[r] >= 0) first = rows[r];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane * 4 + i * 256;
+        ok[i] = c < E;
+        const int cc = ok[i] ? c : 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[r][i] = *reinterpret_cast<const float4*>(x + (size_t)(rows[r] >= 0 ? rows[r] : first) * xstride + cc);
+        gm[i] = *reinterpret_cast<const float4*>(gamma + cc);
+        bt[i] = *reinterpret_cast<const float4*>(beta + cc);
+    }
+    float mean[R], rstd[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) s += ok[i] ? v[r][i].x + v[r][i].y + v[r][i].z + v[r][i].w : 0.f;
+        mean[r] = wave_sum(s) / (float)E;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const float a = v[r][i].x - mean[r], b = v[r][i].y - mean[r], cc = v[r][i].z - mean[r], d = v[r][i].w - mean[r];
+            q += ok[i] ? a * a + b * b + cc * cc + d * d : 0.f;
+        }
+        rstd[r] = rsqrtf(wave_sum(q) / (float)E + 1e-5f);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0), visible to the compiler: every load is in before the first (conditional) store
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int row = rows[r];
+        if (row < 0) continue;
+        if (lane == 0) {
+            if (mean_out) mean_out[row] = mean[r];
+            if (rstd_out) rstd_out[row] = rstd[r];
+        }
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = lane * 4 + i * 256;
+            if (ok[i]) {
+                const float4 g = gm[i], b = bt[i];
+                float4 o;
+                o.x = (v[r][i].x - mean[r]) * rstd[r] * g.x + b.x;
+                o.y = (v[r][i].y - mean[r]) * rstd[r] * g.y + b.y;
+                o.z = (v[r][i].z - mean[r]) * rstd[r] * g.z + b.z;
+                o.w = (v[r][i].w - mean[r]) * rstd[r] * g.w + b.w;
+                if (yb) st_store4<ST>(yb, (size_t)row * E + c, o.x, o.y, o.z, o.w);
+                if (y8) {
+                    int w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(o.x, -448.f), 448.f), fminf(fmaxf(o.y, -448.f), 448.f), 0, false);
+                    w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(o.z, -448.f), 448.f), fminf(fmaxf(o.w, -448.f), 448.f), w, true);
+                    *reinterpret_cast<int*>(y8 + (size_t)row * E + fp8_kperm(c)) = w;
+                }
+            }
+        }
+    }
+}
+
+// dx = dres + rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat))
+// DYT: storage of the upstream gradient dy -- f32, or the activation storage type ST when it comes straight out of a
+// dX GEMM (bf16 in production: one rounding, half the bytes on both sides of this HBM-bound kernel)
+template <typename ST, typename DYT>
+__device__ __forceinline__ void ln_bwd_row(const void* __restrict__ dy_, const float* __restrict__ x, const float* __restrict__ mean_in,
+                                           const float* __restrict__ rstd_in, const float* __restrict__ gamma, const float* dres,
+                                           float* dx, bf16* __restrict__ dx_bf16, int row, int E, size_t xstride,
+                                           const float* __restrict__ bscale, int lane) {
+    constexpr int MAXV = LN_MAXV;
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    const size_t base = (size_t)row * E;          // dy rows are always compact
+    const size_t xb = (size_t)row * xstride;      // x, dres, dx, dx_bf16 share the row stride
+    // All loads -- dy, x, gamma, the residual gradient, the fp8 channel scales -- are requested up front and none sits inside a
+    // bounds branch (columns beyond E read column 0 and are masked; a missing residual gradient reads x and the value is dropped):
+    // with the loads inside `if (c < E)` hipcc waited for each 256-column group before requesting the next (four memory round
+    // trips per row), and the residual gradient, loaded between the stores, cost a fifth plus one store latency per group.
+    float4 gd[MAXV], xh[MAXV], rs[MAXV], sc[MAXV], xv[MAXV], gv[MAXV];
+    typename std::conditional<sizeof(DYT) == 2, bf16x4, float4>::type dv[MAXV];
+    bool ok[MAXV];
+    const float* rsrc = dres ? dres : x;
+    const bool has_res = dres != nullptr;
+    const bool scaled = dx_bf16 && bscale;
+    const float* ssrc = scaled ? bscale : gamma;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane * 4 + i * 256;
+        ok[i] = c < E;
+        const int cc = ok[i] ? c : 0;
+        if constexpr (sizeof(DYT) == 2) dv[i] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(dy_) + base + cc);
+        else dv[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(dy_) + base + cc);
+        xv[i] = *reinterpret_cast<const float4*>(x + xb + cc);
+        gv[i] = *reinterpret_cast<const float4*>(gamma + cc);
+        rs[i] = *reinterpret_cast<const float4*>(rsrc + xb + cc);
+        sc[i] = *reinterpret_cast<const float4*>(ssrc + cc);
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        float4 d;
+        if constexpr (sizeof(DYT) == 2) d = make_float4(bf2f(dv[i][0]), bf2f(dv[i][1]), bf2f(dv[i][2]), bf2f(dv[i][3]));
+        else d = dv[i];
+        const float4 g = gv[i];
+        gd[i] = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
+        xh[i] = make_float4((xv[i].x - mean) * rstd, (xv[i].y - mean) * rstd, (xv[i].z - mean) * rstd, (xv[i].w - mean) * rstd);
+        s1 += ok[i] ? gd[i].x + gd[i].y + gd[i].z + gd[i].w : 0.f;
+        s2 += ok[i] ? gd[i].x * xh[i].x + gd[i].y * xh[i].y + gd[i].z * xh[i].z + gd[i].w * xh[i].w : 0.f;
+        rs[i] = has_res ? rs[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        sc[i] = scaled ? sc[i] : make_float4(1.f, 1.f, 1.f, 1.f);
+    }
+    const float m1 = wave_sum(s1) / (float)E;
+    const float m2 = wave_sum(s2) / (float)E;
+    __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0), visible to the compiler: every load is in before the first (conditional) store
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane * 4 + i * 256;
+        if (ok[i]) {
+            float4 o;
+            o.x = rstd * (gd[i].x - m1 - xh[i].x * m2);
+            o.y = rstd * (gd[i].y - m1 - xh[i].y * m2);
+            o.z = rstd * (gd[i].z - m1 - xh[i].z * m2);
+            o.w = rstd * (gd[i].w - m1 - xh[i].w * m2);
+            o.x += rs[i].x; o.y += rs[i].y; o.z += rs[i].z; o.w += rs[i].w;       // zeros without a residual gradient
+            *reinterpret_cast<float4*>(dx + xb + c) = o;
+            if (dx_bf16) {
+                // fp8 weights: the consuming GEMM contracts over these columns; their power-of-two channel
+                // scales are folded into its bf16 operand here (exact: ones otherwise), the f32 stream stays unscaled
+                o.x *= sc[i].x; o.y *= sc[i].y; o.z *= sc[i].z; o.w *= sc[i].w;
+                st_store4<ST>(dx_bf16, xb + c, o.x, o.y, o.z, o.w);
+            }
+        }
+    }
+}
