@@ -396,6 +396,10 @@ def main():
                                "launches_per_step": cnt / prof_steps, "avg_us": ms_k * 1e3 / cnt,
                                "share_of_gemm_time": ms_k / max(gemm_ms, 1e-9), "tflops": fl_k / sec / 1e12,
                                "frac": fl_k / sec / 1e12 / peak, "algorithmic_TBps": by_k / sec / 1e12})
+        if os.environ.get("PEVIT_BENCH_ALL_SHAPES"):      # measurement: every GEMM shape of the step on stderr
+            for (epi, M, N, K), (cnt, ms_k, fl_k, by_k) in sorted(gemm_by_shape.items(), key=lambda kv: -kv[1][1]):
+                print(f"[shape] epi={EPI_NAMES.get(epi, epi)} M={M} N={N} K={K} n/step={cnt / prof_steps:.1f} avg_us={ms_k * 1e3 / cnt:.1f}",
+                      file=sys.stderr)
         headline = (args.arch, args.method, args.batch, args.weights) == ("ViT-B/32", "kadaptation", 128, "bf16")
         metric = "images/sec fine-tune, CLIP ViT-B/32 + KAdaptation, bs=128, 1/2/4/8 GPU" if headline else \
             f"images/sec fine-tune, CLIP {args.arch} + {args.method}, bs={args.batch}/GPU, {args.weights} weights"
