@@ -92,13 +92,14 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_delta_kernel(bf16* __restric
 
     // ---- every global request of the first phase up front (clamped addresses, no load inside a bounds branch) ----
     constexpr int PIECES = (HPW * 64 * 8 + NT - 1) / NT;  // 16-byte pieces per thread and tensor (N <= 64)
+    // Request order = the order of use: q, v and the delta operands first, k LAST -- the delta phase does not touch k, whose 38 KB
+    // (of this workgroup's 219 KB) may still be on their way while q and v are staged and the delta runs; k goes to LDS behind it.
     bf16x8 rq[PIECES], rk[PIECES], rv[PIECES];
     const int npc = rows * 8;
 #pragma unroll
     for (int it = 0; it < PIECES; ++it) {
         const int idx = min(tid + NT * it, npc - 1);
         rq[it] = load_bf16x8(q + goff + (size_t)idx * 8);
-        rk[it] = load_bf16x8(k + goff + (size_t)idx * 8);
         rv[it] = load_bf16x8(v + goff + (size_t)idx * 8);
     }
     // delta operands.  The first NW/2 waves work on q, the others on v; a wave owns the 32-column steps st = wq, wq + NW/2, ...
@@ -126,6 +127,20 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_delta_kernel(bf16* __restric
 #pragma unroll
         for (int h = 0; h < 2; ++h) qa[i][h] = load_bf16x8(q16 + (size_t)(e_t0 + 4 * h) * 64 + which * 32 + 8 * g);
     }
+    // the bias of this lane's 8 columns of every step: with the other requests (behind the staging it was one more L2 round trip
+    // in front of the delta phase)
+    float4 ba[PER][2];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int st = min(wq + HW * i, steps - 1);
+        ba[i][0] = *reinterpret_cast<const float4*>(bsrc + st * 32 + 8 * g);
+        ba[i][1] = *reinterpret_cast<const float4*>(bsrc + st * 32 + 8 * g + 4);
+    }
+#pragma unroll
+    for (int it = 0; it < PIECES; ++it) {
+        const int idx = min(tid + NT * it, npc - 1);
+        rk[it] = load_bf16x8(k + goff + (size_t)idx * 8);
+    }
     if (tl) { __builtin_amdgcn_s_waitcnt(0x0F70); stamp(1); }       // every request has landed
 #pragma unroll
     for (int it = 0; it < PIECES; ++it) {
@@ -134,7 +149,6 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_delta_kernel(bf16* __restric
             const int y = idx >> 3, c = idx & 7;
             const bool live = idx < npc;
             *reinterpret_cast<bf16x8*>(Qs + y * LDR + 8 * c) = live ? rq[it] : zero_bf16x8();
-            *reinterpret_cast<bf16x8*>(Ks + y * LDR + 8 * c) = live ? rk[it] : zero_bf16x8();
             *reinterpret_cast<bf16x8*>(Vs + y * LDR + 8 * c) = live ? rv[it] : zero_bf16x8();
         }
     }
@@ -144,14 +158,6 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_delta_kernel(bf16* __restric
         *reinterpret_cast<bf16x8*>(Qs + y * LDR + 8 * c) = zero_bf16x8();
         *reinterpret_cast<bf16x8*>(Ks + y * LDR + 8 * c) = zero_bf16x8();
         *reinterpret_cast<bf16x8*>(Vs + y * LDR + 8 * c) = zero_bf16x8();
-    }
-    // the bias of this lane's 8 columns of every step (L2 / L1 hits; the q / k / v registers are free by now)
-    float4 ba[PER][2];
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int st = min(wq + HW * i, steps - 1);
-        ba[i][0] = *reinterpret_cast<const float4*>(bsrc + st * 32 + 8 * g);
-        ba[i][1] = *reinterpret_cast<const float4*>(bsrc + st * 32 + 8 * g + 4);
     }
     __syncthreads();
     stamp(2);
@@ -197,6 +203,15 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_delta_kernel(bf16* __restric
         }
     }
     stamp(3);
+    // ---- k to LDS (requested first thing, used by the attention only) ----
+#pragma unroll
+    for (int it = 0; it < PIECES; ++it) {
+        const int idx = tid + NT * it;
+        if (idx < prow * 8) {
+            const int y = idx >> 3, c = idx & 7;
+            *reinterpret_cast<bf16x8*>(Ks + y * LDR + 8 * c) = idx < npc ? rk[it] : zero_bf16x8();
+        }
+    }
     __syncthreads();
     stamp(4);
 
