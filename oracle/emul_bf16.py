@@ -23,7 +23,7 @@ Storage points reproduced (engine buffer -> here):
   backward  bf16 copy of the gradient stream (dyb)       every LinearE rounds its upstream gradient
             dh = bf16(acc * gelu'(h))                    QuickGeluE.backward
             dxn2, dO, dxn1 bf16 (dX GEMM outputs)        LinearE(round_dx) / QKVAug.backward
-            dS bf16, P bf16 for dV, delta from bf16 O    AttnCore.backward
+            dS bf16, P bf16 for dV, delta = sum P dP (N <= 64) / from bf16 O    AttnCore.backward
             dq, dk, dv bf16                              AttnCore.backward
             u = dDelta Q (Q bf16) f32, bf16 copy         DeltaFromT.backward / QKVAug.backward
             dP = xn^T bf16(u), dQ = dDelta^T bf16(t)     QKVAug / DeltaFromT backward
@@ -176,7 +176,9 @@ class AttnCore(torch.autograd.Function):
         q, k, v, o, lse = ctx.saved_tensors
         p = torch.exp(torch.bmm(q, k.transpose(1, 2)) - lse)      # recomputed, f32
         dp = torch.bmm(go, v.transpose(1, 2))
-        delta = (go * o).sum(-1, keepdim=True)                     # from the stored (bf16) output
+        # N <= 64 (attn_bwd_kernel<2, true, .>): delta = sum_keys P dP from the f32 values of pass A; the larger shapes keep
+        # delta = sum_d dO O from the stored (bf16) output
+        delta = (p * dp).sum(-1, keepdim=True) if q.shape[1] <= 64 else (go * o).sum(-1, keepdim=True)
         ds = bf(p * (dp - delta), "ds")
         dq = bf(torch.bmm(ds, k), "dqkv")
         dk = bf(torch.bmm(ds.transpose(1, 2), q), "dqkv")

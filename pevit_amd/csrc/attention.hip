@@ -250,12 +250,14 @@ __global__ __launch_bounds__(64 * NW, (ALL4 ? ATT_BWD_MINW : 1)) void attn_bwd_k
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, g = lane >> 4, c16 = lane & 15;
 
     if constexpr (ALL4) {
-        // One round trip to HBM: all five tensors of both loop iterations are requested before the first LDS write;
-        // delta[y] = sum_d dO[y][d] * O[y][d] (== sum_keys P*dP) comes out of the same registers.  Padded rows are zero.
+        // One round trip to HBM: the four tensors of both loop iterations are requested before the first LDS write.  Padded rows
+        // are zero.  delta[y] = sum_keys P[y][key] dP[y][key] (== sum_d dO[y][d] O[y][d]) comes out of pass A, where a lane holds
+        // P and dP of its query in f32 anyway: the attention output is not read at all (9.8 of this kernel's 79 MB at ViT-B/32,
+        // batch 128), and delta no longer carries the bf16 rounding of the stored output.
         constexpr int IT = NPAD * 8 / NT;
         // (no load inside a bounds branch: rows beyond N read row N - 1 and are zeroed by a select afterwards -- with
         // `v = 0; if (y < N) v = load` hipcc drains behind every group of requests: one round trip per `it`, and one more for lse)
-        bf16x8 vq[IT], vk[IT], vv[IT], vd[IT], vo[IT];
+        bf16x8 vq[IT], vk[IT], vv[IT], vd[IT];
         float vl[IT];
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
@@ -265,25 +267,18 @@ __global__ __launch_bounds__(64 * NW, (ALL4 ? ATT_BWD_MINW : 1)) void attn_bwd_k
             vk[it] = load_bf16x8(kh + (size_t)yc * 64 + 8 * c);
             vv[it] = load_bf16x8(vh + (size_t)yc * 64 + 8 * c);
             vd[it] = load_bf16x8(doh + (size_t)yc * lddo + 8 * c);
-            vo[it] = load_bf16x8(oh + (size_t)yc * ldo + 8 * c);
             vl[it] = lse[(size_t)bh * N + yc];
         }
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
             const int idx = threadIdx.x + NT * it, y = idx >> 3, c = idx & 7;
-            if (y >= N) { vq[it] = zero_bf16x8(); vk[it] = zero_bf16x8(); vv[it] = zero_bf16x8(); vd[it] = zero_bf16x8(); vo[it] = zero_bf16x8(); vl[it] = 0.f; }
+            if (y >= N) { vq[it] = zero_bf16x8(); vk[it] = zero_bf16x8(); vv[it] = zero_bf16x8(); vd[it] = zero_bf16x8(); vl[it] = 0.f; }
             *reinterpret_cast<bf16x8*>(Qs + y * LDR + 8 * c) = vq[it];
             *reinterpret_cast<bf16x8*>(Ks + y * LDR + 8 * c) = vk[it];
             *reinterpret_cast<bf16x8*>(Vs + y * LDR + 8 * c) = vv[it];
             *reinterpret_cast<bf16x8*>(dOs + y * LDR + 8 * c) = vd[it];
-            float acc = 0.f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) acc += bf2f(vd[it][i]) * bf2f(vo[it][i]);
-            acc += __shfl_xor(acc, 1, 64);
-            acc += __shfl_xor(acc, 2, 64);
-            acc += __shfl_xor(acc, 4, 64);
             if (c == 0) {
-                del_s[y] = acc;
+                del_s[y] = 0.f;                 // rows < N: written by pass A; the pad rows stay 0 (pass B multiplies them by p = 0)
                 lse_s[y] = vl[it];
             }
         }
@@ -332,8 +327,49 @@ __global__ __launch_bounds__(64 * NW, (ALL4 ? ATT_BWD_MINW : 1)) void attn_bwd_k
             bf16x8 x1[2], x2[2];
             x1[0] = rowfrag(Qr, qst, xs, 0, g);  x1[1] = rowfrag(Qr, qst, xs, 1, g);
             x2[0] = rowfrag(Dr, dst_, xs, 0, g); x2[1] = rowfrag(Dr, dst_, xs, 1, g);
-            const float lse_x = lse_s[xs], del_x = del_s[xs];
+            const float lse_x = lse_s[xs];
             f32x4 o[4];
+            if constexpr (ALL4) {
+                // all keys of this lane's query first (P and dP in f32), delta = sum P dP over the lane's keys and the four lane
+                // groups, then dS and the dQ products
+                f32x4 zp[KT32][2], zd[KT32][2];
+                float dsum = 0.f;
+#pragma unroll
+                for (int s = 0; s < KT32; ++s)
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        const int yr = 32 * s + 16 * half + c16;       // padded rows of the LDS tiles are zero
+                        f32x4 z1 = {0.f, 0.f, 0.f, 0.f}, z2 = {0.f, 0.f, 0.f, 0.f};
+                        z1 = mfma16(rowfrag(Ks, LDR, yr, 0, g), x1[0], z1);
+                        z1 = mfma16(rowfrag(Ks, LDR, yr, 1, g), x1[1], z1);
+                        z2 = mfma16(rowfrag(Vs, LDR, yr, 0, g), x2[0], z2);
+                        z2 = mfma16(rowfrag(Vs, LDR, yr, 1, g), x2[1], z2);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int key = 32 * s + 16 * half + 4 * g + r;
+                            const float p = key < N ? __expf(z1[r] - lse_x) : 0.f;
+                            z1[r] = p;
+                            dsum += p * z2[r];
+                        }
+                        zp[s][half] = z1; zd[s][half] = z2;
+                    }
+                dsum += __shfl_xor(dsum, 16, 64);
+                dsum += __shfl_xor(dsum, 32, 64);
+                if (g == 0 && xq < N) del_s[xq] = dsum;            // pass B reads it behind the barrier below
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < KT32; ++s) {
+                    bf16x8 dsb;
+#pragma unroll
+                    for (int half = 0; half < 2; ++half)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) dsb[half * 4 + r] = f2bf(zp[s][half][r] * (zd[s][half][r] - dsum));
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16(tfrag_tr(Ks, LDR, dt, s, lane), dsb, o[dt]);
+                }
+            } else {
+            const float del_x = del_s[xs];
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll(KT32 <= 2 ? KT32 : 1)
@@ -357,9 +393,11 @@ __global__ __launch_bounds__(64 * NW, (ALL4 ? ATT_BWD_MINW : 1)) void attn_bwd_k
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16(tfrag_tr(Ks, LDR, dt, s, lane), dsb, o[dt]);
             }
+            }
             if (xq < N) store16(dqkv + ((size_t)b * N + xq) * ld + h * 64 + 16 * g, o, 1.0f);
         }
     }
+    if constexpr (ALL4) __syncthreads();           // delta of every query is in LDS before pass B reads it
     if constexpr (!ALL4) {
         __syncthreads();                       // every wave is done with K, V
         stage_rows(Qs, LDR, qh, 64, N, NPAD);
