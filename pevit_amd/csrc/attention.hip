@@ -397,7 +397,13 @@ __global__ __launch_bounds__(64 * NW, (ALL4 ? ATT_BWD_MINW : 1)) void attn_bwd_k
             if (xq < N) store16(dqkv + ((size_t)b * N + xq) * ld + h * 64 + 16 * g, o, 1.0f);
         }
     }
-    if constexpr (ALL4) __syncthreads();           // delta of every query is in LDS before pass B reads it
+    if constexpr (ALL4) {
+        // delta of every query is in LDS before pass B reads it.  An LDS-only barrier: __syncthreads() would also wait (vmcnt(0))
+        // for the dQ stores of pass A -- one store round trip per workgroup (tests/test_isa_hygiene.py)
+        __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
     if constexpr (!ALL4) {
         __syncthreads();                       // every wave is done with K, V
         stage_rows(Qs, LDR, qh, 64, N, NPAD);

@@ -63,7 +63,10 @@ CASES = [
     # the next slab's X panel is requested between two slabs' stores, and the one explicit vmcnt(0) that brings it in sits there too
     ("lowrank", "lowrank_grad_kernel", 0, 1, 8),
     ("attention", "attn_fwd_kernelILi2ELi4E", 0, 0, 0),
-    ("attention", "attn_bwd_kernelILi2ELb1ELi4E", 0, 0, 0),
+    # one vmcnt(0): hipcc places it behind the LDS barrier between pass A (dQ stores) and pass B (which reads the delta pass A wrote to
+    # LDS), whatever form the barrier takes (s_waitcnt lgkmcnt(0) + s_barrier, fences, inline asm); with three workgroups per CU the
+    # kernel's in-step time did not move (18.6 -> 18.5 us with 12 % fewer bytes)
+    ("attention", "attn_bwd_kernelILi2ELb1ELi4E", 0, 1, 0),
 ]
 
 
