@@ -227,7 +227,7 @@ __global__ __launch_bounds__(64 * NW, (ALL4 ? ATT_BWD_MINW : 1)) void attn_bwd_k
                                                           const bf16* __restrict__ v, const bf16* __restrict__ out,
                                                           int ldo, const bf16* __restrict__ dout, int lddo,
                                                           const float* __restrict__ lse, bf16* __restrict__ dqkv, int ld,
-                                                          int H, int N) {
+                                                          int H, int N, int dout_cls) {
     constexpr int NPAD = 32 * KT32;
     constexpr int LDR = ATT_LDR;
     constexpr int NT = 64 * NW;
@@ -266,13 +266,14 @@ __global__ __launch_bounds__(64 * NW, (ALL4 ? ATT_BWD_MINW : 1)) void attn_bwd_k
             vq[it] = load_bf16x8(qh + (size_t)yc * 64 + 8 * c);
             vk[it] = load_bf16x8(kh + (size_t)yc * 64 + 8 * c);
             vv[it] = load_bf16x8(vh + (size_t)yc * 64 + 8 * c);
-            vd[it] = load_bf16x8(doh + (size_t)yc * lddo + 8 * c);
+            vd[it] = load_bf16x8(doh + (size_t)(dout_cls ? 0 : yc) * lddo + 8 * c);     // dout_cls: only the class-token row carries a gradient
             vl[it] = lse[(size_t)bh * N + yc];
         }
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
             const int idx = threadIdx.x + NT * it, y = idx >> 3, c = idx & 7;
             if (y >= N) { vq[it] = zero_bf16x8(); vk[it] = zero_bf16x8(); vv[it] = zero_bf16x8(); vd[it] = zero_bf16x8(); vl[it] = 0.f; }
+            if (dout_cls && y != 0) vd[it] = zero_bf16x8();
             *reinterpret_cast<bf16x8*>(Qs + y * LDR + 8 * c) = vq[it];
             *reinterpret_cast<bf16x8*>(Ks + y * LDR + 8 * c) = vk[it];
             *reinterpret_cast<bf16x8*>(Vs + y * LDR + 8 * c) = vv[it];
@@ -480,7 +481,7 @@ int launch_fwd(const bf16* q, const bf16* k, const bf16* v, bf16* out, int ldo, 
 
 template <int KT32, bool ALL4, int NW>
 int launch_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* out, int ldo, const bf16* dout, int lddo,
-               const float* lse, bf16* dqkv, int ld, int B, int H, int N, hipStream_t s) {
+               const float* lse, bf16* dqkv, int ld, int B, int H, int N, hipStream_t s, int dout_cls = 0) {
     constexpr int NPAD = 32 * KT32;
     const int bytes = 2 * NPAD * 4 + (ALL4 ? 4 : 2) * NPAD * ATT_LDR * 2;
     static bool attr = false;
@@ -492,7 +493,7 @@ int launch_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* out, int
         attr = true;
     }
     hipLaunchKernelGGL((attn_bwd_kernel<KT32, ALL4, NW>), dim3(B * H), dim3(64 * NW), bytes, s, q, k, v, out, ldo, dout, lddo, lse,
-                       dqkv, ld, H, N);
+                       dqkv, ld, H, N, ALL4 ? dout_cls : 0);
     LAUNCH_OK("attn_bwd_kernel");
     return 0;
 }
@@ -524,11 +525,12 @@ int pevit_launch_attn_fwd(const bf16* q, const bf16* k, const bf16* v, bf16* out
 }
 
 int pevit_launch_attn_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* out, int ldo, const bf16* dout,
-                          int lddo, const float* lse, bf16* dqkv, int ld, int B, int H, int N, hipStream_t s) {
+                          int lddo, const float* lse, bf16* dqkv, int ld, int B, int H, int N, hipStream_t s, int dout_cls_only) {
     if (N < 1 || N > 288) { pevit_set_error("attn_bwd: tokens per image N=%d outside [1,288]", N); return -1; }
     if ((ldo % 8) || (lddo % 8) || (ld % 8)) { pevit_set_error("attn_bwd: leading dims must be multiples of 8"); return -1; }
     // N <= 64: all four operands LDS-resident; above, the loop side of each pass
-    if (N <= 64) return launch_bwd<2, true, 4>(q, k, v, out, ldo, dout, lddo, lse, dqkv, ld, B, H, N, s);
+    if (N <= 64) return launch_bwd<2, true, 4>(q, k, v, out, ldo, dout, lddo, lse, dqkv, ld, B, H, N, s, dout_cls_only);
+    if (dout_cls_only) { pevit_set_error("attn_bwd: dout_cls_only needs N <= 64 (N = %d)", N); return -1; }
     if (N <= 224) return launch_bwd<7, false, ATT_NW_MID>(q, k, v, out, ldo, dout, lddo, lse, dqkv, ld, B, H, N, s);   // 74 KB: two workgroups per CU
     return launch_bwd<9, false, ATT_NW_BIG>(q, k, v, out, ldo, dout, lddo, lse, dqkv, ld, B, H, N, s);           // 94 KB: one per CU
 }

@@ -878,7 +878,7 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0, bool cls_
         else
             PROF(c, s, PEVIT_PROF_ATTN_BWD, T, (double)T * E * 8 * 2 + (double)B * H * N * 4,     // q, k, v, out, dout in; dq, dk, dv out
                  pevit_launch_attn_bwd(qkv, qkv + plane, qkv + 2 * plane, at<bf16>(W, v.attn_out), E, at<bf16>(W, c->w_dO), E,
-                                       at<float>(W, v.lse), dqkv, c->NQ, B, H, N, s));
+                                       at<float>(W, v.lse), dqkv, c->NQ, B, H, N, s, (cls && N <= 64) ? 1 : 0));
         if (site && combo) {
             // u, dQ_q, dQ_v, d bias of this layer and the dP of the layer before it in ONE launch (lowrank.hip lowrank_combo_kernel)
             float* u_cur = at<float>(W, u_par ? c->w_u32b : c->w_u32);
@@ -924,7 +924,8 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0, bool cls_
             PROF(c, s, PEVIT_PROF_LN_BWD, T, (double)T * E * ((c->dx_stored ? c->es : 4) + 4 + 4 + 4 + c->es),
                  pevit_launch_ln_bwd(dxn, at<float>(W, v.x_in), at<float>(W, v.mean1), at<float>(W, v.rstd1),
                                      at<float>(A, b.ln1w), dxb, dxa, dyb, T, E, s, 0,
-                                     (c->fp8 && l > 0) ? at<float>(A, c->blk[l - 1].spr) : nullptr, c->f32, c->dx_stored));
+                                     (c->fp8 && l > 0) ? at<float>(A, c->blk[l - 1].spr) : nullptr, c->f32, c->dx_stored,
+                                     cls ? N : 0));        // last block, class-token pruning: dxb carries a gradient on the class rows only
         }
     }
     if (side_pending) HIP_OK(hipStreamWaitEvent(s, c->ev_join, 0));
@@ -1162,8 +1163,9 @@ extern "C" int pevit_visual_backward_part(pevit_ctx* c, void* stream, const floa
         // only those rows of dxa / dyb are ever read; the full-size buffers the last block's attention and
         // LN1 backward consume (dO, dxb) are zeroed instead.
         if (cls) {
-            HIP_OK(hipMemsetAsync(W + c->w_dxb, 0, (size_t)T * E * 4, s));
-            HIP_OK(hipMemsetAsync(W + c->w_dO, 0, (size_t)T * E * c->es, s));
+            // ... or not read at all: LayerNorm backward takes the residual gradient on the class-token rows only (res_period), and
+            // the attention backward for N <= 64 reads dO on token 0 only (dout_cls_only) -- no fill of dxb (19.7 MB) / dO (9.8 MB)
+            if (c->f32 || N > 64) HIP_OK(hipMemsetAsync(W + c->w_dO, 0, (size_t)T * E * c->es, s));
         } else {
             HIP_OK(hipMemsetAsync(W + c->w_dxa, 0, (size_t)T * E * 4, s));
             HIP_OK(hipMemsetAsync(W + c->w_dyb, 0, (size_t)T * E * c->es, s));

@@ -87,7 +87,8 @@ int pevit_launch_ln_fwd(const float* x, const float* gamma, const float* beta, i
 // storage type -- bf16 in production -- when it is the output of a dX GEMM
 int pevit_launch_ln_bwd(const void* dy, const float* x, const float* mean, const float* rstd,
                         const float* gamma, const float* dres, float* dx_out, bf16* dx_bf16, int rows, int E,
-                        hipStream_t s, size_t xstride = 0, const float* bf16_colscale = nullptr, int f32 = 0, int dy_stored = 0);
+                        hipStream_t s, size_t xstride = 0, const float* bf16_colscale = nullptr, int f32 = 0, int dy_stored = 0,
+                        int res_period = 0);      // res_period > 0: dres is read on rows that are multiples of it only (zero elsewhere)
 
 // ---- attention.hip ---------------------------------------------------------------
 // q,k,v: (B*H, N, 64) bf16 (q pre-scaled by 1/8, deltas already added); out: rows (b*N+n), cols h*64+d
@@ -96,7 +97,7 @@ int pevit_launch_attn_fwd(const bf16* q, const bf16* k, const bf16* v, bf16* out
 // dqkv: row layout [T][ld]: cols [0,E) dq, [E,2E) dk, [2E,3E) dv
 int pevit_launch_attn_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* out, int ldo,
                           const bf16* dout, int lddo, const float* lse, bf16* dqkv, int ld,
-                          int B, int H, int N, hipStream_t s);
+                          int B, int H, int N, hipStream_t s, int dout_cls_only = 0);   // dout_cls_only (N <= 64): dout is zero except on token 0 of every image; the other rows are not read
 
 // ---- attn_delta.hip (attention-site adapters fused with the attention core, N <= 64) --------------
 // heads per workgroup of the fused forms for this geometry, or 0 when there is none (the two-kernel path is used)

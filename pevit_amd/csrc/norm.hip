@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                                                      const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                      const float* __restrict__ gamma, const float* dres,
                                                      float* dx, bf16* __restrict__ dx_bf16, int rows, int E, size_t xstride,
-                                                     const float* __restrict__ bscale) {
+                                                     const float* __restrict__ bscale, int res_period) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -95,8 +95,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
     float4 gd[MAXV], xh[MAXV], rs[MAXV], sc[MAXV], xv[MAXV], gv[MAXV];
     typename std::conditional<sizeof(DYT) == 2, bf16x4, float4>::type dv[MAXV];
     bool ok[MAXV];
+    // res_period > 0: the residual gradient is zero except on rows that are multiples of res_period (the class-token rows of the
+    // last block, whose upstream gradient exists on those rows only): the other rows read nothing of it (row 0 stands in, dropped)
     const float* rsrc = dres ? dres : x;
-    const bool has_res = dres != nullptr;
+    const bool has_res = dres != nullptr && (res_period <= 0 || row % res_period == 0);
+    const size_t rb = has_res ? xb : 0;
     const bool scaled = dx_bf16 && bscale;
     const float* ssrc = scaled ? bscale : gamma;
 #pragma unroll
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         else dv[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(dy_) + base + cc);
         xv[i] = *reinterpret_cast<const float4*>(x + xb + cc);
         gv[i] = *reinterpret_cast<const float4*>(gamma + cc);
-        rs[i] = *reinterpret_cast<const float4*>(rsrc + xb + cc);
+        rs[i] = *reinterpret_cast<const float4*>(rsrc + rb + cc);
         sc[i] = *reinterpret_cast<const float4*>(ssrc + cc);
     }
     float s1 = 0.f, s2 = 0.f;
@@ -167,17 +170,17 @@ int pevit_launch_ln_fwd(const float* x, const float* gamma, const float* beta, i
 
 int pevit_launch_ln_bwd(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                         const float* dres, float* dx_out, bf16* dx_bf16, int rows, int E, hipStream_t s,
-                        size_t xstride, const float* bf16_colscale, int f32, int dy_stored) {
+                        size_t xstride, const float* bf16_colscale, int f32, int dy_stored, int res_period) {
     if (xstride == 0) xstride = (size_t)E;
     if (E % 4 != 0 || E > 256 * MAXV) { pevit_set_error("ln_bwd: unsupported width %d", E); return -1; }
     if (rows <= 0) return 0;
     const dim3 grid(ceil_div(rows, 4));
     if (f32) hipLaunchKernelGGL((ln_bwd_kernel<float, float>), grid, dim3(256), 0, s, dy, x, mean, rstd, gamma, dres,
-                                dx_out, dx_bf16, rows, E, xstride, bf16_colscale);
+                                dx_out, dx_bf16, rows, E, xstride, bf16_colscale, res_period);
     else if (dy_stored) hipLaunchKernelGGL((ln_bwd_kernel<bf16, bf16>), grid, dim3(256), 0, s, dy, x, mean, rstd, gamma, dres,
-                                           dx_out, dx_bf16, rows, E, xstride, bf16_colscale);
+                                           dx_out, dx_bf16, rows, E, xstride, bf16_colscale, res_period);
     else hipLaunchKernelGGL((ln_bwd_kernel<bf16, float>), grid, dim3(256), 0, s, dy, x, mean, rstd, gamma, dres,
-                            dx_out, dx_bf16, rows, E, xstride, bf16_colscale);
+                            dx_out, dx_bf16, rows, E, xstride, bf16_colscale, res_period);
     LAUNCH_OK("ln_bwd_kernel");
     return 0;
 }
