@@ -59,6 +59,19 @@ def max_rel(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
+def sign_projections(v, index, k=32):
+    """The k seeded +-1 projections of tests/golden/make_golden.py:sign_projections (same generator, same order)."""
+    g = torch.Generator(device="cpu"); g.manual_seed(100003 + index)
+    s = torch.randint(0, 2, (k, v.numel()), generator=g, dtype=torch.int8).double() * 2 - 1
+    return s @ v.double().flatten()
+
+
+def proj_rel_err(v, index, ref_proj, ref_norm):
+    """Estimate of |v - ref| / |ref| from the recorded projections of ref: E[(<s,v> - <s,ref>)^2] = |v - ref|^2."""
+    d = sign_projections(v, index, ref_proj.numel()) - ref_proj.double()
+    return float(torch.sqrt((d * d).mean()) / (float(ref_norm) + 1e-30))
+
+
 @pytest.fixture(scope="session")
 def gpu_required():
     if not has_gpu():

@@ -33,7 +33,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 REF = "/root/reference/vision_benchmark/evaluation"
 
-from pevit_amd.synth import ARCHS, synth_state_dict, synth_batch, randomize_adapters  # noqa: E402
+from pevit_amd.synth import ARCHS, synth_state_dict, synth_batch, randomize_adapters, reference_init_  # noqa: E402
 
 BUILDERS = {
     "kadaptation": ("model", "build_model"),
@@ -97,6 +97,9 @@ def build_ref(method, sd, lora_r=4):
             a.q_proj_adapter2 = torch.nn.Linear(lora_r, E, bias=False)
             a.v_proj_adapter1 = torch.nn.Linear(E, lora_r, bias=False)
             a.v_proj_adapter2 = torch.nn.Linear(lora_r, E, bias=False)
+            # ... with the reference's own initialisation of these four (lora_model.py:466-475): A ~ N(0, 0.02), B = 0
+            torch.nn.init.normal_(a.q_proj_adapter1.weight, std=0.02); a.q_proj_adapter2.weight.data.zero_()
+            torch.nn.init.normal_(a.v_proj_adapter1.weight, std=0.02); a.v_proj_adapter2.weight.data.zero_()
     return model
 
 
@@ -108,8 +111,18 @@ def head_init(dim, classes, seed=5):
     return w, b
 
 
+def sign_projections(v, index, k=32):
+    """k seeded +-1 projections of a flattened tensor (float64): <s_j, v>.  For an error e = a - b the mean of
+    (<s_j, a> - <s_j, b>)^2 over j is an unbiased estimate of |e|^2, so k numbers per tensor pin its relative L2 error to
+    ~ +-sqrt(1/(2k)) and see any permutation / sign / scale error that a norm cannot.  Same generator in the tests
+    (tests/conftest.py:sign_projections)."""
+    g = torch.Generator(device="cpu"); g.manual_seed(100003 + index)
+    s = torch.randint(0, 2, (k, v.numel()), generator=g, dtype=torch.int8).double() * 2 - 1
+    return s @ v.double().flatten()
+
+
 def run_case(method, arch_name, batch, classes, lora_r=4, steps=3, lr=0.01, wd=1e-4,
-             store_tensors=True, reference_init=False):
+             store_tensors=True, reference_init=False, redraw=False, full_layers=None):
     arch = ARCHS[arch_name]
     sd = synth_state_dict(arch, seed=2, text_tower=(arch_name.startswith("tiny")))
     if store_tensors:
@@ -122,6 +135,17 @@ def run_case(method, arch_name, batch, classes, lora_r=4, steps=3, lr=0.01, wd=1
     init_vals = {n: p.detach().clone() for n, p in train_named}   # reference init
     if not reference_init:       # (reference_init: the adapters stay exactly as build_model left them, model.py:533-554,987-999)
         randomize_adapters(train_named, seed=3)
+    elif redraw:
+        # 1.2 M non-zero initial values (bottleneck Adapter) would make the fixture several MB: the reference's draws are replaced by
+        # draws of the SAME law (adapter_model.py:285-295 restated in pevit_amd/synth.py:reference_init_) from a seeded generator,
+        # which the test regenerates; the law is checked against what build_*_model left (mean / std / zero pattern) right here
+        law = {n: (float(p.detach().mean()), float(p.detach().std()) if p.numel() > 1 else 0.0, float(p.detach().abs().max()) == 0.0) for n, p in train_named}
+        reference_init_(train_named, method, seed=7)
+        for n, p in train_named:
+            m, sd_, z = law[n]
+            assert z == (float(p.detach().abs().max()) == 0.0), n
+            if not z and p.numel() > 1000:
+                assert abs(float(p.detach().std()) - sd_) < 0.05 * sd_ and abs(float(p.detach().mean()) - m) < 0.1 * sd_, (n, m, sd_)
     adapters = {n: p.detach().clone() for n, p in train_named}
     # tensors the reference adds but never trains (Compacter's shared phm_rule)
     frozen_extra = {n: p.detach().clone() for n, p in model.named_parameters()
@@ -152,11 +176,14 @@ def run_case(method, arch_name, batch, classes, lora_r=4, steps=3, lr=0.01, wd=1
     out["loss0"] = loss.detach().clone()
     opt.step()
     losses = [float(loss)]
-    for _ in range(steps - 1):
+    grads_last = {}
+    for it in range(steps - 1):
         opt.zero_grad()
         lg = clf(images)
         ls = crit(lg, labels)
         ls.backward()
+        if it == steps - 2:              # the gradients of the LAST recorded step (the adapters have moved: every low-rank factor carries signal)
+            grads_last = {n: p.grad.detach().clone() for n, p in clf.named_parameters() if p.requires_grad and p.grad is not None}
         opt.step()
         losses.append(float(ls))
     final = {n: p.detach().clone() for n, p in clf.named_parameters() if p.requires_grad}
@@ -205,13 +232,45 @@ def run_case(method, arch_name, batch, classes, lora_r=4, steps=3, lr=0.01, wd=1
                 tensors["adapter/" + n] = v.numpy()
         tensors["logits0"] = out["logits0"].numpy(); tensors["loss0"] = out["loss0"].numpy(); tensors["feat"] = out["feat"].numpy()
         meta["zero_grad_tensors"] = [n for n, g in grads.items() if g is not None and float(g.abs().max()) == 0.0]
+        meta["init_source"] = "pevit_amd.synth.reference_init_(seed=7): same law as the reference's init, checked above" if redraw else "the reference's own draws (adapter/*)"
+        meta["full_layers"] = full_layers
+        order = {n: i for i, (n, _) in enumerate(clf.named_parameters())}
+
+        def in_full(n):              # tensors stored in full: everything, or (full_layers given) the named blocks + whatever is not per block
+            if full_layers is None or ".resblocks." not in n:
+                return True
+            return int(n.split(".resblocks.")[1].split(".")[0]) in full_layers
+
+        def put(kind, n, v):
+            if in_full(n):
+                tensors[f"{kind}/{n}"] = v.numpy()
+            else:                    # 32 seeded sign projections + the norm (make_golden.sign_projections)
+                tensors[f"{kind}_proj/{n}"] = sign_projections(v, order[n]).numpy()
+                tensors[f"{kind}_norm/{n}"] = np.float64(float(v.double().norm()))
+        if redraw:
+            meta["init_checksum"] = {n: [float(v.double().sum()), float((v.double() ** 2).sum())] for n, v in adapters.items()}
+            for n in list(tensors):
+                if n.startswith("adapter/"):
+                    del tensors[n]
         for n, g in grads.items():
             if g is not None and float(g.abs().max()) != 0.0:
-                tensors["grad/" + n] = g.numpy()
+                put("grad", n, g)
+        meta["zero_grad_last"] = [n for n, g in grads_last.items() if float(g.abs().max()) == 0.0]
+        for n, g in grads_last.items():
+            if float(g.abs().max()) != 0.0:
+                put("grad_last", n, g)
+        meta["unchanged"] = []
         for n, v in final.items():
-            if n in adapters and torch.equal(v, adapters[n]) and float(v.abs().max()) == 0.0:
-                continue                                   # still exactly zero: nothing to store
-            tensors["final/" + n] = v.numpy()
+            m = n[len("backbone."):] if n.startswith("backbone.") else n
+            base = adapters[m] if m in adapters else (head_w if n.endswith("weight") else head_b)
+            if torch.equal(v, base):
+                meta["unchanged"].append(n)                # never moved (exact zeros that stay zero, dead parameters): nothing to store
+                continue
+            # what the steps CHANGED (final - initial): the final value of a tensor that barely moves would only compare its initial value
+            put("delta", n, v - base)
+        meta["proj_index"] = {n: order[n] for n in order if not in_full(n)}
+        for n, v in frozen_extra.items():
+            tensors["adapter/" + n] = v.numpy()
         tensors["bn_mean"] = clf.channel_bn.running_mean.numpy()
         tensors["bn_var"] = clf.channel_bn.running_var.numpy()
     else:
@@ -284,7 +343,9 @@ def main():
     ap.add_argument("--counts", action="store_true", help="also regenerate the parameter-count table")
     ap.add_argument("--text-only", action="store_true", help="only (re)generate tiny_text.npz")
     ap.add_argument("--refinit", action="store_true",
-                    help="only generate full_b32_kadaptation_refinit: ViT-B/32 + KAdaptation at the reference initialisation, bs 8, 3 SGD steps")
+                    help="only generate the *_refinit fixtures: full size at the reference initialisation, bs 8, 5 SGD steps "
+                         "(ViT-B/32 KAdaptation / LoRA r=8 / Adapter, ViT-B/16 Compacter, ViT-L/14 KAdaptation)")
+    ap.add_argument("--only", default="", help="with --refinit: only the fixtures whose name contains this")
     ap.add_argument("--other-archs", action="store_true",
                     help="only generate the full-size summaries for the ViT-B/16 and ViT-L/14 configurations of BASELINE.json")
     args = ap.parse_args()
@@ -293,13 +354,26 @@ def main():
         print("tiny_text written")
         return
     if args.refinit:
-        torch.manual_seed(0)
-        torch.set_num_threads(8)
-        meta, tensors = run_case("kadaptation", "ViT-B/32", batch=8, classes=100, steps=3, store_tensors=False, reference_init=True)
-        np.savez_compressed(os.path.join(HERE, "full_b32_kadaptation_refinit.npz"), **tensors)
-        with open(os.path.join(HERE, "full_b32_kadaptation_refinit.json"), "w") as f:
-            json.dump(meta, f, indent=1)
-        print("full_b32_kadaptation_refinit ok; losses", meta["losses"], "non-zero grads:", sorted(k for k in tensors if k.startswith("grad/"))[:4], "...")
+        # full size, bs 8, at the reference initialisation, 5 SGD steps (gradients of the first AND the last step recorded: by then
+        # LoRA's B, the bottleneck up-projection and Compacter's factors have moved, so every low-rank gradient kernel carries signal)
+        cases = (("kadaptation", "ViT-B/32", "full_b32_kadaptation_refinit", 4, False, None),
+                 ("lora", "ViT-B/32", "full_b32_lora_r8_refinit", 8, True, [0, 5, 11]),
+                 ("adapter", "ViT-B/32", "full_b32_adapter_refinit", 4, True, [0, 11]),
+                 ("compacter", "ViT-B/16", "full_b16_compacter_refinit", 4, False, None),
+                 ("kadaptation", "ViT-L/14", "full_l14_kadaptation_refinit", 4, False, None))
+        for method, arch_name, tag, lora_r, redraw, full_layers in cases:
+            if args.only and args.only not in tag:
+                continue
+            torch.manual_seed(0)
+            torch.set_num_threads(8)
+            meta, tensors = run_case(method, arch_name, batch=8, classes=100, lora_r=lora_r, steps=5, store_tensors=False,
+                                     reference_init=True, redraw=redraw, full_layers=full_layers)
+            np.savez_compressed(os.path.join(HERE, f"{tag}.npz"), **tensors)
+            with open(os.path.join(HERE, f"{tag}.json"), "w") as f:
+                json.dump(meta, f, indent=1)
+            print(tag, "ok; losses", meta["losses"], "| non-zero grads step 0:", sum(k.startswith(("grad/", "grad_proj/")) for k in tensors),
+                  "last step:", sum(k.startswith(("grad_last/", "grad_last_proj/")) for k in tensors), "| moved:", sum(k.startswith(("delta/", "delta_proj/")) for k in tensors),
+                  "| %.2f MB" % (os.path.getsize(os.path.join(HERE, f"{tag}.npz")) / 1e6), flush=True)
         return
     if args.other_archs:
         for method, arch_name, tag, lora_r in (("compacter", "ViT-B/16", "full_b16_compacter", 4),

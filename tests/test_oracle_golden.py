@@ -163,3 +163,65 @@ def test_full_size_vit_matches_reference(case):
             got = float(tr.p[name].grad.double().norm())
             assert abs(got - ref) <= 2e-3 * max(ref, 1e-6), (name, got, ref)
     assert tr.n_trainable() == meta["n_trainable_params"]
+
+
+REFINIT = ["full_b32_kadaptation_refinit", "full_b32_lora_r8_refinit", "full_b32_adapter_refinit"]
+
+
+@pytest.mark.parametrize("case", REFINIT)
+def test_oracle_trajectory_at_reference_init(case):
+    """The oracle against the *_refinit fixtures (full width / depth, bs 8, the reference's own initialisation, five SGD steps):
+    logits / loss of step 0, every recorded gradient of the first and of the LAST step, what the steps changed, the loss
+    trajectory.  (ViT-B/16 Compacter and ViT-L/14 have the same fixtures; they are compared on the GPU only -- tests/test_gpu_refinit.py
+    -- to keep this suite at minutes.)"""
+    from conftest import proj_rel_err
+    from pevit_amd.synth import ARCHS, reference_init_, synth_batch, synth_state_dict
+    meta, t = load_golden(case)
+    method, arch = meta["method"], ARCHS[meta["arch"]]
+    sd = synth_state_dict(arch, seed=2, text_tower=False)
+    p = {k: v for k, v in sd.items() if k.startswith("visual.")}
+    shapes = ref_cpu.adapter_param_shapes(method, arch.width, arch.layers, meta["lora_r"])
+    named = [(n, torch.zeros(shapes[n])) for n in meta["trainable_names"]]
+    if "init_checksum" in meta:
+        reference_init_(named, method, seed=7)
+    p.update(dict(named))
+    for k, v in t.items():
+        if k.startswith("adapter/"):
+            p[k[len("adapter/"):]] = v.float().view(shapes[k[len("adapter/"):]])
+    tr = ref_cpu.OracleTrainer(p, method, meta["classes"], lr=meta["lr"], wd=meta["wd"])
+    with torch.no_grad():
+        tr.head_w.copy_(t["head_w"]); tr.head_b.copy_(t["head_b"])
+    init = {n: tr.p[n].detach().clone() for n in tr.names}
+    init["layers.0.weight"], init["layers.0.bias"] = tr.head_w.detach().clone(), tr.head_b.detach().clone()
+    images, labels = synth_batch(meta["batch"], arch.resolution, meta["classes"])
+
+    def check(kind, key, v, tol):
+        if f"{kind}/{key}" in t:
+            e = rel_err(v, t[f"{kind}/{key}"].view_as(v))
+            assert e < tol, (kind, key, e)
+            return 1
+        if f"{kind}_proj/{key}" in t:
+            e = proj_rel_err(v, meta["proj_index"][key], t[f"{kind}_proj/{key}"], t[f"{kind}_norm/{key}"])
+            assert e < tol, (kind, key, e)
+            return 1
+        assert v is None or float(v.abs().max()) == 0.0, (kind, key)        # the reference left it exactly zero / untouched
+        return 0
+
+    losses = []
+    for step in range(meta["steps"]):
+        logits, loss = tr.loss_and_grads(images, labels)
+        losses.append(float(loss))
+        if step == 0:
+            assert max_rel(logits, t["logits0"]) < 1e-4 and abs(float(loss) - float(t["loss0"])) < 1e-4
+        if step in (0, meta["steps"] - 1):
+            kind = "grad" if step == 0 else "grad_last"
+            n = sum(check(kind, "backbone." + name, tr.p[name].grad, 5e-3) for name in tr.names)
+            n += check(kind, "layers.0.weight", tr.head_w.grad, 5e-3) + check(kind, "layers.0.bias", tr.head_b.grad, 5e-3)
+            assert n == sum(k.startswith((kind + "/", kind + "_proj/")) for k in t)
+        tr.opt.step()
+    for a, b in zip(losses, meta["losses"]):
+        assert abs(a - b) < 1e-3 * max(1.0, abs(b)), (losses, meta["losses"])
+    n = sum(check("delta", "backbone." + name, tr.p[name].detach() - init[name], 5e-3) for name in tr.names)
+    n += check("delta", "layers.0.weight", tr.head_w.detach() - init["layers.0.weight"], 5e-3)
+    n += check("delta", "layers.0.bias", tr.head_b.detach() - init["layers.0.bias"], 5e-3)
+    assert n == sum(k.startswith(("delta/", "delta_proj/")) for k in t)
