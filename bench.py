@@ -192,11 +192,27 @@ def pmc_traffic(arch, method, batch):
     except (OSError, ValueError):
         entry = None
     if not entry:
-        return None, "no PMC pass committed for this workload"
+        return None, "no PMC pass committed for this workload", None
     if entry.get("kernels_hash") != kernels_hash():
         return None, ("the committed PMC pass (profiles/hbm_traffic.json, kernels %s) was taken with different kernel sources "
-                      "than this build (%s): re-run scripts/run_pmc_passes.sh" % (entry.get("kernels_hash"), kernels_hash()))
-    return entry["gemm"]["hbm_bytes_per_launch"], entry["how"]
+                      "than this build (%s): re-run scripts/run_pmc_passes.sh" % (entry.get("kernels_hash"), kernels_hash())), None
+    return entry["gemm"]["hbm_bytes_per_launch"], entry["how"], entry.get("all_kernels", {}).get("hbm_bytes_per_step")
+
+
+def pin_rank_to_cores(local_rank, local_world):
+    """One contiguous slice of the host's cores per rank (so that N launch threads do not migrate over each other) and a bounded
+    intra-op pool: the step is one C call per batch, its host side needs one core.  PEVIT_NO_PIN=1 leaves the affinity alone."""
+    if os.environ.get("PEVIT_NO_PIN") == "1" or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+        per = max(1, len(cores) // max(local_world, 1))
+        mine = cores[local_rank * per:(local_rank + 1) * per] or cores
+        os.sched_setaffinity(0, mine)
+        torch.set_num_threads(max(1, min(8, len(mine))))
+        return mine
+    except OSError:
+        return None
 
 
 def main():
@@ -242,9 +258,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1 and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run (one rank per GPU of this node,
+        # rendezvous on 127.0.0.1) instead of printing an error line where the driver expects a number
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        raise SystemExit(subprocess.call(cmd, env=env))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
+    pin_rank_to_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     if args.share_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -378,7 +405,7 @@ def main():
         step_tflops = value / world * gflop / 1e3      # whole-step algorithmic TFLOP/s per GPU
         gemm_tflops = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         algo_bytes = algo_bytes_total / max(gemm_launches, 1)
-        traffic, traffic_how = pmc_traffic(args.arch, args.method, args.batch) if args.weights == "bf16" else (None, "no PMC pass for fp8 weights")
+        traffic, traffic_how, traffic_all = pmc_traffic(args.arch, args.method, args.batch) if args.weights == "bf16" else (None, "no PMC pass for fp8 weights", None)
         traffic_stale = traffic is None and "different kernel sources" in traffic_how
         if traffic_stale:
             print("[bench] " + traffic_how, file=sys.stderr, flush=True)
@@ -390,12 +417,22 @@ def main():
         # the GEMM launches of a step by (epilogue, M, N, K), largest share of the time first: which product is furthest
         # from the peak
         per_kernel = []
+        ridge = peak * 1e12 / (PEAK_HBM_TBS * 1e12)            # flop per byte where the two roofs meet (312 for bf16)
+        # both floors of the WHOLE step: algorithmic flops at the matrix peak, algorithmic bytes of every launch at 8 TB/s
+        hbm_bytes_step = algo_bytes_total / prof_steps + sum(v["launches_per_step"] * v["algorithmic_bytes_per_launch"] for v in hbm_kernels.values())
+        mfma_floor_ms = gflop * args.batch / peak               # GFLOP per step / (TFLOP/s) = ms
+        hbm_floor_ms = hbm_bytes_step / (PEAK_HBM_TBS * 1e12) * 1e3
+        for v in hbm_kernels.values():
+            v["bound"] = "hbm"
         for (epi, M, N, K), (cnt, ms_k, fl_k, by_k) in sorted(gemm_by_shape.items(), key=lambda kv: -kv[1][1])[:8]:
             sec = max(ms_k, 1e-9) * 1e-3
             per_kernel.append({"epilogue": EPI_NAMES.get(epi, str(epi)), "M": M, "N": N, "K": K,
                                "launches_per_step": cnt / prof_steps, "avg_us": ms_k * 1e3 / cnt,
                                "share_of_gemm_time": ms_k / max(gemm_ms, 1e-9), "tflops": fl_k / sec / 1e12,
-                               "frac": fl_k / sec / 1e12 / peak, "algorithmic_TBps": by_k / sec / 1e12})
+                               "frac": fl_k / sec / 1e12 / peak, "algorithmic_TBps": by_k / sec / 1e12,
+                               # which roof is lower for THIS product: flop per algorithmic byte against the ridge peak / 8 TB/s
+                               "flop_per_byte": fl_k / max(by_k, 1.0), "bound": "mfma" if fl_k / max(by_k, 1.0) >= ridge else "hbm",
+                               "frac_of_hbm_peak": by_k / sec / 1e12 / PEAK_HBM_TBS})
         if os.environ.get("PEVIT_BENCH_ALL_SHAPES"):      # measurement: every GEMM shape of the step on stderr
             for (epi, M, N, K), (cnt, ms_k, fl_k, by_k) in sorted(gemm_by_shape.items(), key=lambda kv: -kv[1][1]):
                 print(f"[shape] epi={EPI_NAMES.get(epi, epi)} M={M} N={N} K={K} n/step={cnt / prof_steps:.1f} avg_us={ms_k * 1e3 / cnt:.1f}",
@@ -417,7 +454,8 @@ def main():
                                    f"weights {args.weights}" + (" (e4m3 codes + per-channel scales, bf16 activations, f32 accumulate)"
                                                                  if args.weights == "fp8" else ""),
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                       "gradient_exchange": ("none" if world == 1 else args.exchange),
+                       "gradient_exchange": ("none" if world == 1 else args.exchange), "rccl_ranks": world if (world > 1 and args.dist_backend == "nccl") else 0,
+                       "gradient_buckets": 0 if world == 1 else 3, "exchanged_floats_per_step": 0 if world == 1 else int(eng.n_params),
                        "train_gflop_per_image": gflop, "final_loss": final_loss},
             "roofline": {"bound": "mfma", "kernel": "gemm8_kernel<...> + gemm_kphase_kernel<...> + gemm_kernel<...> + gemm_streamk_kernel<...> (pevit_amd/csrc/gemm.hip: all epilogues / tile shapes)",
                          "achieved": gemm_tflops, "peak": peak, "unit": "TFLOP/s",
@@ -425,6 +463,17 @@ def main():
                          # the whole step against the same peak: images/s x algorithmic GFLOP/image, and the matrix-core work
                          # actually executed (class-token pruning of the last block) over the step time
                          "whole_step_frac": step_tflops / peak,
+                         # round 5: BOTH floors of the step.  Its arithmetic intensity (flop per algorithmic byte of every launch)
+                         # lies below the ridge, so the step as a whole is HBM-side; `bound` above names the roof of the dominant
+                         # KERNEL FAMILY (the GEMMs, each well above the ridge), per_kernel[*].bound that of every product
+                         "mfma_floor_ms": mfma_floor_ms, "hbm_floor_ms": hbm_floor_ms,
+                         "algorithmic_bytes_per_step": hbm_bytes_step,
+                         "whole_step_flop_per_byte": gflop * args.batch * 1e9 / max(hbm_bytes_step, 1.0), "ridge_flop_per_byte": ridge,
+                         "whole_step_bound": "hbm" if gflop * args.batch * 1e9 / max(hbm_bytes_step, 1.0) < ridge else "mfma",
+                         "whole_step_hbm_frac": hbm_bytes_step / (ms * 1e-3) / (PEAK_HBM_TBS * 1e12),
+                         # HBM-side bytes of EVERY dispatch of a step from the same two PMC passes as `traffic` (per step)
+                         "traffic_all": traffic_all, "traffic_all_unit": "bytes/step",
+                         "traffic_all_over_algorithmic": (traffic_all / hbm_bytes_step) if traffic_all else None,
                          "executed_gemm_frac_of_peak": gemm_flops / prof_steps / 1e12 / (ms * 1e-3) / peak,
                          "non_gemm_ms_per_step": ms - gemm_ms / prof_steps,
                          "hbm_kernels": hbm_kernels,

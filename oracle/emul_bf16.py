@@ -21,6 +21,9 @@ Storage points reproduced (engine buffer -> here):
             residual stream, LN statistics f32           plain f32
             class-token LayerNorm bf16 -> proj bf16      RoundSTE, LinearE
   backward  bf16 copy of the gradient stream (dyb)       every LinearE rounds its upstream gradient
+            the residual gradient stream ITSELF bf16     RoundGrad at x_mid and at the block output (round 5; attention-site
+            (LayerNorm backward read-modify-writes dyb)  adapters on bf16 weights only: capi.hip gs16; the dx of the lowest block
+                                                         walked leaves in f32)
             dh = bf16(acc * gelu'(h))                    QuickGeluE.backward
             dxn2, dO, dxn1 bf16 (dX GEMM outputs)        LinearE(round_dx) / QKVAug.backward
             dS bf16, P bf16 for dV, delta = sum P dP (N <= 64) / from bf16 O    AttnCore.backward
@@ -43,7 +46,7 @@ from . import ref_cpu as R
 # Named rounding points: ``POINTS_OFF`` switches single storage points of the emulation off (the value then passes in f32), which
 # is how scripts/r4_rounding_ablation.py attributes the bf16 path's distance from the f32 reference to individual buffers.
 POINTS = ("w", "img", "xn", "qkv", "P", "Q_fwd", "q_delta", "p", "attn_out", "h", "gelu", "cls", "dyb", "dh", "dx", "ds", "dqkv",
-          "p_bwd", "u", "Q_bwd", "t_bwd", "bottleneck")
+          "p_bwd", "u", "Q_bwd", "t_bwd", "bottleneck", "gstream")
 POINTS_OFF = set()
 
 
@@ -63,6 +66,18 @@ class RoundSTE(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         return g, None
+
+
+class RoundGrad(torch.autograd.Function):
+    """identity; the gradient arriving at this point of the residual stream is stored in bf16 (the engine's dyb buffer)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return bf(g, "gstream")
 
 
 class LinearE(torch.autograd.Function):
@@ -308,9 +323,9 @@ def block(x, p, i, heads, method, wcache, tower="visual.transformer."):
     pre = f"{tower}resblocks.{i}."
     xn = _ln_b(x, p[pre + "ln_1.weight"], p[pre + "ln_1.bias"])
     if method in ("kadaptation", "lora"):
-        x = x + attention_site(xn, p, pre + "attn.", tower, heads, method, wcache)
+        x = RoundGrad.apply(x + attention_site(xn, p, pre + "attn.", tower, heads, method, wcache))
         xn2 = _ln_b(x, p[pre + "ln_2.weight"], p[pre + "ln_2.bias"])
-        return x + mlp_h(xn2, p, pre, wcache)
+        return RoundGrad.apply(x + mlp_h(xn2, p, pre, wcache))
     x = x + stock_attention(xn, p, pre + "attn.", heads, wcache)
     xn2 = _ln_b(x, p[pre + "ln_2.weight"], p[pre + "ln_2.bias"])
     h = mlp_h(xn2, p, pre, wcache)

@@ -103,6 +103,9 @@ SIGNATURES = {
     "pevit_ar_import": (c_int, [P, c_int, P]),
     "pevit_allreduce_flat": (c_int, [P, P, P, c_size_t]),
     "pevit_ar_error": (c_int, [P, P]),
+    "pevit_ar_error_word": (c_void_p, [P]),
+    "pevit_ar_fine_grained": (c_int, [P]),
+    "pevit_set_external_poison": (c_int, [P, P]),
     "pevit_streamk_error": (c_int, [P, P]),
     "pevit_streamk_status": (c_int, [P, P, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
 }

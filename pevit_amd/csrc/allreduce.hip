@@ -14,12 +14,21 @@
 //     with system-scope loads (they were written by another device; this GPU's L2 may hold lines of the previous use).
 //   * two parities: a rank that is through all-reduce e may push e+1 while a slower peer still reads e; it cannot reach e+2
 //     before that peer has pushed e+1, i.e. after the peer finished reading parity e & 1.
-// What has run: two processes sharing ONE device (tests/test_gpu_allreduce.py) -- IPC export / open, the push, the flag
+// Round 5: the mailbox is allocated FINE-GRAINED where the runtime allows it (hipExtMallocWithFlags; peer DMA
+// writes into coarse-grained, L2-cached memory are not guaranteed to become visible to spinning loads on a multi-XCD part) and every
+// reading thread issues a system-scope acquire behind the barrier; a flag is the pair (epoch, n) so that ranks that disagree on
+// the bucket size raise an error instead of summing garbage; ONE workgroup decides whether the launch reduces or gives up
+// (block 0 polls the peers, the others read its verdict), so a bucket is reduced everywhere or nowhere; the host epoch advances
+// only when every enqueue succeeded; the error word can be handed to the context (pevit_set_external_poison) so that the fused
+// SGD kernel withholds the update of a step whose exchange failed, exactly as for a stream-K hand-off.
+// EXPERIMENTAL: never run across two devices (no multi-GPU box in the build environment); bench.py's default exchange is RCCL.
+// What has run: two / four / eight processes sharing ONE device (tests/test_gpu_allreduce.py) -- IPC export / open, the push, the flag
 // protocol, the reduction order, three buckets per step inside engine.forward_backward_dp.  NOT measured: two GPUs (xGMI).
 #include "../../include/pevit_hip.h"
 #include "common.h"
 #include "kernels.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -36,34 +45,54 @@ struct pevit_ar {
     char* peer[AR_MAX_WORLD] = {};           // IPC-opened allocations of the peers (own entry = base)
     bool opened[AR_MAX_WORLD] = {};
     unsigned epoch = 0;
-    size_t off_flags = 0, off_stage = 0, off_err = 0, bytes = 0;
+    size_t off_flags = 0, off_stage = 0, off_err = 0, off_dec = 0, bytes = 0;
+    bool fine = false;                       // the allocation is fine-grained (hipExtMallocWithFlags)
 };
 
 namespace {
 
 inline size_t mail_off(const pevit_ar* a, int par, int src) { return ((size_t)par * a->world + src) * a->cap * sizeof(float); }
-inline size_t flag_off(const pevit_ar* a, int par, int src) { return a->off_flags + ((size_t)par * a->world + src) * sizeof(unsigned); }
+inline size_t flag_off(const pevit_ar* a, int par, int src) { return a->off_flags + ((size_t)par * a->world + src) * sizeof(unsigned long long); }
 
 // buf[i] = sum over ranks (rank order) of: own contribution (buf itself) / the peers' pushed copies in the local mailbox
-__global__ __launch_bounds__(256) void ar_reduce_kernel(float* __restrict__ buf, size_t n, const float* mail, const unsigned* flags,
+__global__ __launch_bounds__(256) void ar_reduce_kernel(float* __restrict__ buf, size_t n, const float* mail, const unsigned long long* flags,
                                                         int rank, int world, size_t cap, unsigned epoch, unsigned* err,
-                                                        long long spin_limit) {
+                                                        long long spin_limit, unsigned* decision) {
     __shared__ int ok;
     if (threadIdx.x == 0) {
         int good = 1;
-        for (int p = 0; p < world && good; ++p) {
-            if (p == rank) continue;
-            long long spins = 0;
-            while (__hip_atomic_load(flags + p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != epoch) {
-                __builtin_amdgcn_s_sleep(8);
-                if (++spins > spin_limit) { good = 0; break; }
+        if (blockIdx.x == 0) {
+            // the verdict of the whole launch: every peer's flag carries (this epoch, this n)
+            const unsigned long long want = ((unsigned long long)(unsigned)n << 32) | epoch;
+            unsigned why = 1u;
+            for (int p = 0; p < world && good; ++p) {
+                if (p == rank) continue;
+                long long spins = 0;
+                for (;;) {
+                    const unsigned long long f = __hip_atomic_load(flags + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if ((unsigned)(f & 0xffffffffu) == epoch) { if (f != want) { good = 0; why = 2u; } break; }   // same epoch, another n
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > spin_limit) { good = 0; break; }
+                }
             }
+            if (!good) atomicExch(err, why);  // 1: a peer never arrived, 2: the ranks disagree on the size; buf stays as it is
+            __hip_atomic_store(decision, (epoch << 1) | (unsigned)good, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            // block 0 of a grid is dispatched no later than any other block of it, so this wait cannot starve it
+            long long spins = 0;
+            unsigned d;
+            while (((d = __hip_atomic_load(decision, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 1) != epoch) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > 2 * spin_limit) { d = epoch << 1; atomicExch(err, 1u); break; }
+            }
+            good = (int)(d & 1u);
         }
-        if (!good) atomicExch(err, 1u);      // a peer never arrived: leave buf as it is and raise the error word
         ok = good;
     }
     __syncthreads();
     if (!ok) return;
+    // the contributions were written by another device (or its copy engine): nothing this CU or this XCD's L2 holds of them is valid
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
     if (i >= n) return;
     const bool pair = i + 1 < n;
@@ -100,10 +129,19 @@ extern "C" int pevit_ar_create(pevit_ar** out, int rank, int world, size_t max_f
     if (!a) { pevit_set_error("ar_create: out of host memory"); return -1; }
     a->rank = rank; a->world = world; a->cap = (max_floats + 63) & ~(size_t)63;
     a->off_flags = align_up(2 * (size_t)world * a->cap * sizeof(float), 256);
-    a->off_stage = align_up(a->off_flags + 2 * (size_t)world * sizeof(unsigned), 256);
+    a->off_stage = align_up(a->off_flags + 2 * (size_t)world * sizeof(unsigned long long), 256);
     a->off_err = a->off_stage + AR_STAGE * 256;
-    a->bytes = a->off_err + 256;
-    if (hipMalloc((void**)&a->base, a->bytes) != hipSuccess) { pevit_set_error("ar_create: hipMalloc of %zu bytes failed", a->bytes); delete a; return -1; }
+    a->off_dec = a->off_err + 256;
+    a->bytes = a->off_dec + 256;
+    // fine-grained first (peer writes become visible without relying on this GPU's L2 being bypassed); PEVIT_AR_COARSE=1 or a
+    // runtime that refuses falls back to the plain allocation
+    const char* coarse = getenv("PEVIT_AR_COARSE");
+    if (!(coarse && coarse[0] == '1') && hipExtMallocWithFlags((void**)&a->base, a->bytes, hipDeviceMallocFinegrained) == hipSuccess) a->fine = true;
+    else {
+        (void)hipGetLastError();
+        a->base = nullptr;
+        if (hipMalloc((void**)&a->base, a->bytes) != hipSuccess) { pevit_set_error("ar_create: hipMalloc of %zu bytes failed", a->bytes); delete a; return -1; }
+    }
     if (hipMemset(a->base, 0, a->bytes) != hipSuccess) { pevit_set_error("ar_create: hipMemset failed"); (void)hipFree(a->base); delete a; return -1; }
     a->peer[rank] = a->base;
     *out = a;
@@ -123,6 +161,15 @@ extern "C" int pevit_ar_handle_bytes(void) { return (int)sizeof(hipIpcMemHandle_
 extern "C" int pevit_ar_export(pevit_ar* a, void* handle_out) {
     if (!a || !handle_out) { pevit_set_error("ar_export: null argument"); return -1; }
     hipIpcMemHandle_t h;
+    if (a->fine && hipIpcGetMemHandle(&h, a->base) != hipSuccess) {
+        // this runtime does not export fine-grained allocations: take the plain one (nothing has been pushed yet)
+        (void)hipGetLastError();
+        (void)hipFree(a->base);
+        a->base = nullptr; a->fine = false;
+        HIP_OK(hipMalloc((void**)&a->base, a->bytes));
+        HIP_OK(hipMemset(a->base, 0, a->bytes));
+        a->peer[a->rank] = a->base;
+    }
     HIP_OK(hipIpcGetMemHandle(&h, a->base));
     memcpy(handle_out, &h, sizeof(h));
     return 0;
@@ -148,30 +195,39 @@ extern "C" int pevit_allreduce_flat(pevit_ar* a, void* stream, float* buf, size_
     for (int p = 0; p < a->world; ++p)
         if (!a->peer[p]) { pevit_set_error("allreduce_flat: peer %d has not been imported", p); return -1; }
     hipStream_t s = (hipStream_t)stream;
-    const unsigned e = ++a->epoch;
+    if (n >> 32) { pevit_set_error("allreduce_flat: %zu floats do not fit the 32-bit size field of the flag", n); return -1; }
+    const unsigned e = a->epoch + 1;                            // committed below, once every enqueue has succeeded
     const int par = (int)(e & 1u);
     unsigned* stage = reinterpret_cast<unsigned*>(a->base + a->off_stage + (size_t)(e % AR_STAGE) * 256);
-    HIP_OK(hipMemsetD32Async((hipDeviceptr_t)stage, (int)e, 1, s));
+    HIP_OK(hipMemsetD32Async((hipDeviceptr_t)stage, (int)e, 1, s));                     // flag = (n << 32) | epoch
+    HIP_OK(hipMemsetD32Async((hipDeviceptr_t)(stage + 1), (int)(unsigned)n, 1, s));
     for (int k = 1; k < a->world; ++k) {                       // start with the right-hand neighbour: the pushes of the ranks spread over the links
         const int p = (a->rank + k) % a->world;
         HIP_OK(hipMemcpyAsync(a->peer[p] + mail_off(a, par, a->rank), buf, n * sizeof(float), hipMemcpyDeviceToDevice, s));
-        HIP_OK(hipMemcpyAsync(a->peer[p] + flag_off(a, par, a->rank), stage, sizeof(unsigned), hipMemcpyDeviceToDevice, s));
+        HIP_OK(hipMemcpyAsync(a->peer[p] + flag_off(a, par, a->rank), stage, sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
     }
     const unsigned blocks = (unsigned)((n + 511) / 512);
     hipLaunchKernelGGL(ar_reduce_kernel, dim3(blocks), dim3(256), 0, s, buf, n,
                        reinterpret_cast<const float*>(a->base + mail_off(a, par, 0)),
-                       reinterpret_cast<const unsigned*>(a->base + flag_off(a, par, 0)), a->rank, a->world, a->cap, e,
-                       reinterpret_cast<unsigned*>(a->base + a->off_err), (long long)8000000);      // a few seconds of polling
+                       reinterpret_cast<const unsigned long long*>(a->base + flag_off(a, par, 0)), a->rank, a->world, a->cap, e,
+                       reinterpret_cast<unsigned*>(a->base + a->off_err), (long long)8000000,       // a few seconds of polling
+                       reinterpret_cast<unsigned*>(a->base + a->off_dec) + par);
     LAUNCH_OK("ar_reduce_kernel");
+    a->epoch = e;
     return 0;
 }
 
-// 1 if a reduction ever gave up waiting for a peer (synchronises the stream), 0 otherwise; clears the word
+// device address of the error word (0 = fine, 1 = a peer never arrived, 2 = the ranks passed different sizes): hand it to
+// pevit_set_external_poison so that the fused SGD kernel withholds the update of a step whose exchange failed
+extern "C" const unsigned* pevit_ar_error_word(pevit_ar* a) { return a ? reinterpret_cast<const unsigned*>(a->base + a->off_err) : nullptr; }
+extern "C" int pevit_ar_fine_grained(pevit_ar* a) { return a && a->fine ? 1 : 0; }
+
+// 1 / 2 if a reduction ever gave up waiting for a peer / saw another size (synchronises the stream), 0 otherwise; clears the word
 extern "C" int pevit_ar_error(pevit_ar* a, void* stream) {
     if (!a) return -1;
     unsigned v = 0;
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return -1;
     if (hipMemcpy(&v, a->base + a->off_err, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     if (v) (void)hipMemset(a->base + a->off_err, 0, 4);
-    return v ? 1 : 0;
+    return (int)v;
 }

@@ -109,6 +109,9 @@ struct pevit_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // A/B-measurement knobs (pevit_tune): per context, so that contexts stay independent of each other
     GemmTune tune;
+    const unsigned* ext_poison = nullptr;   // pevit_set_external_poison: a second error word that withholds the optimizer update (the DP exchange's)
+    float* last_loss = nullptr;             // where the loss of the step in flight was written (NaN goes there when its update is withheld)
+    int gstream16 = 1;        // attention-site adapters, bf16 weights: the residual GRADIENT stream is carried in bf16 only (the copy the dX GEMMs read), LayerNorm backward read-modify-writes it in place: 10 instead of 16 B per element (round 5)
     int dx_stored = 1;        // dX GEMMs hand the LN-input gradient to LayerNorm backward in the activation storage type (bf16)
     int fused_bn = 0;         // post-MLP adapters: down -> activation -> up (and its backward) as one launch each (adapter.hip
                               // bottleneck_pair_kernel): 24.4 + 22.1 us against 22.9 + 19.5 us for the four GEMM launches -- opt-in
@@ -762,6 +765,7 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0, bool cls_
     const bool use_side = c->side_stream && site;
     bool side_pending = false;
     const bool combo = c->lowrank_combo && site && !c->f32 && !use_side;
+    const bool gs16 = c->gstream16 && site && !c->f32 && c->dx_stored;
     int prev_layer = -1, u_par = 0;
     float* u_last = nullptr;
     int tn_pend = -1, tn_par = 0;          // post-MLP adapters: layer whose d W_down product is still owed, and the d pre buffer in turn
@@ -859,6 +863,12 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0, bool cls_
         }
         // fp8: the bf16 copy feeds the out-projection backward, whose contraction runs over out_proj's output channels
         // dy (stored type or f32) + x + residual gradient read, f32 gradient + its stored copy written
+        if (gs16)
+            PROF(c, s, PEVIT_PROF_LN_BWD, R, (double)R * E * (c->es + 4 + c->es + c->es),
+                 pevit_launch_ln_bwd(dxn, at<float>(W, v.x_mid), at<float>(W, v.mean2), at<float>(W, v.rstd2),
+                                     at<float>(A, b.ln2w), reinterpret_cast<const float*>(dyb), nullptr, dyb, R, E, s, (size_t)rs,
+                                     c->fp8 ? at<float>(A, b.so) : nullptr, 0, 1, 0, 1, c->fp8 ? at<float>(A, b.spr) : nullptr));
+        else
         PROF(c, s, PEVIT_PROF_LN_BWD, R, (double)R * E * ((c->dx_stored ? c->es : 4) + 4 + 4 + 4 + c->es),
              pevit_launch_ln_bwd(dxn, at<float>(W, v.x_mid), at<float>(W, v.mean2), at<float>(W, v.rstd2),
                                  at<float>(A, b.ln2w), dxa, dxb, dyb, R, E, s, (size_t)rs,
@@ -921,6 +931,13 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0, bool cls_
             if (c->dx_stored) { p.outb = reinterpret_cast<bf16*>(dxn); p.ldob = E; CHECK(gemm(c, EPI_BF16, p, s)); }
             else { p.outf = dxn; p.ldo = E; CHECK(gemm(c, EPI_F32, p, s)); }
             // fp8: this bf16 copy is the upstream gradient of layer l-1's c_proj backward
+            if (gs16)      // the f32 copy only where the caller asked for dx (the lowest block walked)
+                PROF(c, s, PEVIT_PROF_LN_BWD, T, (double)T * E * (c->es + 4 + c->es + c->es),
+                     pevit_launch_ln_bwd(dxn, at<float>(W, v.x_in), at<float>(W, v.mean1), at<float>(W, v.rstd1),
+                                         at<float>(A, b.ln1w), reinterpret_cast<const float*>(dyb), (need_dx0 && l == l_lo) ? dxa : nullptr, dyb,
+                                         T, E, s, 0, (c->fp8 && l > 0) ? at<float>(A, c->blk[l - 1].spr) : nullptr, 0, 1, cls ? N : 0, 1,
+                                         c->fp8 ? at<float>(A, b.so) : nullptr));
+            else
             PROF(c, s, PEVIT_PROF_LN_BWD, T, (double)T * E * ((c->dx_stored ? c->es : 4) + 4 + 4 + 4 + c->es),
                  pevit_launch_ln_bwd(dxn, at<float>(W, v.x_in), at<float>(W, v.mean1), at<float>(W, v.rstd1),
                                      at<float>(A, b.ln1w), dxb, dxa, dyb, T, E, s, 0,
@@ -1043,8 +1060,17 @@ extern "C" int pevit_sgd_step(pevit_ctx* c, void* stream, float lr, float moment
     // no hand-off that could fail and nothing to guard)
     unsigned* poison = (c->ws && c->sk_slots) ? at<unsigned>(c->ws, c->w_skflag) + c->sk_slots : nullptr;
     unsigned* skipped = poison ? at<unsigned>(c->ws, c->w_skflag) + PEVIT_SK_MAX_SLOTS + 1 : nullptr;
+    float* loss_slot = c->last_loss; c->last_loss = nullptr;
     return pevit_launch_sgd(c->params, c->grads, c->mom, c->grad_mask, c->n_total, lr, momentum, wd, flags,
-                            grad_scale, (hipStream_t)stream, poison, skipped);
+                            grad_scale, (hipStream_t)stream, poison, skipped, c->ext_poison, (poison || c->ext_poison) ? loss_slot : nullptr);
+}
+
+// a device word owned by the caller (e.g. pevit_ar_error_word) that, while non-zero, makes pevit_sgd_step withhold the update --
+// the same treatment a stream-K hand-off error gets.  nullptr detaches it.  The word must outlive the context's use of it.
+extern "C" int pevit_set_external_poison(pevit_ctx* c, const unsigned* device_word) {
+    if (!c) { pevit_set_error("set_external_poison: null context"); return -1; }
+    c->ext_poison = device_word;
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------
@@ -1196,6 +1222,7 @@ extern "C" int pevit_head_forward_backward(pevit_ctx* c, void* stream, const flo
     hipStream_t s = (hipStream_t)stream;
     char* W = c->ws;
     if (c->saved_batch == 0) { size_t total; layout_workspace(c, B, c->sav, &total, c); }
+    if (labels) c->last_loss = loss;
     return pevit_launch_head(feat, labels, c->params + c->p_head_w, c->params + c->p_head_b,
                              labels ? c->grads + c->p_head_w : nullptr, labels ? c->grads + c->p_head_b : nullptr,
                              running_mean, running_var, bn_training, at<float>(W, c->w_ybn), at<float>(W, c->w_bnrstd),
@@ -1498,6 +1525,7 @@ extern "C" int pevit_tune(pevit_ctx* c, const char* key, int value) {
     if (key && !strcmp(key, "gemm_band")) { t.band = value; return 0; }
     if (key && !strcmp(key, "gemm_stagger")) { t.stagger = value; return 0; }
     if (key && c && !strcmp(key, "dx_stored")) { c->dx_stored = value; return 0; }
+    if (key && c && !strcmp(key, "gstream_bf16")) { c->gstream16 = value; return 0; }
     if (key && c && !strcmp(key, "profile_all")) { c->prof_all = value; return 0; }
     if (key && c && !strcmp(key, "fused_attn_delta")) { c->fused_attn_delta = value; return 0; }
     if (key && c && !strcmp(key, "fp8_tail")) { c->fp8_tail = value; return 0; }

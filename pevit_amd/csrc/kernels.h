@@ -88,7 +88,9 @@ int pevit_launch_ln_fwd(const float* x, const float* gamma, const float* beta, i
 int pevit_launch_ln_bwd(const void* dy, const float* x, const float* mean, const float* rstd,
                         const float* gamma, const float* dres, float* dx_out, bf16* dx_bf16, int rows, int E,
                         hipStream_t s, size_t xstride = 0, const float* bf16_colscale = nullptr, int f32 = 0, int dy_stored = 0,
-                        int res_period = 0);      // res_period > 0: dres is read on rows that are multiples of it only (zero elsewhere)
+                        int res_period = 0,       // res_period > 0: dres is read on rows that are multiples of it only (zero elsewhere)
+                        int res16 = 0,            // dres points at bf16 values (may be dx_bf16 itself: in place); dx_out may then be null
+                        const float* res_colscale = nullptr);   // res16 + fp8 weights: the power-of-two column scales folded into dres (taken out exactly)
 
 // ---- attention.hip ---------------------------------------------------------------
 // q,k,v: (B*H, N, 64) bf16 (q pre-scaled by 1/8, deltas already added); out: rows (b*N+n), cols h*64+d
@@ -164,7 +166,7 @@ int pevit_launch_scale_f32(float* p, size_t n, float scale, hipStream_t s);
 int pevit_launch_sgd(float* p, const float* g, float* mom, const unsigned char* has_grad, size_t n,
                      float lr, float momentum, float wd, int first_step, float grad_scale, hipStream_t s,
                      const unsigned* poison = nullptr,    // device word: non-zero = skip the update (stream-K hand-off error)
-                     unsigned* skipped = nullptr);        // device counter of the updates skipped that way
+                     unsigned* skipped = nullptr, const unsigned* poison2 = nullptr, float* loss_slot = nullptr);        // device counter of the updates skipped that way
 
 int pevit_launch_occupy(int blocks, int lds_bytes, double micros, hipStream_t s);   // measurement only (pevit_debug_occupy)
 

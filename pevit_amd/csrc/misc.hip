@@ -55,14 +55,20 @@ __global__ void scale_f32_kernel(float* p, size_t n, float scale) {
 
 __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ mom,
                            const unsigned char* __restrict__ has_grad, size_t n, float lr, float momentum, float wd,
-                           int flags, float grad_scale, const unsigned* __restrict__ poison, unsigned* skipped) {
+                           int flags, float grad_scale, const unsigned* __restrict__ poison, unsigned* skipped,
+                           const unsigned* __restrict__ poison2, float* loss_slot) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     // a stream-K hand-off that timed out in this step's GEMMs left a wrong tile behind and raised the context's error
     // word (gemm.hip): the update is skipped, parameters and momentum stay as they were, and the host finds the word at
     // its next check (engine.check_streamk) -- corrupted gradients never reach the parameters
-    if (poison && *poison) {
+    // poison2: an error word owned by somebody else (pevit_set_external_poison: the gradient exchange of data parallelism,
+    // allreduce.hip) -- a bucket that was never reduced must not reach the parameters either
+    if ((poison && *poison) || (poison2 && *poison2)) {
         if (i == 0 && skipped) atomicAdd(skipped, 1u);      // how many updates were withheld: reported with the error
+        // ... and the loss of this step reads NaN wherever the caller had it written: logs that are read before the host's next
+        // check of the error word (engine.STREAMK_CHECK_EVERY) show the failure instead of a number from a corrupted step
+        if (i == 0 && loss_slot) *loss_slot = __builtin_nanf("");
         return;
     }
     if (has_grad && !has_grad[i]) return;       // torch skips parameters whose .grad is None
@@ -137,10 +143,10 @@ int pevit_launch_scale_f32(float* p, size_t n, float scale, hipStream_t s) {
 
 int pevit_launch_sgd(float* p, const float* g, float* mom, const unsigned char* has_grad, size_t n, float lr,
                      float momentum, float wd, int first_step, float grad_scale, hipStream_t s, const unsigned* poison,
-                     unsigned* skipped) {
+                     unsigned* skipped, const unsigned* poison2, float* loss_slot) {
     if (n == 0) return 0;
     hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, g, mom, has_grad, n, lr,
-                       momentum, wd, first_step, grad_scale, poison, skipped);
+                       momentum, wd, first_step, grad_scale, poison, skipped, poison2, loss_slot);
     LAUNCH_OK("sgd_kernel");
     return 0;
 }

@@ -76,12 +76,16 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // dx = dres + rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat))
 // DYT: storage of the upstream gradient dy -- f32, or the activation storage type ST when it comes straight out of a
 // dX GEMM (bf16 in production: one rounding, half the bytes on both sides of this HBM-bound kernel)
-template <typename ST, typename DYT>
+// RES16 (round 5): the residual gradient arrives in the activation storage type (the bf16 copy of the gradient stream that the
+// dX GEMMs read anyway) instead of f32, and dx may be null -- the stream is then carried in bf16 only, read-modify-write in place
+// (dres == dx_bf16: every lane has all its loads in registers before its first store): 10 instead of 16 bytes per element.
+template <typename ST, typename DYT, bool RES16 = false>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy_, const float* __restrict__ x,
                                                      const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                      const float* __restrict__ gamma, const float* dres,
-                                                     float* dx, bf16* __restrict__ dx_bf16, int rows, int E, size_t xstride,
-                                                     const float* __restrict__ bscale, int res_period) {
+                                                     float* dx, bf16* dx_bf16, int rows, int E, size_t xstride,
+                                                     const float* __restrict__ bscale, int res_period,
+                                                     const float* __restrict__ rscale = nullptr) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -94,10 +98,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
     // trips per row), and the residual gradient, loaded between the stores, cost a fifth plus one store latency per group.
     float4 gd[MAXV], xh[MAXV], rs[MAXV], sc[MAXV], xv[MAXV], gv[MAXV];
     typename std::conditional<sizeof(DYT) == 2, bf16x4, float4>::type dv[MAXV];
+    bf16x4 rs16[MAXV];
+    float4 ru[MAXV];        // RES16 with fp8 weights: the power-of-two channel scales folded into the incoming bf16 stream (taken out again, exactly)
+    const float* usrc = (RES16 && rscale) ? rscale : gamma;
     bool ok[MAXV];
     // res_period > 0: the residual gradient is zero except on rows that are multiples of res_period (the class-token rows of the
     // last block, whose upstream gradient exists on those rows only): the other rows read nothing of it (row 0 stands in, dropped)
-    const float* rsrc = dres ? dres : x;
+    const float* rsrc = (dres && !RES16) ? dres : x;
+    const bf16* rsrc16 = reinterpret_cast<const bf16*>(dres);
     const bool has_res = dres != nullptr && (res_period <= 0 || row % res_period == 0);
     const size_t rb = has_res ? xb : 0;
     const bool scaled = dx_bf16 && bscale;
@@ -111,7 +119,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         else dv[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(dy_) + base + cc);
         xv[i] = *reinterpret_cast<const float4*>(x + xb + cc);
         gv[i] = *reinterpret_cast<const float4*>(gamma + cc);
-        rs[i] = *reinterpret_cast<const float4*>(rsrc + rb + cc);
+        if constexpr (RES16) { rs16[i] = *reinterpret_cast<const bf16x4*>(rsrc16 + rb + cc); ru[i] = *reinterpret_cast<const float4*>(usrc + cc); }
+        else rs[i] = *reinterpret_cast<const float4*>(rsrc + rb + cc);
         sc[i] = *reinterpret_cast<const float4*>(ssrc + cc);
     }
     float s1 = 0.f, s2 = 0.f;
@@ -125,6 +134,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         xh[i] = make_float4((xv[i].x - mean) * rstd, (xv[i].y - mean) * rstd, (xv[i].z - mean) * rstd, (xv[i].w - mean) * rstd);
         s1 += ok[i] ? gd[i].x + gd[i].y + gd[i].z + gd[i].w : 0.f;
         s2 += ok[i] ? gd[i].x * xh[i].x + gd[i].y * xh[i].y + gd[i].z * xh[i].z + gd[i].w * xh[i].w : 0.f;
+        if constexpr (RES16) {
+            rs[i] = make_float4(bf2f(rs16[i][0]), bf2f(rs16[i][1]), bf2f(rs16[i][2]), bf2f(rs16[i][3]));
+            if (rscale) {   // 1 / 2^k, exact: (254 << 23) - bits(2^k)
+                rs[i].x *= __int_as_float(0x7F000000 - __float_as_int(ru[i].x)); rs[i].y *= __int_as_float(0x7F000000 - __float_as_int(ru[i].y));
+                rs[i].z *= __int_as_float(0x7F000000 - __float_as_int(ru[i].z)); rs[i].w *= __int_as_float(0x7F000000 - __float_as_int(ru[i].w));
+            }
+        }
         rs[i] = has_res ? rs[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         sc[i] = scaled ? sc[i] : make_float4(1.f, 1.f, 1.f, 1.f);
     }
@@ -141,7 +157,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
             o.z = rstd * (gd[i].z - m1 - xh[i].z * m2);
             o.w = rstd * (gd[i].w - m1 - xh[i].w * m2);
             o.x += rs[i].x; o.y += rs[i].y; o.z += rs[i].z; o.w += rs[i].w;       // zeros without a residual gradient
-            *reinterpret_cast<float4*>(dx + xb + c) = o;
+            if (!RES16 || dx) *reinterpret_cast<float4*>(dx + xb + c) = o;
             if (dx_bf16) {
                 // fp8 weights: the consuming GEMM contracts over these columns; their power-of-two channel
                 // scales are folded into its bf16 operand here (exact: ones otherwise), the f32 stream stays unscaled
@@ -170,12 +186,18 @@ int pevit_launch_ln_fwd(const float* x, const float* gamma, const float* beta, i
 
 int pevit_launch_ln_bwd(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                         const float* dres, float* dx_out, bf16* dx_bf16, int rows, int E, hipStream_t s,
-                        size_t xstride, const float* bf16_colscale, int f32, int dy_stored, int res_period) {
+                        size_t xstride, const float* bf16_colscale, int f32, int dy_stored, int res_period, int res16,
+                        const float* res_colscale) {
     if (xstride == 0) xstride = (size_t)E;
     if (E % 4 != 0 || E > 256 * MAXV) { pevit_set_error("ln_bwd: unsupported width %d", E); return -1; }
     if (rows <= 0) return 0;
     const dim3 grid(ceil_div(rows, 4));
-    if (f32) hipLaunchKernelGGL((ln_bwd_kernel<float, float>), grid, dim3(256), 0, s, dy, x, mean, rstd, gamma, dres,
+    if (res16) {
+        if (f32 || !dy_stored || !dx_bf16) { pevit_set_error("ln_bwd: the bf16 residual form needs bf16 storage on both sides"); return -1; }
+        hipLaunchKernelGGL((ln_bwd_kernel<bf16, bf16, true>), grid, dim3(256), 0, s, dy, x, mean, rstd, gamma, dres,
+                           dx_out, dx_bf16, rows, E, xstride, bf16_colscale, res_period, res_colscale);
+    }
+    else if (f32) hipLaunchKernelGGL((ln_bwd_kernel<float, float>), grid, dim3(256), 0, s, dy, x, mean, rstd, gamma, dres,
                                 dx_out, dx_bf16, rows, E, xstride, bf16_colscale, res_period);
     else if (dy_stored) hipLaunchKernelGGL((ln_bwd_kernel<bf16, bf16>), grid, dim3(256), 0, s, dy, x, mean, rstd, gamma, dres,
                                            dx_out, dx_bf16, rows, E, xstride, bf16_colscale, res_period);

@@ -69,6 +69,11 @@ class FlatAllReduce:
             if p != self.rank:
                 _lib.check(self.lib.pevit_ar_import(self._ar, p, C.create_string_buffer(h, hb)), "pevit_ar_import")
         dist.barrier(group=group)                       # every mailbox is open everywhere before the first push
+        self.fine_grained = bool(self.lib.pevit_ar_fine_grained(self._ar))
+
+    def error_word(self):
+        """Device address of the error word (for engine / pevit_set_external_poison)."""
+        return self.lib.pevit_ar_error_word(self._ar)
 
     def all_reduce(self, buf: torch.Tensor, stream=None):
         """In place, asynchronous on ``stream`` (default: the current stream).  Same stream, same call order on every rank."""
@@ -79,20 +84,31 @@ class FlatAllReduce:
                             "pevit_allreduce_flat")
 
     def check(self, stream=None):
+        """Raise if a reduction gave up (synchronises ``stream``: pass the stream the all-reduces run on); clears the word."""
         s = self._C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
         rc = self.lib.pevit_ar_error(self._ar, s)
         if rc != 0:
-            raise self._lib_mod.PevitError("pevit_allreduce_flat: a peer's contribution never arrived (gradients of that step were "
-                                           "left unreduced)" if rc > 0 else "pevit_ar_error failed")
+            raise self._lib_mod.PevitError({1: "pevit_allreduce_flat: a peer's contribution never arrived (that bucket was left unreduced; "
+                                               "the optimizer update of the step was withheld if the engine holds the error word)",
+                                            2: "pevit_allreduce_flat: the ranks passed different sizes for the same all-reduce"}.get(
+                                               rc, "pevit_ar_error failed"))
 
-    def close(self):
+    def close(self, barrier: bool = True):
+        """Peers may still have pushes in flight into this mailbox: every rank drains its device and meets the others first
+        (a collective: call it on every rank; the finalizer skips the meeting, it cannot know the other ranks are there)."""
         if getattr(self, "_ar", None):
+            try:
+                torch.cuda.synchronize()
+                if barrier and dist.is_initialized():
+                    dist.barrier(group=self.group)
+            except Exception:
+                pass                                   # interpreter shutdown / a torn-down group: free anyway
             self.lib.pevit_ar_destroy(self._ar)
             self._ar = None
 
     def __del__(self):
         try:
-            self.close()
+            self.close(barrier=False)
         except Exception:
             pass
 

@@ -347,6 +347,8 @@ class HipEngine:
         withheld and every later check raises again until the caller acknowledges with ``clear_streamk_error()``."""
         word, skipped = C.c_uint(), C.c_uint()
         _lib.check(self.lib.pevit_streamk_status(self._ctx, _lib.stream_ptr(), C.byref(word), C.byref(skipped)), "pevit_streamk_status")
+        if getattr(self, "_flat_ar", None) is not None:       # the DP exchange's error word (updates were withheld on device while raised)
+            self._flat_ar.check(stream=self._flat_ar_stream)
         if word.value:
             raise _lib.PevitError(f"stream-K GEMM hand-off timed out: the logits / loss returned since are invalid and "
                                   f"{skipped.value} optimizer update(s) were withheld on device (parameters and momentum are those "
@@ -430,6 +432,9 @@ class HipEngine:
         from . import dp
         self._flat_ar = dp.FlatAllReduce(self.n_params, group=process_group, device=self.device)
         self._flat_ar_stream = torch.cuda.Stream(self.device)
+        # a bucket whose exchange gave up (a peer never arrived, sizes disagree) must not reach the parameters: the fused SGD
+        # kernel reads the all-reduce's error word next to the stream-K one and withholds the update while either is raised
+        _lib.check(self.lib.pevit_set_external_poison(self._ctx, C.c_void_p(self._flat_ar.error_word())), "pevit_set_external_poison")
         return self._flat_ar
 
     def _exchange(self, view, process_group):

@@ -65,7 +65,18 @@ def main():
     assert gn_f == gn_w and gn_f > 0, (gn_f, gn_w)
     rd = gf * 1024.0 / gn_f * read_factor
     wr = gw * 1024.0 / gn_w * write_factor
+    # every dispatch of the step (round 5): all kernels except the calibration casts, per train step (one sgd_kernel dispatch each)
+    def whole(stats, factor, cal_name):
+        steps = sum(c for k, (c, _) in stats.items() if k.startswith("sgd_kernel"))
+        n = sum(c for k, (c, _) in stats.items() if k != cal_name)
+        tot = sum(t for k, (_, t) in stats.items() if k != cal_name)
+        return steps, n, tot * 1024.0 * factor / max(steps, 1)
+    st_f, n_all, rd_all = whole(fetch, read_factor, cal_f[0])
+    st_w, _, wr_all = whole(write, write_factor, cal_w[0])
+    assert st_f == st_w and st_f > 0, (st_f, st_w)
     entry = {
+        "all_kernels": {"steps_profiled": st_f, "dispatches_per_step": n_all / st_f, "read_bytes_per_step": rd_all,
+                        "write_bytes_per_step": wr_all, "hbm_bytes_per_step": rd_all + wr_all},
         "gemm": {"launches_profiled": gn_f, "fetch_size_kib_per_launch_raw": gf / gn_f, "write_size_kib_per_launch_raw": gw / gn_w,
                  "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr},
         "calibration": {"kernel": "cast_f32_to_bf16 over 2^28 elements (1 GiB read, 0.5 GiB written)",
