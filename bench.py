@@ -155,11 +155,15 @@ def cpu_model():
 
 
 def kernels_hash():
-    """sha256 over the kernel sources the library is built from: a PMC pass is only valid for the kernels it profiled."""
+    """sha256 over the kernel sources the library is built from: a PMC pass is only valid for the kernels it profiled.
+    (allreduce.hip -- the DP exchange -- and verify.hip -- the f32 verification mode -- hold no kernel of the profiled single-GPU
+    bf16 step and are left out.)"""
     import hashlib
     d = os.path.join(ROOT, "pevit_amd", "csrc")
     h = hashlib.sha256()
     for name in sorted(os.listdir(d)):
+        if name in ("allreduce.hip", "verify.hip"):
+            continue
         if name.endswith((".hip", ".h")) or name == "Makefile":
             h.update(name.encode()); h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]
@@ -230,6 +234,9 @@ def main():
                     help="(N = 1) also time the step through engine.forward_backward_dp on a 1-rank RCCL group -- staged backward, "
                          "stream-K off, three asynchronous bucketed all-reduces -- and report it beside the fused step (dp_route)")
     ap.add_argument("--no-harness", action="store_true", help="skip the reference-API (train_one) throughput measurement")
+    ap.add_argument("--graph", action="store_true",
+                    help="(N = 1, measurement) time the step as ONE captured HIP graph replay (engine.capture_train_step) instead of the "
+                         "~200 launches of the C call; the line then carries step_launch = 'hip-graph'")
     ap.add_argument("--cpu-sweep", action="store_true", help="only time the CPU baseline at 8/16/32/64/128 threads and exit")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=INT",
                     help="library tuning knob for A/B runs, e.g. gemm_big=0 (see pevit_tune)")
@@ -326,6 +333,10 @@ def main():
 
     def step():
         return eng.train_step(images, labels, lr=0.01, momentum=0.9, weight_decay=1e-6, world_size=world)
+    eager_step = step
+    if args.graph and world == 1:
+        eager_step()                                   # the first step (no momentum yet) cannot be the captured one
+        step = eng.capture_train_step(images, labels, lr=0.01, momentum=0.9, weight_decay=1e-6)
 
     for _ in range(args.warmup):
         step()
@@ -358,6 +369,7 @@ def main():
     # ---- dominant kernel (MFMA GEMM family): HIP events around every GEMM launch, measured over
     # extra steps right after the timed region so that event recording does not perturb `value`.
     prof_steps = max(1, min(args.steps, 10))
+    step = eager_step                                  # the per-launch event passes below bracket individual launches: eager
     gemm_ms, gemm_flops, gemm_launches = eng.profile_gemms(lambda: [step() for _ in range(prof_steps)])
     gemm_by_shape = dict(eng.last_profile_by_shape)
     algo_bytes_total = eng.last_profile_bytes
@@ -454,6 +466,7 @@ def main():
                                    f"weights {args.weights}" + (" (e4m3 codes + per-channel scales, bf16 activations, f32 accumulate)"
                                                                  if args.weights == "fp8" else ""),
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                       "step_launch": "hip-graph replay" if (args.graph and world == 1) else "eager (one C call, ~200 kernel launches)",
                        "gradient_exchange": ("none" if world == 1 else args.exchange), "rccl_ranks": world if (world > 1 and args.dist_backend == "nccl") else 0,
                        "gradient_buckets": 0 if world == 1 else 3, "exchanged_floats_per_step": 0 if world == 1 else int(eng.n_params),
                        "train_gflop_per_image": gflop, "final_loss": final_loss},

@@ -325,6 +325,9 @@ int pevit_ar_error(pevit_ar* ar, void* stream);       /* 0 fine, 1 a peer never 
  * step's loss), as it does for a stream-K hand-off error; the word stays raised until pevit_ar_error clears it.
  * EXPERIMENTAL: exercised with 2 / 4 / 8 processes on ONE device only; the measured multi-GPU route is RCCL (torch.distributed). */
 const unsigned* pevit_ar_error_word(pevit_ar* ar);
+/* back to the initial protocol state (epoch 0, flags and error word cleared).  Collective by convention: every rank drains its device
+ * and meets the others BEFORE and AFTER this call (dp.FlatAllReduce.resync does both). */
+int pevit_ar_reset(pevit_ar* ar, void* stream);
 int pevit_ar_fine_grained(pevit_ar* ar);
 int pevit_set_external_poison(pevit_ctx* ctx, const unsigned* device_word);
 

@@ -22,8 +22,8 @@ Storage points reproduced (engine buffer -> here):
             class-token LayerNorm bf16 -> proj bf16      RoundSTE, LinearE
   backward  bf16 copy of the gradient stream (dyb)       every LinearE rounds its upstream gradient
             the residual gradient stream ITSELF bf16     RoundGrad at x_mid and at the block output (round 5; attention-site
-            (LayerNorm backward read-modify-writes dyb)  adapters on bf16 weights only: capi.hip gs16; the dx of the lowest block
-                                                         walked leaves in f32)
+            (LayerNorm backward read-modify-writes dyb)  and fused post-MLP adapters: capi.hip gstream16_on; the dx of the lowest
+                                                         block walked leaves in f32)
             dh = bf16(acc * gelu'(h))                    QuickGeluE.backward
             dxn2, dO, dxn1 bf16 (dX GEMM outputs)        LinearE(round_dx) / QKVAug.backward
             dS bf16, P bf16 for dV, delta = sum P dP (N <= 64) / from bf16 O    AttnCore.backward
@@ -327,6 +327,8 @@ def block(x, p, i, heads, method, wcache, tower="visual.transformer."):
         xn2 = _ln_b(x, p[pre + "ln_2.weight"], p[pre + "ln_2.bias"])
         return RoundGrad.apply(x + mlp_h(xn2, p, pre, wcache))
     x = x + stock_attention(xn, p, pre + "attn.", heads, wcache)
+    if method != "none":
+        x = RoundGrad.apply(x)                      # post-MLP adapters on their fused kernels: the stream is bf16 here too
     xn2 = _ln_b(x, p[pre + "ln_2.weight"], p[pre + "ln_2.bias"])
     h = mlp_h(xn2, p, pre, wcache)
     if method == "none":
@@ -342,7 +344,7 @@ def block(x, p, i, heads, method, wcache, tower="visual.transformer."):
         wu = _phm_weight(rule, p[a + "adapter_up.W_left"], p[a + "adapter_up.W_right"]).t()
         act = GeluNewE.apply(LinearTrain.apply(z, wd, p[a + "adapter_down.1.b"], False))
         up = LinearTrain.apply(act, wu, p[a + "adapter_up.b"], True)
-    return x + h + up
+    return RoundGrad.apply(x + h + up)
 
 
 def make_wcache(p):

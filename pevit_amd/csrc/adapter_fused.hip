@@ -399,7 +399,8 @@ __device__ __forceinline__ void af_tn_range(char* smem, int blk, int nblk, const
 // backward.  dyb: bf16 copy of dx_out (the operand of the products), dres: dx_out itself (f32).  Outputs: dpre (bf16 [T][64], feeds
 // the d W_down contraction), dh_bf16 = bf16(dres + LN_a'(d z)) (operand of the c_proj backward GEMM), partial[block][3][E] =
 // column sums of dz*xhat (d gamma), dz (d beta), dres (d b_up) over the block's rows (layout of ln_bwd_affine_kernel).
-template <int ACT>
+// RES16 (round 5, bf16 gradient stream): dx_out exists in bf16 only -- the residual and the d b_up column sums take it from dyb.
+template <int ACT, bool RES16 = false>
 __global__ __launch_bounds__(64 * AF_WAVES) void adapter_bwd_kernel(const bf16* __restrict__ dyb, const float* __restrict__ dres,
                                                                     const bf16* __restrict__ wuT, const bf16* __restrict__ saved,
                                                                     const bf16* __restrict__ wdT, const float* __restrict__ hraw,
@@ -473,7 +474,10 @@ __global__ __launch_bounds__(64 * AF_WAVES) void adapter_bwd_kernel(const bf16* 
 #pragma unroll
             for (int i = 0; i < AF_MAXV; ++i) {
                 xv[k][i] = *reinterpret_cast<const float4*>(hraw + (size_t)row * E + cc[i]);
-                rv[k][i] = *reinterpret_cast<const float4*>(dres + (size_t)row * E + cc[i]);
+                if constexpr (RES16) {
+                    const bf16x4 r16 = *reinterpret_cast<const bf16x4*>(dyb + (size_t)row * E + cc[i]);
+                    rv[k][i] = make_float4(bf2f(r16[0]), bf2f(r16[1]), bf2f(r16[2]), bf2f(r16[3]));
+                } else rv[k][i] = *reinterpret_cast<const float4*>(dres + (size_t)row * E + cc[i]);
             }
             mu[k] = mean_a[row]; rs[k] = rstd_a[row];
         }
@@ -607,14 +611,17 @@ int pevit_launch_adapter_bwd(int act_kind, const bf16* dyb, const float* dres, c
     const int ntn = min(ceil_div(tn.n1 + tn.n2, 2), tn_blocks > 0 ? tn_blocks : (1 << 30));
     const int lds = ntn ? max(L.colred, 2 * TNH_BYTES) : L.colred;
     const dim3 grid(nb + ntn), block(64 * AF_WAVES);
-    static bool attr[2] = {false, false};
-    if (act_kind == 0) {
-        if (!attr[0]) { if (af_attr(adapter_bwd_kernel<0>, 160 * 1024, "adapter_bwd")) return -1; attr[0] = true; }
-        hipLaunchKernelGGL(adapter_bwd_kernel<0>, grid, block, lds, s, dyb, dres, wuT, saved, wdT, hraw, bpr, mean_a, rstd_a, gamma, dpre, dh_bf16, partial, T, E, rb, nb, tn);
-    } else {
-        if (!attr[1]) { if (af_attr(adapter_bwd_kernel<1>, 160 * 1024, "adapter_bwd")) return -1; attr[1] = true; }
-        hipLaunchKernelGGL(adapter_bwd_kernel<1>, grid, block, lds, s, dyb, dres, wuT, saved, wdT, hraw, bpr, mean_a, rstd_a, gamma, dpre, dh_bf16, partial, T, E, rb, nb, tn);
-    }
+    static bool attr[4] = {false, false, false, false};
+    // dres == nullptr: the bf16 gradient stream (round 5) -- dx_out is read from dyb wherever the f32 copy was
+    auto go = [&](auto kern, int slot) -> int {
+        if (!attr[slot]) { if (af_attr(kern, 160 * 1024, "adapter_bwd")) return -1; attr[slot] = true; }
+        hipLaunchKernelGGL(kern, grid, block, lds, s, dyb, dres, wuT, saved, wdT, hraw, bpr, mean_a, rstd_a, gamma, dpre, dh_bf16, partial, T, E, rb, nb, tn);
+        return 0;
+    };
+    int rc;
+    if (act_kind == 0) rc = dres ? go(adapter_bwd_kernel<0, false>, 0) : go(adapter_bwd_kernel<0, true>, 2);
+    else rc = dres ? go(adapter_bwd_kernel<1, false>, 1) : go(adapter_bwd_kernel<1, true>, 3);
+    if (rc) return rc;
     LAUNCH_OK("adapter_bwd_kernel");
     return 0;
 }

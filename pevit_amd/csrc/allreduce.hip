@@ -67,10 +67,14 @@ __global__ __launch_bounds__(256) void ar_reduce_kernel(float* __restrict__ buf,
             unsigned why = 1u;
             for (int p = 0; p < world && good; ++p) {
                 if (p == rank) continue;
-                long long spins = 0;
+                long long spins = 0, torn = 0;
                 for (;;) {
                     const unsigned long long f = __hip_atomic_load(flags + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    if ((unsigned)(f & 0xffffffffu) == epoch) { if (f != want) { good = 0; why = 2u; } break; }   // same epoch, another n
+                    if (f == want) break;
+                    // this epoch with another n: either the 8-byte flag copy is landing dword by dword (seen with eight processes on
+                    // one device: the copy path does not write the pair atomically) -- it completes within microseconds -- or the
+                    // ranks really disagree: then it stays that way, and the wait ends after a grace period instead of the full bound
+                    if ((unsigned)(f & 0xffffffffu) == epoch && ++torn > 200000) { good = 0; why = 2u; break; }
                     __builtin_amdgcn_s_sleep(8);
                     if (++spins > spin_limit) { good = 0; break; }
                 }
@@ -214,6 +218,17 @@ extern "C" int pevit_allreduce_flat(pevit_ar* a, void* stream, float* buf, size_
                        reinterpret_cast<unsigned*>(a->base + a->off_dec) + par);
     LAUNCH_OK("ar_reduce_kernel");
     a->epoch = e;
+    return 0;
+}
+
+// After an error the ranks' epochs may be out of step for good (one rank refused a call the others made, a peer died and was
+// replaced): every rank drains its device and meets the others (the caller's job: a barrier on both sides of this call), then
+// calls this -- flags, verdict words, error word and the host epoch return to their initial state.
+extern "C" int pevit_ar_reset(pevit_ar* a, void* stream) {
+    if (!a) { pevit_set_error("ar_reset: null argument"); return -1; }
+    HIP_OK(hipMemsetAsync(a->base + a->off_flags, 0, a->bytes - a->off_flags, (hipStream_t)stream));
+    HIP_OK(hipStreamSynchronize((hipStream_t)stream));
+    a->epoch = 0;
     return 0;
 }
 

@@ -401,8 +401,12 @@ __global__ __launch_bounds__(64 * NW, (ALL4 ? ATT_BWD_MINW : 1)) void attn_bwd_k
     if constexpr (ALL4) {
         // delta of every query is in LDS before pass B reads it.  An LDS-only barrier: __syncthreads() would also wait (vmcnt(0))
         // for the dQ stores of pass A -- one store round trip per workgroup (tests/test_isa_hygiene.py)
+        // (the barrier intrinsic carries no memory semantics and a fence would bring the vmcnt(0) back: the compiler-only memory
+        // clobbers on both sides keep the del_s stores above and the del_s loads below from being moved across it)
+        asm volatile("" ::: "memory");
         __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (!ALL4) {

@@ -751,6 +751,14 @@ int blocks_forward(pevit_ctx* c, hipStream_t s, int B, bool cls_only, int l_lo =
 // Layers l_hi-1 .. l_lo are processed (the whole tower: L, 0) and the adapter gradients of exactly these layers are
 // reduced and chained onto the reference's tensors at the end -- data parallelism runs the tower in two halves so that
 // the all-reduce of the upper half's gradients overlaps the backward of the lower half.
+// the residual GRADIENT stream lives in bf16 only (pevit_ctx::gstream16): attention-site adapters, and the post-MLP adapters on
+// their fused kernels; bf16 / fp8 weights (never the f32 verification mode)
+bool gstream16_on(const pevit_ctx* c) {
+    if (!c->gstream16 || c->f32 || !c->dx_stored) return false;
+    if (attention_site(c)) return true;
+    return post_mlp(c) && c->adapter_fused && !c->fused_bn && pevit_adapter_fused_ok(c->E);
+}
+
 int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0, bool cls_only, int l_hi, int l_lo) {
     const int E = c->E, T = B * c->N, H = c->H, N = c->N;
     cls_only = cls_only && !post_mlp(c);
@@ -765,7 +773,7 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0, bool cls_
     const bool use_side = c->side_stream && site;
     bool side_pending = false;
     const bool combo = c->lowrank_combo && site && !c->f32 && !use_side;
-    const bool gs16 = c->gstream16 && site && !c->f32 && c->dx_stored;
+    const bool gs16 = gstream16_on(c);
     int prev_layer = -1, u_par = 0;
     float* u_last = nullptr;
     int tn_pend = -1, tn_par = 0;          // post-MLP adapters: layer whose d W_down product is still owed, and the d pre buffer in turn
@@ -800,7 +808,7 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0, bool cls_
                 // d pre, d z and the LayerNorm backward with its affine-gradient column sums in one launch (adapter_fused.hip); the
                 // forward pass left the c_proj accumulators WITHOUT their bias in hf32
                 PROF(c, s, PEVIT_PROF_ADAPTER_BWD, T, (double)T * E * (2 + 4 + 4 + 2) + (double)T * 64 * 4,
-                     pevit_launch_adapter_bwd(c->d.method == PEVIT_ADAPTER ? 0 : 1, dyb, dxa, at<bf16>(A, b.wuT),
+                     pevit_launch_adapter_bwd(c->d.method == PEVIT_ADAPTER ? 0 : 1, dyb, gs16 ? nullptr : dxa, at<bf16>(A, b.wuT),
                                               c->d.method == PEVIT_ADAPTER ? at<bf16>(W, v.act) : at<bf16>(W, v.apre), at<bf16>(A, b.wdT),
                                               at<float>(W, v.hf32), at<float>(A, b.bpr), at<float>(W, v.mean_a), at<float>(W, v.rstd_a),
                                               lp + c->o_nw, dpre, at<bf16>(W, c->w_dhb), at<float>(W, c->w_lnp + (size_t)l * c->lnp_layer), T, E, s,
@@ -976,8 +984,8 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0, bool cls_
         float* g0 = c->grads + pl0;
         float* Gd = at<float>(W, c->w_Gd) + (size_t)l_lo * gl;
         float* Gu = at<float>(W, c->w_Gu) + (size_t)l_lo * gl;
-        HIP_OK(hipMemsetAsync(Gd, 0, (size_t)nl * gl * 4, s));
-        HIP_OK(hipMemsetAsync(Gu, 0, (size_t)nl * gl * 4, s));
+        CHECK(pevit_launch_zero(Gd, (size_t)nl * gl * 4, s));
+        CHECK(pevit_launch_zero(Gu, (size_t)nl * gl * 4, s));
         CHECK(pevit_launch_colsum_reduce(at<float>(W, c->w_tnD + (size_t)l_lo * c->tn_layer), tch, (int)gl, Gd, nl, c->tn_layer / 4, gl, s));
         CHECK(pevit_launch_colsum_reduce(at<float>(W, c->w_tnU + (size_t)l_lo * c->tn_layer), tch, (int)gl, Gu, nl, c->tn_layer / 4, gl, s));
         // biases and LayerNorm affine: straight column sums into the flat gradient buffer
@@ -1049,7 +1057,7 @@ extern "C" int pevit_transformer_backward(pevit_ctx* c, void* stream, const floa
 
 extern "C" int pevit_zero_grads(pevit_ctx* c, void* stream) {
     if (!c || !c->grads) { pevit_set_error("zero_grads: parameters not set"); return -1; }
-    HIP_OK(hipMemsetAsync(c->grads, 0, c->n_total * sizeof(float), (hipStream_t)stream));
+    CHECK(pevit_launch_zero(c->grads, c->n_total * sizeof(float), (hipStream_t)stream));
     return 0;
 }
 
@@ -1191,10 +1199,10 @@ extern "C" int pevit_visual_backward_part(pevit_ctx* c, void* stream, const floa
         if (cls) {
             // ... or not read at all: LayerNorm backward takes the residual gradient on the class-token rows only (res_period), and
             // the attention backward for N <= 64 reads dO on token 0 only (dout_cls_only) -- no fill of dxb (19.7 MB) / dO (9.8 MB)
-            if (c->f32 || N > 64) HIP_OK(hipMemsetAsync(W + c->w_dO, 0, (size_t)T * E * c->es, s));
+            if (c->f32 || N > 64) CHECK(pevit_launch_zero(W + c->w_dO, (size_t)T * E * c->es, s));
         } else {
-            HIP_OK(hipMemsetAsync(W + c->w_dxa, 0, (size_t)T * E * 4, s));
-            HIP_OK(hipMemsetAsync(W + c->w_dyb, 0, (size_t)T * E * c->es, s));
+            if (!gstream16_on(c)) CHECK(pevit_launch_zero(W + c->w_dxa, (size_t)T * E * 4, s));      // (the bf16 stream never reads the f32 copy)
+            CHECK(pevit_launch_zero(W + c->w_dyb, (size_t)T * E * c->es, s));
         }
         CHECK(pevit_launch_ln_bwd(at<float>(W, c->w_dxpost), at<float>(W, c->w_xfinal), at<float>(W, c->w_pmean),
                                   at<float>(W, c->w_prstd), at<float>(A, c->a_lnpost_w), nullptr, at<float>(W, c->w_dxa),

@@ -551,7 +551,6 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmParams p, int ntiles)
         for (int kt = 0; kt < nk; ++kt) {
             const char* st = smem + (kt & 1) * STAGE_BYTES;
             const bool more = kt + 1 < nk;
-            i32x4 braw[WN][2];                                    // fp8: this lane's 32 codes of the k-tile per fragment column
 #pragma unroll
             for (int ph = 0; ph < NPH; ++ph) {
                 // ---- LOAD
@@ -578,23 +577,22 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmParams p, int ntiles)
                         }
                     }
                 } else {
-                if constexpr (BF8) {
-                    if (ph == 0 && !PANEL) {
-                        const char* sb = smem + ((kt >> 1) & 1) * STAGE_BYTES;
-                        const int c0 = (kt & 1) * 4 + fhalf * 2;
-#pragma unroll
-                        for (int j = 0; j < WN; ++j) {
-                            braw[j][0] = *reinterpret_cast<const i32x4*>(sb + b_base + j * 32 * ROWB + ((c0 ^ fswz) << 4));
-                            braw[j][1] = *reinterpret_cast<const i32x4*>(sb + b_base + j * 32 * ROWB + (((c0 + 1) ^ fswz) << 4));
-                        }
-                    }
-                }
+                // fp8 B (round 5): the 8 codes of this lane for k-step ks are read where they are converted, one 8-byte read per
+                // fragment column and k-step.  (Rounds 3-4 fetched the lane's 32 codes of the whole k-tile in phase 0 and kept them:
+                // 16 more live registers pushed the 320x256 / 256x256 kernels to 256 VGPRs + 64 bytes of scratch in the k-loop, and
+                // the fp8 form of every K = E product ran 4-7 us behind its bf16 form at ViT-L/14.)
 #pragma unroll
                 for (int s = 0; s < KSP; ++s) {
                     const int ks = ph * KSP + s;
 #pragma unroll
                     for (int j = 0; j < WN; ++j) {
-                        if constexpr (BF8 && !PANEL) bfr[s][j] = fp8x8_to_bf16(braw[j][ks >> 1][(ks & 1) * 2], braw[j][ks >> 1][(ks & 1) * 2 + 1]);
+                        if constexpr (BF8 && !PANEL) {
+                            typedef __attribute__((ext_vector_type(2))) int i32x2;
+                            const char* sb = smem + ((kt >> 1) & 1) * STAGE_BYTES;
+                            const int c0 = (kt & 1) * 4 + fhalf * 2 + (ks >> 1);
+                            const i32x2 raw = *reinterpret_cast<const i32x2*>(sb + b_base + j * 32 * ROWB + ((c0 ^ fswz) << 4) + (ks & 1) * 8);
+                            bfr[s][j] = fp8x8_to_bf16(raw[0], raw[1]);
+                        }
                         else bfr[s][j] = *reinterpret_cast<const bf16x8*>(st + b_base + j * 32 * ROWB + coff[ks]);
                     }
 #pragma unroll

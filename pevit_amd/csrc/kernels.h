@@ -163,6 +163,7 @@ int pevit_launch_transpose_bf16(const float* src, int rows, int cols, bf16* dst,
 int pevit_launch_permute_rows(const float* src, float* dst, int N, int B, int E, int to_internal,
                               hipStream_t s);
 int pevit_launch_scale_f32(float* p, size_t n, float scale, hipStream_t s);
+int pevit_launch_zero(void* ptr, size_t bytes, hipStream_t s);      // the step's memsets as a kernel (capturable in order into a HIP graph)
 int pevit_launch_sgd(float* p, const float* g, float* mom, const unsigned char* has_grad, size_t n,
                      float lr, float momentum, float wd, int first_step, float grad_scale, hipStream_t s,
                      const unsigned* poison = nullptr,    // device word: non-zero = skip the update (stream-K hand-off error)

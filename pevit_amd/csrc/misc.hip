@@ -53,6 +53,15 @@ __global__ void scale_f32_kernel(float* p, size_t n, float scale) {
     if (i < n) p[i] *= scale;
 }
 
+// zero-fill (16 bytes per lane, grid-stride): the step's own memsets.  hipMemsetAsync would do the same work, but as a memset NODE
+// of a captured HIP graph it did not keep its place among the kernels of the step (engine.capture_train_step: the gradient
+// buffer was not clear when the chain kernels accumulated into it from the second replay on); a kernel node does.
+__global__ __launch_bounds__(256) void zero_fill_kernel(uint4* __restrict__ p, size_t n16, unsigned char* __restrict__ tail, int ntail) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) p[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0;
+}
+
 __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ mom,
                            const unsigned char* __restrict__ has_grad, size_t n, float lr, float momentum, float wd,
                            int flags, float grad_scale, const unsigned* __restrict__ poison, unsigned* skipped,
@@ -131,6 +140,20 @@ int pevit_launch_permute_rows(const float* src, float* dst, int N, int B, int E,
     if (E % 4) { pevit_set_error("permute_rows: width %d must be a multiple of 4", E); return -1; }
     hipLaunchKernelGGL(permute_rows_kernel, dim3(N * B), dim3(192), 0, s, src, dst, N, B, E, to_internal);
     LAUNCH_OK("permute_rows_kernel");
+    return 0;
+}
+
+int pevit_launch_zero(void* ptr, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return 0;
+    if (reinterpret_cast<size_t>(ptr) & 15) { pevit_set_error("zero: the buffer must be 16-byte aligned"); return -1; }
+    const size_t n16 = bytes / 16;
+    const int ntail = (int)(bytes - n16 * 16);
+    size_t blocks = (n16 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<uint4*>(ptr), n16,
+                       reinterpret_cast<unsigned char*>(ptr) + n16 * 16, ntail);
+    LAUNCH_OK("zero_fill_kernel");
     return 0;
 }
 

@@ -93,6 +93,13 @@ class FlatAllReduce:
                                             2: "pevit_allreduce_flat: the ranks passed different sizes for the same all-reduce"}.get(
                                                rc, "pevit_ar_error failed"))
 
+    def resync(self):
+        """After an error (check() raised): bring every rank's protocol state back to the start.  Collective."""
+        torch.cuda.synchronize()
+        dist.barrier(group=self.group)
+        self._lib_mod.check(self.lib.pevit_ar_reset(self._ar, self._C.c_void_p(torch.cuda.current_stream().cuda_stream)), "pevit_ar_reset")
+        dist.barrier(group=self.group)
+
     def close(self, barrier: bool = True):
         """Peers may still have pushes in flight into this mailbox: every rank drains its device and meets the others first
         (a collective: call it on every rank; the finalizer skips the meeting, it cannot know the other ranks are there)."""

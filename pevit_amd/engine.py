@@ -426,6 +426,44 @@ class HipEngine:
         self.sgd_step(lr, momentum, weight_decay, 1.0 / world_size, nesterov)
         return logits, loss
 
+    # ---- whole-step HIP graph -----------------------------------------------------
+    def capture_train_step(self, images, labels, lr, momentum=0.9, weight_decay=0.0, bn_training=True, nesterov=False):
+        """Capture ``forward_backward + sgd_step`` on THESE buffers (pointers, batch, hyper-parameters and BatchNorm mode are baked
+        in) into a HIP graph and return a callable that replays it: one hipGraphLaunch instead of ~200 kernel launches from the
+        C call.  The step counter, the periodic error-word check and the results (``self._logits``, ``self._loss``) behave as in
+        ``train_step``.  At least one eager step must have run (the first SGD step has no momentum buffer to read, and the
+        library's one-time attribute calls are not stream operations).  Same kernels, same order: bit-identical to eager
+        (tests/test_gpu_mirror.py::test_graph_replay_equals_eager).  Measured: profiles/r05_graph_capture.md."""
+        if self._steps == 0:
+            raise _lib.PevitError("capture_train_step: run one eager train_step first (first-step flag, one-time kernel attributes)")
+        B = images.shape[0]
+        self._check_batch(images, labels)
+        fn = self.lib.pevit_train_forward_backward_u8 if images.dtype == torch.uint8 else self.lib.pevit_train_forward_backward
+        flags = 2 if nesterov else 0
+        logits, loss = self._logits[:B], self._loss
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream(self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+                _lib.check(fn(self._ctx, _lib.stream_ptr(), _lib.ptr(images), _lib.ptr(labels), _lib.ptr(self.running_mean),
+                              _lib.ptr(self.running_var), int(bn_training), _lib.ptr(logits), _lib.ptr(loss), B),
+                           "pevit_train_forward_backward (capture)")
+                _lib.check(self.lib.pevit_sgd_step(self._ctx, _lib.stream_ptr(), lr, momentum, weight_decay, 1.0, flags),
+                           "pevit_sgd_step (capture)")
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        keep = (images, labels)                     # the graph reads these addresses on every replay
+
+        def replay():
+            self.forward_generation += 1
+            graph.replay()
+            if self._steps % self.STREAMK_CHECK_EVERY == 0:
+                self.check_streamk()
+            self._steps += 1
+            return logits, loss
+        replay.graph, replay.buffers = graph, keep
+        return replay
+
     def use_flat_allreduce(self, process_group=None):
         """Exchange the gradient buckets with pevit_allreduce_flat (dp.FlatAllReduce: IPC-mapped peer mailboxes, copy-engine
         pushes, deterministic local reduction on a side stream) instead of the process group's all-reduce."""

@@ -167,6 +167,7 @@ class ClassifierBase(nn.Module):
         self.optim = None
         self.l2_lambda = l2_lambda
         self.channel_bn = nn.BatchNorm1d(input_dim, affine=False)
+        self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: module.flush_bn_counter())
         self.layers = nn.Sequential(nn.Linear(input_dim, output_dim))
         dev = self.backbone.logit_scale.device
         self.channel_bn.to(dev); self.layers.to(dev)
@@ -299,7 +300,10 @@ class ClassifierBase(nn.Module):
             loss = loss.clone()
         return logits, loss
 
-    def flush_bn_counter(self):
+    def flush_bn_counter(self, *_):
+        """Fold the fused steps counted since the last flush into ``channel_bn.num_batches_tracked`` (train_one does it at the end
+        of an epoch, also when the epoch raises; ``state_dict()`` does it first, so a checkpoint taken mid-epoch -- or after direct
+        calls of ``fused_train_step`` -- carries the reference BatchNorm1d's counter)."""
         n = getattr(self, "_bn_steps", 0)
         if n and isinstance(self.channel_bn, nn.BatchNorm1d):
             self.channel_bn.num_batches_tracked += n
@@ -465,36 +469,38 @@ def train_one(train_loader, model, criterion, optimizer, epoch, config):
         loss_buf = torch.empty((len(train_loader) + 1,), dtype=torch.float32, device=out_buf.device)
     row = step = 0
     end = time.time()
-    for images, target in (DeviceFeeder(train_loader, dev) if single else ((b[0], b[1]) for b in train_loader)):
-        data_time.update(time.time() - end)
-        if images.shape[0] == 1:
-            continue                                      # BatchNorm cannot take a single-sample batch (reference :341)
-        if target.shape[-1] == 1:
-            target = target[:, 0]
-        if not target.is_cuda:
-            target = target.cuda(dev, non_blocking=True)
+    try:     # the fused step counts its BatchNorm batches host-side: folded into num_batches_tracked whatever ends the epoch
+        for images, target in (DeviceFeeder(train_loader, dev) if single else ((b[0], b[1]) for b in train_loader)):
+            data_time.update(time.time() - end)
+            if images.shape[0] == 1:
+                continue                                      # BatchNorm cannot take a single-sample batch (reference :341)
+            if target.shape[-1] == 1:
+                target = target[:, 0]
+            if not target.is_cuda:
+                target = target.cuda(dev, non_blocking=True)
 
-        if fused and target.dim() == 1 and target.dtype == torch.int64:
-            n = images.shape[0]
-            direct = out_buf is not None and row + n <= out_buf.shape[0] and step < loss_buf.shape[0]
-            output, loss = model.fused_train_step(images, target, optimizer,
-                                                  out_buf[row:row + n] if direct else None,
-                                                  loss_buf[step:step + 1] if direct else None)
-            row += n if direct else 0
-            step += 1 if direct else 0
-        else:
-            optimizer.zero_grad()
-            output = model.forward(images)
-            loss = criterion(output, target)
-            loss.backward()
-            optimizer.step()
-        step_losses.append(loss.detach().reshape(1)); step_sizes.append(images.size(0))
-        outputs.append(output.detach())
-        targets.append(target)
-        batch_time.update(time.time() - end)
-        end = time.time()
-    if fused:
-        model.flush_bn_counter()
+            if fused and target.dim() == 1 and target.dtype == torch.int64:
+                n = images.shape[0]
+                direct = out_buf is not None and row + n <= out_buf.shape[0] and step < loss_buf.shape[0]
+                output, loss = model.fused_train_step(images, target, optimizer,
+                                                      out_buf[row:row + n] if direct else None,
+                                                      loss_buf[step:step + 1] if direct else None)
+                row += n if direct else 0
+                step += 1 if direct else 0
+            else:
+                optimizer.zero_grad()
+                output = model.forward(images)
+                loss = criterion(output, target)
+                loss.backward()
+                optimizer.step()
+            step_losses.append(loss.detach().reshape(1)); step_sizes.append(images.size(0))
+            outputs.append(output.detach())
+            targets.append(target)
+            batch_time.update(time.time() - end)
+            end = time.time()
+    finally:
+        if fused:
+            model.flush_bn_counter()
 
     if not outputs:
         return

@@ -67,9 +67,10 @@ def main():
     wr = gw * 1024.0 / gn_w * write_factor
     # every dispatch of the step (round 5): all kernels except the calibration casts, per train step (one sgd_kernel dispatch each)
     def whole(stats, factor, cal_name):
-        steps = sum(c for k, (c, _) in stats.items() if k.startswith("sgd_kernel"))
-        n = sum(c for k, (c, _) in stats.items() if k != cal_name)
-        tot = sum(t for k, (_, t) in stats.items() if k != cal_name)
+        steps = sum(c for k, (c, _) in stats.items() if "sgd_kernel" in k)
+        mine = lambda k: k != cal_name and "Cijk_" not in k      # not the calibration casts, not bench.py's vendor-GEMM side measurement
+        n = sum(c for k, (c, _) in stats.items() if mine(k))
+        tot = sum(t for k, (_, t) in stats.items() if mine(k))
         return steps, n, tot * 1024.0 * factor / max(steps, 1)
     st_f, n_all, rd_all = whole(fetch, read_factor, cal_f[0])
     st_w, _, wr_all = whole(write, write_factor, cal_w[0])

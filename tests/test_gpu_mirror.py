@@ -499,3 +499,61 @@ def test_device_feeder_uploads_host_batches_ahead_and_changes_nothing(ckpt):
     for other in finals[1:]:
         assert other[0] == finals[0][0] and other[1] == finals[0][1] and torch.equal(other[2], finals[0][2])
     assert finals[0][3] == 6
+
+
+def test_state_dict_mid_epoch_carries_the_bn_counter(ckpt):
+    """fused_train_step counts its BatchNorm batches host-side and folds them into num_batches_tracked lazily; state_dict() (a
+    checkpoint taken mid-epoch, or after direct calls outside train_one) flushes first, and an epoch that raises flushes too."""
+    meta, t = load_golden("tiny_kadaptation")
+    mod, cfg, clf = seeded_classifier("kadaptation", ckpt, meta, t)
+    opt = mod.build_optimizer(cfg, clf)
+    crit = torch.nn.CrossEntropyLoss().cuda(0)
+    assert clf.can_fuse(crit, opt)
+    images, labels = t["images"].cuda(), t["labels"].cuda()
+    for _ in range(3):
+        clf.fused_train_step(images, labels, opt)
+    assert int(clf.state_dict()["channel_bn.num_batches_tracked"]) == 3
+
+    class Boom(OneBatch):
+        def __iter__(self):
+            yield self.batch
+            yield self.batch
+            raise RuntimeError("loader died")
+    with pytest.raises(RuntimeError, match="loader died"):
+        mod.train_one(Boom(t["images"], t["labels"], 4), clf, crit, opt, 0, cfg)
+    assert int(clf.channel_bn.num_batches_tracked) == 5
+
+
+def test_graph_replay_equals_eager():
+    """engine.capture_train_step: the whole step (zero_grad, forward, head + loss, backward, SGD) as ONE HIP graph replay --
+    same kernels in the same order as the eager C call, so parameters, momentum, BatchNorm buffers, logits and loss are identical
+    bit for bit after every step."""
+    from pevit_amd.engine import HipEngine, adapter_param_spec
+    from pevit_amd.synth import ARCHS, randomize_adapters, synth_batch, synth_state_dict
+    arch, method, B, C = ARCHS["tiny-128"], "kadaptation", 8, 10
+    sd = {k: v for k, v in synth_state_dict(arch, seed=2, text_tower=False).items() if k.startswith("visual.")}
+    ad = [(n, torch.zeros(s)) for n, s, _ in adapter_param_spec(method, arch.width, arch.layers)]
+    randomize_adapters(ad, seed=3); sd.update(dict(ad))
+    images, labels = synth_batch(B, arch.resolution, C)
+    images, labels = images.cuda(), labels.cuda()
+    engs = []
+    for _ in range(2):
+        e = HipEngine(arch, method, C, B)
+        e.load_state_dict(sd)
+        torch.nn.init.normal_(e.param_views()["layers.0.weight"], std=0.05, generator=torch.Generator(device="cuda").manual_seed(1))
+        engs.append(e)
+    eager, graphed = engs
+    graphed.params.copy_(eager.params)
+    for e in engs:
+        e.train_step(images, labels, lr=0.05, momentum=0.9, weight_decay=1e-4)
+    replay = graphed.capture_train_step(images, labels, lr=0.05, momentum=0.9, weight_decay=1e-4)
+    for step in range(4):
+        l0, s0 = eager.train_step(images, labels, lr=0.05, momentum=0.9, weight_decay=1e-4)
+        l1, s1 = replay()
+        torch.cuda.synchronize()
+        assert torch.equal(l0, l1) and torch.equal(s0, s1), step
+        for a, b in ((eager.params, graphed.params), (eager.momentum, graphed.momentum), (eager.grads, graphed.grads),
+                     (eager.running_mean, graphed.running_mean), (eager.running_var, graphed.running_var)):
+            assert torch.equal(a, b), step
+    with pytest.raises(Exception, match="eager train_step first"):
+        HipEngine(arch, method, C, B).capture_train_step(images, labels, lr=0.05)
