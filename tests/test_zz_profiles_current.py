@@ -25,5 +25,6 @@ def test_the_committed_pmc_pass_was_taken_with_these_kernel_sources():
         "profiles/hbm_traffic.json was measured on other kernel sources than pevit_amd/csrc/ holds now: "
         "re-run scripts/run_pmc_passes.sh on the GPU box and commit the refreshed profiles/")
     assert entry["gemm"]["hbm_bytes_per_launch"] > 0
-    traffic, how = bench.pmc_traffic("ViT-B/32", "kadaptation", 128)
+    traffic, how, traffic_all = bench.pmc_traffic("ViT-B/32", "kadaptation", 128)
     assert traffic == entry["gemm"]["hbm_bytes_per_launch"], how
+    assert traffic_all == entry["all_kernels"]["hbm_bytes_per_step"] and traffic_all > 98 * traffic      # every dispatch of a step >= its 98 GEMMs
