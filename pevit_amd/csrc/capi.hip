@@ -110,6 +110,8 @@ struct pevit_ctx {
     // A/B-measurement knobs (pevit_tune): per context, so that contexts stay independent of each other
     GemmTune tune;
     const unsigned* ext_poison = nullptr;   // pevit_set_external_poison: a second error word that withholds the optimizer update (the DP exchange's)
+    bool in_fused_step = false;
+    const float* dfeatb_of = nullptr;       // the dfeat buffer whose bf16 copy the head's BatchNorm backward has just left in w_dfeatb (consumed by the next visual backward)
     float* last_loss = nullptr;             // where the loss of the step in flight was written (NaN goes there when its update is withheld)
     int gstream16 = 1;        // attention-site adapters, bf16 weights: the residual GRADIENT stream is carried in bf16 only (the copy the dX GEMMs read), LayerNorm backward read-modify-writes it in place: 10 instead of 16 B per element (round 5)
     int dx_stored = 1;        // dX GEMMs hand the LN-input gradient to LayerNorm backward in the activation storage type (bf16)
@@ -894,7 +896,7 @@ int blocks_backward(pevit_ctx* c, hipStream_t s, int B, bool need_dx0, bool cls_
                                             at<float>(W, v.attn_out), E, at<float>(W, c->w_dO), E, at<float>(W, v.lse), (float*)dqkv,
                                             c->NQ, B, H, N, s));
         else
-            PROF(c, s, PEVIT_PROF_ATTN_BWD, T, (double)T * E * 8 * 2 + (double)B * H * N * 4,     // q, k, v, out, dout in; dq, dk, dv out
+            PROF(c, s, PEVIT_PROF_ATTN_BWD, T, (double)T * E * (N <= 64 ? 7 : 8) * 2 + (double)B * H * N * 4,     // q, k, v, (out: N > 64 only), dout in; dq, dk, dv out
                  pevit_launch_attn_bwd(qkv, qkv + plane, qkv + 2 * plane, at<bf16>(W, v.attn_out), E, at<bf16>(W, c->w_dO), E,
                                        at<float>(W, v.lse), dqkv, c->NQ, B, H, N, s, (cls && N <= 64) ? 1 : 0));
         if (site && combo) {
@@ -1187,7 +1189,9 @@ extern "C" int pevit_visual_backward_part(pevit_ctx* c, void* stream, const floa
     const bool cls = !post_mlp(c);
     if (l_hi == c->L) {
         if (!dfeat) { pevit_set_error("visual_backward: dfeat is required for the part that starts at the last block"); return -1; }
-        CHECK(pevit_launch_cast_bf16(dfeat, at<bf16>(W, c->w_dfeatb), (size_t)B * c->D, 1.0f, s, c->f32));
+        // (the head's BatchNorm backward leaves the bf16 copy of ITS dfeat in w_dfeatb: no cast launch then)
+        if (c->dfeatb_of != dfeat) CHECK(pevit_launch_cast_bf16(dfeat, at<bf16>(W, c->w_dfeatb), (size_t)B * c->D, 1.0f, s, c->f32));
+        c->dfeatb_of = nullptr;
         {
             GemmParams p = gp(at<bf16>(W, c->w_dfeatb), c->D, at<bf16>(A, c->a_projT), c->D, E, B, E, c->D);
             p.outf = at<float>(W, c->w_dxpost); p.ldo = E;
@@ -1231,10 +1235,13 @@ extern "C" int pevit_head_forward_backward(pevit_ctx* c, void* stream, const flo
     char* W = c->ws;
     if (c->saved_batch == 0) { size_t total; layout_workspace(c, B, c->sav, &total, c); }
     if (labels) c->last_loss = loss;
+    // only inside the fused step (train_fb_impl): there nobody can touch dfeat between the head and the tower backward
+    bf16* dfb = (c->in_fused_step && dfeat && labels && !c->f32) ? at<bf16>(W, c->w_dfeatb) : nullptr;
+    c->dfeatb_of = dfb ? dfeat : nullptr;
     return pevit_launch_head(feat, labels, c->params + c->p_head_w, c->params + c->p_head_b,
                              labels ? c->grads + c->p_head_w : nullptr, labels ? c->grads + c->p_head_b : nullptr,
                              running_mean, running_var, bn_training, at<float>(W, c->w_ybn), at<float>(W, c->w_bnrstd),
-                             logits, at<float>(W, c->w_dlogits), at<float>(W, c->w_dybn), loss, dfeat, B, c->D, c->C, s);
+                             logits, at<float>(W, c->w_dlogits), at<float>(W, c->w_dybn), loss, dfeat, B, c->D, c->C, s, dfb);
 }
 
 static int train_fb_impl(pevit_ctx* c, void* stream, const void* images, int u8, const int64_t* labels, float* running_mean,
@@ -1257,8 +1264,10 @@ static int train_fb_impl(pevit_ctx* c, void* stream, const void* images, int u8,
     CHECK(visual_forward_impl(c, stream, images, u8, nullptr, B, 1));
     float* feat = at<float>(c->ws, c->w_feat);
     float* dfeat = at<float>(c->ws, c->w_dfeat);
-    CHECK(pevit_head_forward_backward(c, stream, feat, labels, running_mean, running_var, bn_training, logits, loss,
-                                      dfeat, B));
+    c->in_fused_step = true;
+    const int hrc = pevit_head_forward_backward(c, stream, feat, labels, running_mean, running_var, bn_training, logits, loss, dfeat, B);
+    c->in_fused_step = false;
+    if (hrc) { c->dfeatb_of = nullptr; return hrc; }
     CHECK(pevit_visual_backward(c, stream, dfeat, B));
     return 0;
 }

@@ -14,7 +14,7 @@
 //     (N = 768 products of the ViT-B step: 300-600 tiles for 256 CUs);
 //   * 8 waves (2x4 / 4x2), tiles 256x128 .. 320x256, ONE workgroup per CU: every k-tile moves
 //     (BM+BN)*128 bytes through the CU's L1 for 2*BM*BN*64 flops, half the bytes per flop of the
-//     128x128 tile.  The L2 -> LDS operand stream (~23 B/clk/CU, profiles/r01_l2_fetch_bound.md) is
+//     128x128 tile.  The L2 -> LDS operand stream (~23 B/clk/CU, profiles/NOTES_gemm.md (r01_l2_fetch_bound)) is
 //     what bounds these GEMMs, so the large tile is the lever wherever the tile count still fills
 //     the chip (N >= 2304 at M = 6400).
 // Operands are staged HBM->LDS with 16-byte LDS-DMA (global_load_lds), double buffered,
@@ -190,13 +190,13 @@ __global__ __launch_bounds__(WGM * WGN * 64, MINW) void gemm_kernel(GemmParams p
         // per group of WN MFMAs): a wave issues in order, and a CU accepts only ~64 outstanding 128-byte requests, so
         // a burst of PA+PB requests at the top of the iteration parks every wave in its issue slot until the burst has
         // drained -- the k-loop then runs load + compute instead of max(load, compute) (measured: 320x256 tile,
-        // 5200 clk per k-tile against 2560 of MFMA and ~3100 of stream; profiles/r02_gemm_experiments.md).
+        // 5200 clk per k-tile against 2560 of MFMA and ~3100 of stream; profiles/NOTES_gemm.md (r02_gemm_experiments)).
         auto k_tile = [&](int kt, auto issue_next) {
             constexpr bool ISSUE = decltype(issue_next)::value;
             constexpr int NG = KS * WM, NP = PA + PB;       // MFMA groups per k-tile, pieces per wave
             // ... and only between the groups of the FIRST HALF of the k-tile: a request issued late in the iteration is
             // still in flight at the top of the next one (the windows 3 ... 10 of 20 groups all measure +1.0-1.4 % per step
-            // over the full spread; profiles/r02_gemm_experiments.md section 16)
+            // over the full spread; profiles/NOTES_gemm.md (r02_gemm_experiments) section 16)
             constexpr int SPREAD_NG = NG / 2 > 0 ? NG / 2 : 1;
 #ifdef GEMM_STREAM_FREE   // measurement build only (scripts/build_variants.sh): the stream-only ablation issues without waiting
             if (!GEMM_DBG(p, 8)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, MINW) void gemm_kernel(GemmParams p
 // two-group schedule (round 3).  In gemm_kernel above hipcc serialises every pair of MFMAs behind a ds_read_b128 it has just
 // issued (one fragment register set, re-used: the 160 accumulator registers leave room for nothing else), all eight waves
 // cross the k-tile barrier together, read together and compute together: "compute only" that loop keeps the matrix pipe 46 %
-// busy (profiles/r02_gemm_experiments.md section 1).  Here a k-tile is cut into phases of KSP k-steps; in a phase a wave
+// busy (profiles/NOTES_gemm.md (r02_gemm_experiments) section 1).  Here a k-tile is cut into phases of KSP k-steps; in a phase a wave
 //     LOAD : reads ALL its fragments of the phase (KSP * (WM + 2) ds_read_b128), requests its share of the next k-tile
 //            (LDS-DMA), waits for its reads                                          -> s_barrier
 //     MFMA : KSP * WM * 2 MFMAs back to back at raised priority                      -> s_barrier
@@ -973,7 +973,7 @@ __global__ __launch_bounds__(256, 2) void gemm_streamk_kernel(GemmParams p, int 
 // (tile, slice) with a FOUR-stage ring and exact vmcnt waits; the 128x64 f32 partial goes to a slab (write-through stores) and
 // the workgroup that draws the LAST ticket of its tile adds the slabs in slice order -- a fixed order, so the result does not
 // depend on who arrives last -- and runs the epilogue.  Nobody waits for anybody: no residency requirement.
-// Bounds (measured, profiles/r03_gemm_experiments.md 5c): one CU moves ~60 GB/s, so both the k-walk of a workgroup and the
+// Bounds (measured, profiles/NOTES_gemm.md (r03_gemm_experiments) 5c): one CU moves ~60 GB/s, so both the k-walk of a workgroup and the
 // slabs its tile's finisher re-reads must stay at a few hundred KB: 16 slices of 3 k-tiles made the finisher read 1 MB (27 us).
 // Slabs and ticket words are the stream-K workspace (GemmParams::sk_slab / sk_flag; tickets return to 0).
 template <int EPI>
@@ -1178,14 +1178,14 @@ __device__ __forceinline__ void ksplit_finish(const GemmParams& p, char* smem, f
 
 // ---------------------------------------------------------------------------------------------------------------------
 // One-tile-per-CU form for the N = E products: a 160x128 tile gives M = 6400, N = 768 exactly 240 tiles for 256 CUs (the
-// vendor library picks the same shape class for these problems: MT128x160 / MT160x128, profiles/r02_vendor_gemm_shapes.md),
+// vendor library picks the same shape class for these problems: MT128x160 / MT160x128, profiles/NOTES_gemm.md (r02_vendor_gemm_shapes)),
 // so every CU streams the same 288 rows per k-tile -- 10 % fewer bytes than two 128x128 halves and no imbalance.  With one
 // 4-wave workgroup per CU that tile ran at ~19 B/clk/CU of operand stream whatever the depth of the LDS ring (2, 3 or 4
-// stages: 45.8 / 45.8 / 45.4 us for c_proj; profiles/r02_gemm_experiments.md section 15): the stream rate depends on how
+// stages: 45.8 / 45.8 / 45.4 us for c_proj; profiles/NOTES_gemm.md (r02_gemm_experiments) section 15): the stream rate depends on how
 // many waves issue requests.  Hence:
 // The same tile with TWO wave groups that take alternate k-tiles (k-tile 2i -> group 0, 2i+1 -> group 1): twice the waves
 // issue LDS-DMA requests and twice the bytes are in flight per CU, which is what the L2 -> LDS stream rate depends on
-// (4-wave tiles measure ~19-25 B/clk/CU, 8-wave tiles 32; profiles/r02_gemm_experiments.md section 12), without shrinking the
+// (4-wave tiles measure ~19-25 B/clk/CU, 8-wave tiles 32; profiles/NOTES_gemm.md (r02_gemm_experiments) section 12), without shrinking the
 // tile or the per-wave fragment block.  Each group double-buffers its own k-tiles (4 LDS stages in all); one workgroup
 // barrier per pair of k-tiles; at the end the two partial sums (even k-tiles, odd k-tiles) meet through LDS, every 32x32
 // fragment being finished and stored by one of the two groups.
@@ -1562,7 +1562,7 @@ int launch_kphase(const GemmParams& p, const GemmTune& t, hipStream_t stream) {
 struct TileConfig { int wgm, wgn, wm, wn, wgs; bool hoist, spread, pipe; };
 constexpr TileConfig kConfigs[] = {
     // 4-wave tiles request the next k-tile in one burst: with 2-4 workgroups per CU another workgroup computes while
-    // this one sits in its issue slots (in the step: burst 5.59 ms, spread 5.75 ms; profiles/r02_gemm_experiments.md section 2).  The 8-wave tiles (one workgroup per
+    // this one sits in its issue slots (in the step: burst 5.59 ms, spread 5.75 ms; profiles/NOTES_gemm.md (r02_gemm_experiments) section 2).  The 8-wave tiles (one workgroup per
     // CU) spread the requests between their MFMAs.
     {2, 2, 2, 2, 2, true, false, false},   // 0: 128x128, 4 waves, 64 KiB, 2 workgroups / CU
     {2, 2, 1, 2, 3, true, false, false},   // 1:  64x128, 4 waves, 48 KiB, 3 workgroups / CU
@@ -1574,7 +1574,7 @@ constexpr TileConfig kConfigs[] = {
     // software-pipelined twins of 0 and 1 (register double buffer, two k-tiles of LDS-DMA in flight): bit-identical
     // results, measured SLOWER on every shape of the step (c_proj 62.8 vs 54.9 us, 5.48 vs 5.45 ms per step) -- the
     // k-loop is bound by the operand stream, not by the ds_read -> MFMA latency the pipelining removes
-    // (profiles/r02_gemm_experiments.md section 3).  Opt-in through gemm_config / gemm_cfg_longk for measurements only.
+    // (profiles/NOTES_gemm.md (r02_gemm_experiments) section 3).  Opt-in through gemm_config / gemm_cfg_longk for measurements only.
     {2, 2, 2, 2, 2, true, false, true},    // 7
     {2, 2, 1, 2, 2, true, false, true},    // 8
 };
@@ -1612,7 +1612,7 @@ int launch_cfg(const GemmParams& p, const GemmTune& t, hipStream_t stream) {
     return 0;
 }
 
-// Tile shape per problem.  Measured on MI355X (scripts/bench_gemm.py, profiles/r02_gemm_experiments.md).
+// Tile shape per problem.  Measured on MI355X (scripts/bench_gemm.py, profiles/NOTES_gemm.md (r02_gemm_experiments)).
 // The 8-wave tiles win when their tiling still gives (almost) every CU one tile per round;
 // the N = 768 products of the ViT-B step (75 tiles of 256x256) stay on the 4-wave tiles.
 // configuration 9 = 160x256 on 1 x 8 waves: only the staggered kernel has it (gemm8_kernel; `allow9`).  It is what fills the
@@ -1648,12 +1648,12 @@ int pick_config(const GemmParams& p, const GemmTune& t, bool allow9) {
     if (t128 >= 700) return 0;
     // few-tile problems (the N = E products): 128x128 only when K is long AND its tiles fit the 2 x CUs residency slots in
     // one round -- 300 tiles at ViT-B/32 B=128; at 520 (ViT-L/14, B=32) or 594 (ViT-B/16, B=64) tiles the handful of
-    // second-round tiles doubles the kernel time and 64x128 is 1.3-2.7 % faster per step (profiles/r02_gemm_experiments.md 9)
+    // second-round tiles doubles the kernel time and 64x128 is 1.3-2.7 % faster per step (profiles/NOTES_gemm.md (r02_gemm_experiments) 9)
     return (p.K >= t.kswitch && t128 <= 2L * cus) ? t.cfg_longk : t.cfg_shortk;
 }
 
 // Stream-K share (k-iterations per workgroup), 0 = keep the plain tiling.  Measured on the N = 768 products of ViT-B/32
-// (scripts/gpu_streamk_sweep.py, profiles/r02_gemm_experiments.md section 13): the k-loops only get faster when workgroups
+// (scripts/gpu_streamk_sweep.py, profiles/NOTES_gemm.md (r02_gemm_experiments) section 13): the k-loops only get faster when workgroups
 // that share an A panel -- TILE_BAND tiles = TILE_BAND * nk iterations apart in the walk -- stay in PHASE (same k at the
 // same time), i.e. when the share divides TILE_BAND * nk: otherwise every workgroup streams its own k-slices through the
 // XCD's 4 MiB L2 and the kernel becomes fabric-bound (63-75 us against 54 plain).  A share of at least nk / 2 keeps the
@@ -1811,7 +1811,7 @@ int launch_epi(const GemmParams& p, const GemmTune& t, hipStream_t stream) {
         const int kwm = use_ksplit(p, t, cfg);
         if (kwm && t.ksplit_stagger == 2) {
             // requests between the MFMAs (kphase_nl = 2: two in LOAD, the rest behind every second MFMA) win 3 % back to back and
-            // lose 0.9 % in the step (28.14 k vs 27.89 k images/s, two pairs; profiles/r03_gemm_experiments.md section 8)
+            // lose 0.9 % in the step (28.14 k vs 27.89 k images/s, two pairs; profiles/NOTES_gemm.md (r03_gemm_experiments) section 8)
             if (kwm == 5) return t.kphase_nl <= 2 ? launch_kphase<EPI, 5, 2>(p, t, stream) : launch_kphase<EPI, 5, 8>(p, t, stream);
             return t.kphase_nl <= 2 ? launch_kphase<EPI, 3, 2>(p, t, stream) : launch_kphase<EPI, 3, 8>(p, t, stream);
         }

@@ -204,7 +204,7 @@ int pevit_launch_conv_weight(const float* w, bf16* out, int E, int K, int Kp, hi
 int pevit_launch_cls_row(const float* cls, const float* pos, float* x, int B, int N, int E, hipStream_t s);
 int pevit_launch_head(const float* feat, const int64_t* labels, const float* W, const float* bias, float* gW, float* gb,
                       float* running_mean, float* running_var, int training, float* ybn, float* rstd, float* logits,
-                      float* dlogits, float* dybn, float* loss, float* dfeat, int B, int D, int Cc, hipStream_t s);
+                      float* dlogits, float* dybn, float* loss, float* dfeat, int B, int D, int Cc, hipStream_t s, bf16* dfeat_bf16 = nullptr);   // dfeat_bf16: bf16 copy of dfeat written by the BatchNorm backward (no cast launch)
 
 // ---- adapter.hip (post-MLP bottleneck adapters: Adapter, Compacter) -------------------------------
 struct BottleneckPanels { bf16* wd; bf16* wdT; bf16* wu; bf16* wuT; };   // [64][E], [E][64], [E][64], [64][E]

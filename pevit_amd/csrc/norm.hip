@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     // Every load of the row -- x, gamma, beta -- is requested before the first reduction, and none of them sits inside a bounds
     // branch (columns beyond E read column 0 and are masked): a value loaded inside a branch makes hipcc wait with vmcnt(0) at its
     // first use after the join, and on gfx950 that also waits for the STORES issued so far -- the store loop below then paid one
-    // store latency per 256 columns (profiles/r03_gemm_experiments.md section 3 has the same finding for the GEMM epilogues).
+    // store latency per 256 columns (profiles/NOTES_gemm.md (r03_gemm_experiments) section 3 has the same finding for the GEMM epilogues).
     float4 v[MAXV], gm[MAXV], bt[MAXV];
     bool ok[MAXV];
 #pragma unroll

@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void bn_fwd_kernel(const float* __restrict__ f
 // dfeat = rstd * (dy - mean_b(dy) - yhat * mean_b(dy*yhat))   (training) ;  rstd * dy (eval)
 __global__ __launch_bounds__(256) void bn_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ yhat,
                                                      const float* __restrict__ rstd, float* __restrict__ dfeat,
-                                                     int training, int B, int D) {
+                                                     int training, int B, int D, bf16* __restrict__ dfeat_b16) {
     __shared__ float red[16][17];
     const int f = threadIdx.x & 15, g = threadIdx.x >> 4;
     const int d = blockIdx.x * 16 + f;
@@ -194,7 +194,9 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const float* __restrict__ d
     const float r = rstd[d];
     for (int b = g; b < B; b += 16) {
         const float gg = dy[(size_t)b * D + d];
-        dfeat[(size_t)b * D + d] = training ? r * (gg - m1 - yhat[(size_t)b * D + d] * m2) : r * gg;
+        const float o = training ? r * (gg - m1 - yhat[(size_t)b * D + d] * m2) : r * gg;
+        dfeat[(size_t)b * D + d] = o;
+        if (dfeat_b16) dfeat_b16[(size_t)b * D + d] = f2bf(o);      // the operand of the projection backward (round 5: no cast launch)
     }
 }
 
@@ -344,6 +346,42 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logit
     if (lane == 0) rowloss[b] = ignored ? 0.f : (bad ? nanv : lse - lr[lab]);
 }
 
+// ce_kernel + loss_mean_kernel as ONE workgroup (round 5: one launch less on the class-token tail): wave w takes rows w, w + 16, ...
+// with exactly ce_kernel's arithmetic, then wave 0 forms the mean with exactly loss_mean_kernel's summation order.
+__global__ __launch_bounds__(1024) void ce_loss_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                       float* __restrict__ dlogits, float* __restrict__ rowloss,
+                                                       float* __restrict__ loss, int B, int Cc) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const float nvalid = ce_valid_rows(labels, B, lane);
+    const float nanv = __builtin_nanf("");
+    for (int b = wid; b < B; b += 16) {
+        const float* lr = logits + (size_t)b * Cc;
+        float m = -3.0e38f;
+        for (int c = lane; c < Cc; c += 64) m = fmaxf(m, lr[c]);
+        m = wave_max(m);
+        float s = 0.f;
+        for (int c = lane; c < Cc; c += 64) s += __expf(lr[c] - m);
+        s = wave_sum(s);
+        const float lse = m + __logf(s);
+        const int64_t lab64 = labels[b];
+        const bool ignored = lab64 == CE_IGNORE, bad = !ignored && (lab64 < 0 || lab64 >= Cc);
+        const int lab = (int)lab64;
+        for (int c = lane; c < Cc; c += 64) {
+            const float pr = __expf(lr[c] - lse);
+            const float g = (pr - (c == lab ? 1.f : 0.f)) / nvalid;
+            dlogits[(size_t)b * Cc + c] = ignored ? 0.f : (bad ? nanv : g);
+        }
+        if (lane == 0) rowloss[b] = ignored ? 0.f : (bad ? nanv : lse - lr[lab]);
+    }
+    __syncthreads();                                 // (global stores of this workgroup are visible to it behind the barrier)
+    if (wid == 0) {
+        float s = 0.f;
+        for (int b = lane; b < B; b += 64) s += rowloss[b];
+        s = wave_sum(s);
+        if (lane == 0) loss[0] = s / nvalid;
+    }
+}
+
 // loss = sum(rowloss) / (number of non-ignored rows): one wave, fixed summation order
 __global__ void loss_mean_kernel(const float* __restrict__ rowloss, const int64_t* __restrict__ labels,
                                  float* __restrict__ loss, int B) {
@@ -405,7 +443,7 @@ int pevit_launch_cls_row(const float* cls, const float* pos, float* x, int B, in
 }
 int pevit_launch_head(const float* feat, const int64_t* labels, const float* W, const float* bias, float* gW, float* gb,
                       float* running_mean, float* running_var, int training, float* ybn, float* rstd, float* logits,
-                      float* dlogits, float* dybn, float* loss, float* dfeat, int B, int D, int Cc, hipStream_t s) {
+                      float* dlogits, float* dybn, float* loss, float* dfeat, int B, int D, int Cc, hipStream_t s, bf16* dfeat_b16) {
     hipLaunchKernelGGL(bn_fwd_kernel, dim3(ceil_div(D, 16)), dim3(256), 0, s, feat, ybn, rstd, running_mean, running_var,
                        training, B, D);
     LAUNCH_OK("bn_fwd_kernel");
@@ -416,10 +454,15 @@ int pevit_launch_head(const float* feat, const int64_t* labels, const float* W, 
     }
     if (!labels) return 0;
     float* rowloss = dybn;      // dybn is written later (by the dgrad product); reuse its head as scratch
-    hipLaunchKernelGGL(ce_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, s, logits, labels, dlogits, rowloss, B, Cc);
-    LAUNCH_OK("ce_kernel");
-    hipLaunchKernelGGL(loss_mean_kernel, dim3(1), dim3(64), 0, s, rowloss, labels, loss, B);
-    LAUNCH_OK("loss_mean_kernel");
+    if (B <= 2048) {        // one workgroup: cross entropy of every row + the mean (bit-identical to the two kernels below)
+        hipLaunchKernelGGL(ce_loss_kernel, dim3(1), dim3(1024), 0, s, logits, labels, dlogits, rowloss, loss, B, Cc);
+        LAUNCH_OK("ce_loss_kernel");
+    } else {
+        hipLaunchKernelGGL(ce_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, s, logits, labels, dlogits, rowloss, B, Cc);
+        LAUNCH_OK("ce_kernel");
+        hipLaunchKernelGGL(loss_mean_kernel, dim3(1), dim3(64), 0, s, rowloss, labels, loss, B);
+        LAUNCH_OK("loss_mean_kernel");
+    }
     if (gW) {   // gW[c][d] += sum_b dl[b][c] ybn[b][d] ; gb[c] += sum_b dl[b][c]
         SmallGemm g{dlogits, 1, Cc, ybn, D, 1, gW, D, nullptr, gb, Cc, D, B, 1};
         hipLaunchKernelGGL(small_gemm_kernel, dim3(ceil_div(D, 32), ceil_div(Cc, 32)), dim3(256), 0, s, g);
@@ -429,7 +472,7 @@ int pevit_launch_head(const float* feat, const int64_t* labels, const float* W, 
         SmallGemm g{dlogits, Cc, 1, W, D, 1, dybn, D, nullptr, nullptr, B, D, Cc, 0};
         hipLaunchKernelGGL(small_gemm_kernel, dim3(ceil_div(D, 32), ceil_div(B, 32)), dim3(256), 0, s, g);
         LAUNCH_OK("small_gemm_kernel");
-        hipLaunchKernelGGL(bn_bwd_kernel, dim3(ceil_div(D, 16)), dim3(256), 0, s, dybn, ybn, rstd, dfeat, training, B, D);
+        hipLaunchKernelGGL(bn_bwd_kernel, dim3(ceil_div(D, 16)), dim3(256), 0, s, dybn, ybn, rstd, dfeat, training, B, D, dfeat_b16);
         LAUNCH_OK("bn_bwd_kernel");
     }
     return 0;

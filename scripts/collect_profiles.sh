@@ -1,5 +1,5 @@
 #!/bin/bash
-# copy the summaries of the last scripts/gpu_r4_final.sh call from gpurun_out/ (scratch) into profiles/ (tracked)
+# copy the summaries of the last scripts/gpu_r5_final.sh call from gpurun_out/ (scratch) into profiles/ (tracked)
 cd "$(dirname "$0")/.."
 R=${1:-r05}
 cp gpurun_out/hbm_traffic.json profiles/hbm_traffic.json

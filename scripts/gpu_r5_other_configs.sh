@@ -15,7 +15,7 @@ run --arch ViT-L/14 --batch 32 --weights fp8-act
 python - <<'PY'
 import json
 rows=[json.loads(l) for l in open('gpurun_out/r05_other_configs.jsonl') if l.strip().startswith('{')]
-out=["# Other configurations, round 5 (one MI355X, one box for the whole table; `scripts/gpu_r4_other_configs.sh`: `bench.py --steps 60 --warmup 15`)","",
+out=["# Other configurations, round 5 (one MI355X, one box for the whole table; `scripts/gpu_r5_other_configs.sh`: `bench.py --steps 60 --warmup 15`)","",
 "| configuration | images/s | ms / step (median) | whole-step frac of MFMA peak | GEMM family frac (events) | GEMM launches / step | non-GEMM ms / step |","|---|---|---|---|---|---|---|"]
 for d in rows:
     r=d['roofline']; w=d['config']['workload'].split(' fine-tune')[0].replace('CLIP ','')

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The step's eight GEMM products, this build against the vendor library (torch.matmul -> hipBLASLt), LIKE FOR LIKE
-(round-5 re-take of profiles/r02_vendor_gemm_shapes.md; measurement only -- the product path never calls the vendor library).
+(round-5 re-take of profiles/NOTES_gemm.md (r02_vendor_gemm_shapes); measurement only -- the product path never calls the vendor library).
 
 Two cache regimes per product:
   * back to back   : the same buffers every call (operands and outputs warm in L2 / Infinity Cache) -- what the round-2

@@ -3,7 +3,7 @@
 hipcc waits with ``s_waitcnt vmcnt(0)`` (a) right behind a load whose destination has a second definition at a branch join
 (``v = 0; if (ok) v = load``): one memory round trip per load; (b) before the first use, after a conditional store, of a value
 loaded earlier -- and on gfx950 vmcnt counts stores, so that wait is a store round trip.  The kernels below were rewritten so
-that neither pattern occurs (profiles/r03_gemm_experiments.md 5d); this test keeps it that way by scanning the ``-S`` listing
+that neither pattern occurs (profiles/NOTES_gemm.md (r03_gemm_experiments) 5d); this test keeps it that way by scanning the ``-S`` listing
 like scripts/isa_serial_loads.py / scripts/isa_store_waits.py do."""
 import os
 import re
