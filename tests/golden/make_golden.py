@@ -122,12 +122,21 @@ def sign_projections(v, index, k=32):
 
 
 def run_case(method, arch_name, batch, classes, lora_r=4, steps=3, lr=0.01, wd=1e-4,
-             store_tensors=True, reference_init=False, redraw=False, full_layers=None):
+             store_tensors=True, reference_init=False, redraw=False, full_layers=None, keep_frozen_from=None):
     arch = ARCHS[arch_name]
     sd = synth_state_dict(arch, seed=2, text_tower=(arch_name.startswith("tiny")))
     if store_tensors:
         sd = {k: (v.half().float() if v.dim() > 0 else v) for k, v in sd.items()}
     model = build_ref(method, sd, lora_r)
+    if keep_frozen_from and os.path.exists(keep_frozen_from):
+        # tensors the reference draws from torch's GLOBAL generator and never trains (Compacter's shared phm_rule ~ U(-1, 1),
+        # compacter_model.py:511-519) depend on everything that drew before them in the recording process: a re-recording of an
+        # existing fixture keeps the draw it was recorded with, everything else is recomputed from the reference
+        old = np.load(keep_frozen_from)
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                if n not in sd and not trainable_rule(method, n) and "adapter/" + n in old.files:
+                    p.copy_(torch.from_numpy(np.asarray(old["adapter/" + n])))
     all_names = [n for n, _ in model.named_parameters()]
     for n, p in model.named_parameters():
         p.requires_grad = trainable_rule(method, n)
@@ -285,6 +294,13 @@ def run_case(method, arch_name, batch, classes, lora_r=4, steps=3, lr=0.01, wd=1
             tensors["adapter/" + n] = v.numpy()
         meta["grad_norms"] = {n: (None if g is None else float(g.double().norm())) for n, g in grads.items()}
         meta["final_norms"] = {n: float(v.double().norm()) for n, v in final.items()}
+        # round 5: a norm cannot see a permutation / sign error -- 32 seeded sign projections per gradient tensor can (an unbiased
+        # estimate of the relative L2 error, tests/conftest.py:proj_rel_err); index = position in Classifier.named_parameters()
+        order = {n: i for i, (n, _) in enumerate(clf.named_parameters())}
+        meta["proj_index"] = {n: order[n] for n, g in grads.items() if g is not None}
+        for n, g in grads.items():
+            if g is not None:
+                tensors["grad_proj/" + n] = sign_projections(g, order[n]).numpy()
     return meta, tensors
 
 
@@ -340,6 +356,7 @@ def text_case():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also run the full-size ViT-B/32 bs=8 cases")
+    ap.add_argument("--full-only", action="store_true", help="only the full-size ViT-B/32 bs=8 summaries (full_b32_<method>)")
     ap.add_argument("--counts", action="store_true", help="also regenerate the parameter-count table")
     ap.add_argument("--text-only", action="store_true", help="only (re)generate tiny_text.npz")
     ap.add_argument("--refinit", action="store_true",
@@ -375,11 +392,23 @@ def main():
                   "last step:", sum(k.startswith(("grad_last/", "grad_last_proj/")) for k in tensors), "| moved:", sum(k.startswith(("delta/", "delta_proj/")) for k in tensors),
                   "| %.2f MB" % (os.path.getsize(os.path.join(HERE, f"{tag}.npz")) / 1e6), flush=True)
         return
+    if args.full_only:
+        torch.manual_seed(0)
+        torch.set_num_threads(8)
+        for method in BUILDERS:
+            meta, tensors = run_case(method, "ViT-B/32", batch=8, classes=100, steps=2, store_tensors=False,
+                                     keep_frozen_from=os.path.join(HERE, f"full_b32_{method}.npz"))
+            np.savez_compressed(os.path.join(HERE, f"full_b32_{method}.npz"), **tensors)
+            with open(os.path.join(HERE, f"full_b32_{method}.json"), "w") as f:
+                json.dump(meta, f, indent=1)
+            print(method, "full ok; losses", meta["losses"])
+        return
     if args.other_archs:
         for method, arch_name, tag, lora_r in (("compacter", "ViT-B/16", "full_b16_compacter", 4),
                                                 ("kadaptation", "ViT-L/14", "full_l14_kadaptation", 4),
                                                 ("lora", "ViT-B/32", "full_b32_lora_r8", 8)):
-            meta, tensors = run_case(method, arch_name, batch=8, classes=100, lora_r=lora_r, steps=1, store_tensors=False)
+            meta, tensors = run_case(method, arch_name, batch=8, classes=100, lora_r=lora_r, steps=1, store_tensors=False,
+                                     keep_frozen_from=os.path.join(HERE, f"{tag}.npz"))
             np.savez_compressed(os.path.join(HERE, f"{tag}.npz"), **tensors)
             with open(os.path.join(HERE, f"{tag}.json"), "w") as f:
                 json.dump(meta, f, indent=1)

@@ -23,6 +23,11 @@ from conftest import golden_param_dict, load_golden, load_tiny_sd, max_rel, rel_
 
 pytestmark = pytest.mark.gpu
 
+# sign-projection estimate of a gradient tensor's relative L2 error on the full-size random-adapter fixtures (round 5).  Measured on
+# the production bf16 path: worst per fixture 0.06 (LoRA r=8) / 0.15 (KAdaptation, Compacter B/32) / 0.18 (LoRA) / 0.29 (Compacter B/16)
+# / 0.37 (Adapter: adapter_down.1.bias, the ill-conditioned column sums of profiles/r05_parity_refinit.md); a permuted tensor reads
+# 1.4, a sign-flipped one 2.0.  The f32 verification mode holds the same projections to the STATED 5e-2 (tests/test_gpu_verify.py).
+PROJ_GRAD_TOL = 0.5
 LOGIT_TOL, LOSS_TOL, GRAD_TOL = 3e-2, 2e-2, 1.5e-1
 DEEP_LOGIT_TOL, DEEP_GRAD_TOL = 1e-1, 1.5e-1
 TRAJ_LOSS_TOL, TRAJ_NORM_TOL = 1.5e-1, 6e-2     # second SGD step of the full-size fixtures (random x160 adapters): calibrated, see profiles/r04_parity_gates.md
@@ -272,7 +277,7 @@ def test_full_size_bs8_matches_reference_fixture(case):
     deep = 1.0
     assert max_rel(logits.cpu(), t["logits0"]) < DEEP_LOGIT_TOL * deep
     assert abs(float(loss) - float(t["loss0"])) < LOSS_TOL * deep
-    bad = []
+    bad, proj_errs = [], {}
     for name, gten in eng.grad_views().items():
         key = name if name.startswith("layers.") else "backbone." + name
         ref = meta["grad_norms"][key]
@@ -282,7 +287,17 @@ def test_full_size_bs8_matches_reference_fixture(case):
             got = float(gten.double().norm())
             if abs(got - ref) > DEEP_GRAD_TOL * deep * max(ref, 1e-8):
                 bad.append((name, got, ref))
+            # the tensor itself through its 32 recorded sign projections (round 5): an unbiased estimate of the relative L2 error that
+            # sees what a norm cannot -- a permuted or sign-flipped tensor reads 1.4 / 2.0.  Gate: the calibrated bf16 gradient gate
+            # of the random-adapter towers (GRAD_TOL) widened by the 3-sigma sampling width of 32 projections
+            if "grad_proj/" + key in t:
+                from conftest import proj_rel_err
+                e = proj_rel_err(gten.cpu(), meta["proj_index"][key], t["grad_proj/" + key], ref)
+                proj_errs[name] = e
     assert not bad, bad[:5]
+    worst_p = max(proj_errs.items(), key=lambda kv: kv[1]) if proj_errs else ("-", 0.0)
+    print(f"projection-estimated gradient errors {case}: worst {worst_p[1]:.3e} ({worst_p[0]}), mean {sum(proj_errs.values()) / max(len(proj_errs), 1):.3e}")
+    assert worst_p[1] < PROJ_GRAD_TOL, worst_p
     # the recorded SGD trajectory (full_b32_*: two steps): loss of the second step and the norm of every trained tensor after it
     if len(meta["losses"]) > 1:
         eng.sgd_step(meta["lr"], 0.9, meta["wd"])

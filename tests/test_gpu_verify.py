@@ -115,6 +115,11 @@ def test_stated_gates_on_full_size_fixtures(case):
             assert float(g.abs().max()) == 0.0
         else:
             assert abs(float(g.double().norm()) - ref) < 5e-3 * max(ref, 1e-8), (name, float(g.double().norm()), ref)
+            key = name if name.startswith("layers.") else "backbone." + name
+            if "grad_proj/" + key in t:               # the tensor itself through its recorded sign projections (round 5)
+                from conftest import proj_rel_err
+                e = proj_rel_err(g.cpu(), meta["proj_index"][key], t["grad_proj/" + key], ref)
+                assert e < STATED_GRADS, (name, e)
 
 
 @pytest.mark.parametrize("arch_name,method,lora_r,B", [("ViT-B/32", "kadaptation", 4, 8), ("ViT-B/32", "lora", 8, 8),

@@ -162,6 +162,12 @@ def test_full_size_vit_matches_reference(case):
         else:
             got = float(tr.p[name].grad.double().norm())
             assert abs(got - ref) <= 2e-3 * max(ref, 1e-6), (name, got, ref)
+            # ... and the 32 recorded sign projections of the tensor (round 5): a norm cannot see a permutation or a sign
+            k = "backbone." + name
+            if "grad_proj/" + k in t:
+                from conftest import proj_rel_err
+                e = proj_rel_err(tr.p[name].grad, meta["proj_index"][k], t["grad_proj/" + k], ref)
+                assert e < 5e-3, (name, e)
     assert tr.n_trainable() == meta["n_trainable_params"]
 
 
