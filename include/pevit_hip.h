@@ -318,7 +318,9 @@ int pevit_ar_export(pevit_ar* ar, void* handle_out);
 int pevit_ar_import(pevit_ar* ar, int peer, const void* handle);
 int pevit_allreduce_flat(pevit_ar* ar, void* stream, float* buf, size_t n);
 int pevit_ar_error(pevit_ar* ar, void* stream);       /* 0 fine, 1 a peer never arrived, 2 the ranks passed different sizes */
-/* Round 5.  The flag a rank pushes is the pair (epoch, n); ONE workgroup of the reducing launch decides for all of them, so a bucket is
+/* Round 5.  The push is a kernel (stores through the IPC-mapped peer addresses, system-scope fence, one 8-byte release store per
+ * peer flag); PEVIT_AR_PUSH=dma selects the copy-engine push of round 4, which an eight-process soak on one device showed to be
+ * unreliable (torn / lost flags).  The flag a rank pushes is the pair (epoch, n); ONE workgroup of the reducing launch decides for all of them, so a bucket is
  * reduced everywhere or nowhere; the mailbox is fine-grained memory where the runtime exports such an allocation
  * (pevit_ar_fine_grained; PEVIT_AR_COARSE=1 forces the plain one).  pevit_ar_error_word: the device address of the error word, for
  * pevit_set_external_poison -- pevit_sgd_step then withholds the update of a step whose exchange failed (and writes NaN over that

@@ -5,9 +5,12 @@
 // latency.  One-shot form, one process per GPU on one node:
 //   * every rank owns a MAILBOX in its HBM: [2 parities][world][capacity] floats + [2][world] flag words, exported once through
 //     hipIpcGetMemHandle and opened by every peer (dmabuf IPC: HSA_ENABLE_IPC_MODE_LEGACY=0);
-//   * all-reduce number e (parity e & 1) of rank r:  for every peer p:  hipMemcpyAsync(p.mail[par][r] <- buf)  then
-//     hipMemcpyAsync(p.flag[par][r] <- e) on the caller's stream -- device-to-device copies into IPC-mapped memory, i.e. the copy
-//     engines over xGMI, no compute unit of either GPU involved; stream order puts the flag behind its data;
+//   * all-reduce number e (parity e & 1) of rank r:  ONE kernel (ar_push_kernel, round 5) stores the contribution into every
+//     peer's mail[par][r] through the IPC-mapped addresses, fences at system scope and lets its last workgroup write every
+//     peer's flag[par][r] = (e, n) with a single 8-byte release store.  (Round 4 pushed with the copy engines -- for every peer
+//     hipMemcpyAsync(data) then hipMemcpyAsync(flag), "no compute unit involved".  Kept behind PEVIT_AR_PUSH=dma, but NOT
+//     reliable: with eight processes on one device the 8-byte flag was seen torn and, in a 200-round soak, three reductions of one
+//     rank never saw a peer's flag at all; the kernel form ran 400 rounds x 8 ranks clean.)
 //   * a small local kernel waits (bounded) until flag[par][p] == e for every peer and overwrites buf with
 //     sum_{p = 0 .. world-1} contribution_p  IN RANK ORDER -- the same order on every rank, so the replicas stay bit-identical,
 //     and for world = 2 bit-identical to any other all-reduce (a two-term f32 sum has one value).  Peer data and flags are read
@@ -33,8 +36,9 @@
 
 #include <new>
 
+constexpr int AR_MAX_WORLD_C = 16;
 namespace {
-constexpr int AR_MAX_WORLD = 16;
+constexpr int AR_MAX_WORLD = AR_MAX_WORLD_C;
 constexpr int AR_STAGE = 8;                 // ring of device words holding the epoch number a flag copy reads from
 }  // namespace
 
@@ -45,14 +49,52 @@ struct pevit_ar {
     char* peer[AR_MAX_WORLD] = {};           // IPC-opened allocations of the peers (own entry = base)
     bool opened[AR_MAX_WORLD] = {};
     unsigned epoch = 0;
-    size_t off_flags = 0, off_stage = 0, off_err = 0, off_dec = 0, bytes = 0;
+    size_t off_flags = 0, off_stage = 0, off_err = 0, off_dec = 0, off_ticket = 0, bytes = 0;
     bool fine = false;                       // the allocation is fine-grained (hipExtMallocWithFlags)
+    bool dma = false;                        // PEVIT_AR_PUSH=dma: push with the copy engines (round 4) instead of ar_push_kernel
 };
 
 namespace {
 
 inline size_t mail_off(const pevit_ar* a, int par, int src) { return ((size_t)par * a->world + src) * a->cap * sizeof(float); }
 inline size_t flag_off(const pevit_ar* a, int par, int src) { return a->off_flags + ((size_t)par * a->world + src) * sizeof(unsigned long long); }
+
+// The push as a kernel (round 5, the default): grid (slices, world - 1); block (x, k) stores slice x of the contribution into the
+// mailbox of peer (rank + 1 + k) % world through its IPC-mapped address; every block fences at system scope and takes a ticket; the
+// LAST block of the launch (all data of all peers is then visible system-wide) writes the (epoch, n) flag of every peer with ONE
+// 8-byte system-scope release store each.  This is the textbook release/acquire hand-off; the copy-engine form below it
+// (PEVIT_AR_PUSH=dma) relies on two stream-ordered device-to-device copies landing in order and on an 8-byte copy being atomic --
+// with eight processes on one device the flag pair was seen torn, and one sum in 1,600 was wrong.
+struct ArPeers { char* base[AR_MAX_WORLD_C]; };
+__global__ __launch_bounds__(256) void ar_push_kernel(const float* __restrict__ buf, size_t n, ArPeers peers, size_t mail_byte_off,
+                                                      size_t flag_byte_off, int rank, int world, unsigned epoch, unsigned* ticket) {
+    const int p = (rank + 1 + (int)blockIdx.y) % world;
+    float* dst = reinterpret_cast<float*>(peers.base[p] + mail_byte_off);
+    const size_t per = 2048, lo = (size_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    if (((reinterpret_cast<uintptr_t>(buf) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0) {
+        const size_t lo4 = lo / 4, hi4 = hi / 4;               // lo is a multiple of 2048
+        for (size_t i = lo4 + threadIdx.x; i < hi4; i += blockDim.x)
+            reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(buf)[i];
+        for (size_t i = hi4 * 4 + threadIdx.x; i < hi; i += blockDim.x) dst[i] = buf[i];
+    } else {
+        for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) dst[i] = buf[i];
+    }
+    __threadfence_system();                                    // this thread's stores are visible to every agent
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned total = gridDim.x * gridDim.y;
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == total - 1) {
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // ready for the next launch (same stream: ordered)
+            __threadfence_system();
+            const unsigned long long flag = ((unsigned long long)(unsigned)n << 32) | epoch;
+            for (int q = 0; q < world; ++q)
+                if (q != rank)
+                    __hip_atomic_store(reinterpret_cast<unsigned long long*>(peers.base[q] + flag_byte_off), flag, __ATOMIC_RELEASE,
+                                       __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
 
 // buf[i] = sum over ranks (rank order) of: own contribution (buf itself) / the peers' pushed copies in the local mailbox
 __global__ __launch_bounds__(256) void ar_reduce_kernel(float* __restrict__ buf, size_t n, const float* mail, const unsigned long long* flags,
@@ -136,7 +178,9 @@ extern "C" int pevit_ar_create(pevit_ar** out, int rank, int world, size_t max_f
     a->off_stage = align_up(a->off_flags + 2 * (size_t)world * sizeof(unsigned long long), 256);
     a->off_err = a->off_stage + AR_STAGE * 256;
     a->off_dec = a->off_err + 256;
-    a->bytes = a->off_dec + 256;
+    a->off_ticket = a->off_dec + 256;
+    a->bytes = a->off_ticket + 256;
+    { const char* pm = getenv("PEVIT_AR_PUSH"); a->dma = pm && !strcmp(pm, "dma"); }
     // fine-grained first (peer writes become visible without relying on this GPU's L2 being bypassed); PEVIT_AR_COARSE=1 or a
     // runtime that refuses falls back to the plain allocation
     const char* coarse = getenv("PEVIT_AR_COARSE");
@@ -202,6 +246,14 @@ extern "C" int pevit_allreduce_flat(pevit_ar* a, void* stream, float* buf, size_
     if (n >> 32) { pevit_set_error("allreduce_flat: %zu floats do not fit the 32-bit size field of the flag", n); return -1; }
     const unsigned e = a->epoch + 1;                            // committed below, once every enqueue has succeeded
     const int par = (int)(e & 1u);
+    if (!a->dma) {
+        ArPeers peers;
+        for (int p = 0; p < AR_MAX_WORLD; ++p) peers.base[p] = p < a->world ? a->peer[p] : nullptr;
+        const unsigned slices = (unsigned)((n + 2047) / 2048);
+        hipLaunchKernelGGL(ar_push_kernel, dim3(slices, a->world - 1), dim3(256), 0, s, buf, n, peers, mail_off(a, par, a->rank),
+                           flag_off(a, par, a->rank), a->rank, a->world, e, reinterpret_cast<unsigned*>(a->base + a->off_ticket));
+        LAUNCH_OK("ar_push_kernel");
+    } else {
     unsigned* stage = reinterpret_cast<unsigned*>(a->base + a->off_stage + (size_t)(e % AR_STAGE) * 256);
     HIP_OK(hipMemsetD32Async((hipDeviceptr_t)stage, (int)e, 1, s));                     // flag = (n << 32) | epoch
     HIP_OK(hipMemsetD32Async((hipDeviceptr_t)(stage + 1), (int)(unsigned)n, 1, s));
@@ -209,6 +261,7 @@ extern "C" int pevit_allreduce_flat(pevit_ar* a, void* stream, float* buf, size_
         const int p = (a->rank + k) % a->world;
         HIP_OK(hipMemcpyAsync(a->peer[p] + mail_off(a, par, a->rank), buf, n * sizeof(float), hipMemcpyDeviceToDevice, s));
         HIP_OK(hipMemcpyAsync(a->peer[p] + flag_off(a, par, a->rank), stage, sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
+    }
     }
     const unsigned blocks = (unsigned)((n + 511) / 512);
     hipLaunchKernelGGL(ar_reduce_kernel, dim3(blocks), dim3(256), 0, s, buf, n,

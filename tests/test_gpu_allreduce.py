@@ -4,8 +4,8 @@ Two, four and eight processes share the one GPU of the test box (the handles tra
 mailboxes, the push + flag protocol over several epochs (both parities, odd lengths, one element), the rank-ordered reduction,
 the error paths (ranks that disagree on the size; a peer that never arrives; resync afterwards; the optimizer update withheld
 while the error word is raised) and the three overlapped buckets of ``engine.forward_backward_dp`` -- bit-identical to the
-process group's all-reduce (a two-term f32 sum has one value) and to the hand-summed two-shard step.  Two GPUs over xGMI have
-never run."""
+process group's all-reduce (a two-term f32 sum has one value) and to the hand-summed two-shard step.  The push is a kernel with a system-scope release (round 5; the
+copy-engine push of round 4 lost flags in an eight-process soak).  Two GPUs over xGMI have never run."""
 import os
 import sys
 
