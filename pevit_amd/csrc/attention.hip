@@ -318,11 +318,61 @@ __global__ __launch_bounds__(64 * NW, (ALL4 ? ATT_BWD_MINW : 1)) void attn_bwd_k
     __syncthreads();
 
     const int ntile = (N + 15) >> 4;
+    // One tile more than a whole number of rounds (ViT-L/14: N = 257 -> 17 tiles on 16 waves, i.e. TWO rounds for 1.06 rounds of
+    // work; a 9-wave build of this kernel ran exactly as long as the 16-wave one): the last tile is then shared by the waves --
+    // wave w takes the 32-key (pass B: 32-query) chunk w of it, the partial sums meet in LDS scratch behind the tiles
+    // (launch_bwd reserves COOP_BYTES) and wave 0 stores them.  Round 5.
+    const bool coop = !ALL4 && (ntile % NW) == 1 && ntile > NW && KT32 <= NW;
+    const int nmain = coop ? ntile - 1 : ntile;
+    float* coop_s = reinterpret_cast<float*>(smem + 2 * NPAD * 4 + 2 * NPAD * LDR * 2);      // [KT32][64 lanes][16] f32
+    // the y-chunks [s0, s1) of one x-tile of pass A: dQ^T partial sums in o
+    auto passA_chunks = [&](const bf16x8 (&x1)[2], const bf16x8 (&x2)[2], float lse_x, float del_x, int s0, int s1, f32x4 (&o)[4]) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll(KT32 <= 2 ? KT32 : 1)
+        for (int s = s0; s < s1; ++s) {
+            bf16x8 dsb;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int yr = 32 * s + 16 * half + c16;       // padded rows of the LDS tiles are zero
+                f32x4 z1 = {0.f, 0.f, 0.f, 0.f}, z2 = {0.f, 0.f, 0.f, 0.f};
+                z1 = mfma16(rowfrag(Ks, LDR, yr, 0, g), x1[0], z1);
+                z1 = mfma16(rowfrag(Ks, LDR, yr, 1, g), x1[1], z1);
+                z2 = mfma16(rowfrag(Vs, LDR, yr, 0, g), x2[0], z2);
+                z2 = mfma16(rowfrag(Vs, LDR, yr, 1, g), x2[1], z2);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = 32 * s + 16 * half + 4 * g + r;
+                    const float p = key < N ? __expf(z1[r] - lse_x) : 0.f;
+                    dsb[half * 4 + r] = f2bf(p * (z2[r] - del_x));
+                }
+            }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16(tfrag_tr(Ks, LDR, dt, s, lane), dsb, o[dt]);
+        }
+    };
+    // partial sums of the shared tile: every wave with a chunk leaves 16 floats per lane, wave 0 adds them in chunk order
+    auto coop_put = [&](const f32x4 (&o)[4]) {
+        if (wid < KT32) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(coop_s + ((size_t)wid * 64 + lane) * 16 + 4 * dt) = o[dt];
+        }
+    };
+    auto coop_sum = [&](f32x4 (&o)[4]) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int w = 0; w < KT32; ++w)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(coop_s + ((size_t)w * 64 + lane) * 16 + 4 * dt);
+                o[dt][0] += v[0]; o[dt][1] += v[1]; o[dt][2] += v[2]; o[dt][3] += v[3];
+            }
+    };
     // ---------------- pass A: x = queries, y = keys -> dQ -----------------------------
     {
         const bf16* Qr = ALL4 ? Qs : qh;   const size_t qst = ALL4 ? LDR : 64;
         const bf16* Dr = ALL4 ? dOs : doh; const size_t dst_ = ALL4 ? LDR : (size_t)lddo;
-        for (int xt = wid; xt < ntile; xt += NW) {
+        for (int xt = wid; xt < nmain; xt += NW) {
             const int xq = 16 * xt + c16;
             const int xs = xq < N ? xq : N - 1;
             bf16x8 x1[2], x2[2];
@@ -370,32 +420,27 @@ __global__ __launch_bounds__(64 * NW, (ALL4 ? ATT_BWD_MINW : 1)) void attn_bwd_k
                     for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16(tfrag_tr(Ks, LDR, dt, s, lane), dsb, o[dt]);
                 }
             } else {
-            const float del_x = del_s[xs];
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll(KT32 <= 2 ? KT32 : 1)
-            for (int s = 0; s < KT32; ++s) {
-                bf16x8 dsb;
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const int yr = 32 * s + 16 * half + c16;       // padded rows of the LDS tiles are zero
-                    f32x4 z1 = {0.f, 0.f, 0.f, 0.f}, z2 = {0.f, 0.f, 0.f, 0.f};
-                    z1 = mfma16(rowfrag(Ks, LDR, yr, 0, g), x1[0], z1);
-                    z1 = mfma16(rowfrag(Ks, LDR, yr, 1, g), x1[1], z1);
-                    z2 = mfma16(rowfrag(Vs, LDR, yr, 0, g), x2[0], z2);
-                    z2 = mfma16(rowfrag(Vs, LDR, yr, 1, g), x2[1], z2);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int key = 32 * s + 16 * half + 4 * g + r;
-                        const float p = key < N ? __expf(z1[r] - lse_x) : 0.f;
-                        dsb[half * 4 + r] = f2bf(p * (z2[r] - del_x));
-                    }
-                }
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16(tfrag_tr(Ks, LDR, dt, s, lane), dsb, o[dt]);
-            }
+            passA_chunks(x1, x2, lse_x, del_s[xs], 0, KT32, o);
             }
             if (xq < N) store16(dqkv + ((size_t)b * N + xq) * ld + h * 64 + 16 * g, o, 1.0f);
+        }
+        if constexpr (!ALL4) {
+            if (coop) {                                    // workgroup-uniform
+                const int xt = ntile - 1, xq = 16 * xt + c16, xs = xq < N ? xq : N - 1;
+                f32x4 o[4];
+                if (wid < KT32) {
+                    bf16x8 x1[2], x2[2];
+                    x1[0] = rowfrag(Qr, qst, xs, 0, g);  x1[1] = rowfrag(Qr, qst, xs, 1, g);
+                    x2[0] = rowfrag(Dr, dst_, xs, 0, g); x2[1] = rowfrag(Dr, dst_, xs, 1, g);
+                    passA_chunks(x1, x2, lse_s[xs], del_s[xs], wid, wid + 1, o);
+                }
+                coop_put(o);
+                __syncthreads();
+                if (wid == 0) {
+                    coop_sum(o);
+                    if (xq < N) store16(dqkv + ((size_t)b * N + xq) * ld + h * 64 + 16 * g, o, 1.0f);
+                }
+            }
         }
     }
     if constexpr (ALL4) {
@@ -419,17 +464,12 @@ __global__ __launch_bounds__(64 * NW, (ALL4 ? ATT_BWD_MINW : 1)) void attn_bwd_k
     {
         const bf16* Kr = ALL4 ? Ks : kh;   const size_t kst = ALL4 ? LDR : 64;
         const bf16* Vr = ALL4 ? Vs : vh;   const size_t vst = ALL4 ? LDR : 64;
-        for (int xt = wid; xt < ntile; xt += NW) {
-            const int xk = 16 * xt + c16;
-            const int xs = xk < N ? xk : N - 1;
-            bf16x8 x1[2], x2[2];
-            x1[0] = rowfrag(Kr, kst, xs, 0, g); x1[1] = rowfrag(Kr, kst, xs, 1, g);
-            x2[0] = rowfrag(Vr, vst, xs, 0, g); x2[1] = rowfrag(Vr, vst, xs, 1, g);
-            f32x4 ok[4], ov[4];
+        // the y-chunks [s0, s1) of one x-tile of pass B: dK^T, dV^T partial sums
+        auto passB_chunks = [&](const bf16x8 (&x1)[2], const bf16x8 (&x2)[2], int s0, int s1, f32x4 (&ok)[4], f32x4 (&ov)[4]) {
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) { ok[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; ov[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll(KT32 <= 2 ? KT32 : 1)
-            for (int s = 0; s < KT32; ++s) {
+            for (int s = s0; s < s1; ++s) {
                 bf16x8 dsb, pb;
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
@@ -456,10 +496,40 @@ __global__ __launch_bounds__(64 * NW, (ALL4 ? ATT_BWD_MINW : 1)) void attn_bwd_k
                     ov[dt] = mfma16(tfrag_tr(dOs, LDR, dt, s, lane), pb, ov[dt]);
                 }
             }
+        };
+        for (int xt = wid; xt < nmain; xt += NW) {
+            const int xk = 16 * xt + c16;
+            const int xs = xk < N ? xk : N - 1;
+            bf16x8 x1[2], x2[2];
+            x1[0] = rowfrag(Kr, kst, xs, 0, g); x1[1] = rowfrag(Kr, kst, xs, 1, g);
+            x2[0] = rowfrag(Vr, vst, xs, 0, g); x2[1] = rowfrag(Vr, vst, xs, 1, g);
+            f32x4 ok[4], ov[4];
+            passB_chunks(x1, x2, 0, KT32, ok, ov);
             if (xk < N) {
                 bf16* dst = dqkv + ((size_t)b * N + xk) * ld + h * 64 + 16 * g;
                 store16(dst + E, ok, 1.0f);
                 store16(dst + 2 * E, ov, 1.0f);
+            }
+        }
+        if constexpr (!ALL4) {
+            if (coop) {
+                const int xt = ntile - 1, xk = 16 * xt + c16, xs = xk < N ? xk : N - 1;
+                f32x4 ok[4], ov[4];
+                if (wid < KT32) {
+                    bf16x8 x1[2], x2[2];
+                    x1[0] = rowfrag(Kr, kst, xs, 0, g); x1[1] = rowfrag(Kr, kst, xs, 1, g);
+                    x2[0] = rowfrag(Vr, vst, xs, 0, g); x2[1] = rowfrag(Vr, vst, xs, 1, g);
+                    passB_chunks(x1, x2, wid, wid + 1, ok, ov);
+                }
+                __syncthreads();                               // pass A's reduction has read the scratch
+                coop_put(ok);
+                __syncthreads();
+                bf16* dst = dqkv + ((size_t)b * N + xk) * ld + h * 64 + 16 * g;
+                if (wid == 0) { f32x4 t[4]; coop_sum(t); if (xk < N) store16(dst + E, t, 1.0f); }
+                __syncthreads();
+                coop_put(ov);
+                __syncthreads();
+                if (wid == 0) { f32x4 t[4]; coop_sum(t); if (xk < N) store16(dst + 2 * E, t, 1.0f); }
             }
         }
     }
@@ -487,7 +557,8 @@ template <int KT32, bool ALL4, int NW>
 int launch_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* out, int ldo, const bf16* dout, int lddo,
                const float* lse, bf16* dqkv, int ld, int B, int H, int N, hipStream_t s, int dout_cls = 0) {
     constexpr int NPAD = 32 * KT32;
-    const int bytes = 2 * NPAD * 4 + (ALL4 ? 4 : 2) * NPAD * ATT_LDR * 2;
+    // + the scratch of the shared last tile (attn_bwd_kernel `coop`): [KT32][64][16] f32 behind the two tiles
+    const int bytes = 2 * NPAD * 4 + (ALL4 ? 4 : 2) * NPAD * ATT_LDR * 2 + (ALL4 ? 0 : KT32 * 64 * 16 * 4);
     static bool attr = false;
     if (!attr && bytes > 48 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<KT32, ALL4, NW>),
