@@ -557,13 +557,17 @@ template <int KT32, bool ALL4, int NW>
 int launch_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* out, int ldo, const bf16* dout, int lddo,
                const float* lse, bf16* dqkv, int ld, int B, int H, int N, hipStream_t s, int dout_cls = 0) {
     constexpr int NPAD = 32 * KT32;
-    // + the scratch of the shared last tile (attn_bwd_kernel `coop`): [KT32][64][16] f32 behind the two tiles
-    const int bytes = 2 * NPAD * 4 + (ALL4 ? 4 : 2) * NPAD * ATT_LDR * 2 + (ALL4 ? 0 : KT32 * 64 * 16 * 4);
+    // + the scratch of the shared last tile (attn_bwd_kernel `coop`: same condition), [KT32][64][16] f32 behind the two tiles -- only
+    // where it is used: at N = 197 (13 tiles on 8 waves: no shared tile) the 74 KB block must keep admitting two workgroups per CU
+    const int ntile = (N + 15) >> 4;
+    const bool coop = !ALL4 && (ntile % NW) == 1 && ntile > NW && KT32 <= NW;
+    const int bytes = 2 * NPAD * 4 + (ALL4 ? 4 : 2) * NPAD * ATT_LDR * 2 + (coop ? KT32 * 64 * 16 * 4 : 0);
+    constexpr int bytes_max = 2 * NPAD * 4 + (ALL4 ? 4 : 2) * NPAD * ATT_LDR * 2 + (ALL4 ? 0 : KT32 * 64 * 16 * 4);   // the LIMIT set once; a launch passes what it uses
     static bool attr = false;
-    if (!attr && bytes > 48 * 1024) {
+    if (!attr && bytes_max > 48 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<KT32, ALL4, NW>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
-            pevit_set_error("attn_bwd: cannot reserve %d bytes of LDS", bytes); return -1;
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes_max) != hipSuccess) {
+            pevit_set_error("attn_bwd: cannot reserve %d bytes of LDS", bytes_max); return -1;
         }
         attr = true;
     }
