@@ -25,10 +25,29 @@
 #include "common.h"
 #include "kernels.h"
 
-// LDS tiles are row-major [tokens][ATT_LDR] (16-byte writes as loaded); rows of 80 elements = 40 dwords keep both the
-// ds_read_b128 row fragments and the ds_read_b64_tr_b16 transposed fragments spread over the banks (72 measured equal).
-#ifndef ATT_LDR
-#define ATT_LDR 80
+// LDS tiles are row-major [tokens][LD], in one of two layouts chosen per kernel instance (template parameter LD):
+//   LD = 64: unpadded 128-byte rows, the 16-byte chunks of a row XOR-swizzled by the row (chunk c of row r sits at c ^ ((r >> 1) & 7));
+//   LD = 80: rows padded to 160 bytes, no swizzle (rounds 1-4).
+// Round 5 (PMC: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.44-0.62 on every attention kernel; model: scripts/lds_bank_model2.py):
+// with padded rows the ds_read_b128 row fragments are conflict free but every ds_read_b64_tr_b16 transposed fragment is 4-way
+// conflicted -- its 32 lanes address 8 rows x 4 pieces 32 bytes apart, and 40-dword rows put all of them on 16 of the 64 banks.
+// The swizzled layout keeps row fragments and staging writes conflict free and brings the transposed reads to 2-way (the minimum
+// for 8-byte pieces in 16-byte-aligned rows); tiles are 20 % smaller.  It costs address arithmetic: a padded address is base +
+// immediate, a swizzled one needs an XOR per fragment.  Measured on one box (profiles/r05_experiments.md): LDS-active cycles -31 %
+// (backward, N = 257) / -42 % (forward) as modelled, kernel time -6 % / -3 % there, -3 % at N = 50, forward -6 % at N = 197 -- but
+// the N = 197 backward (8 waves, two workgroups per CU, VALU-bound) LOSES 12 % (71 -> 80 us; with padding AND swizzle 84 us:
+// it is the arithmetic).  So: swizzled everywhere except that one instance.
+#ifndef ATT_LD_FWD
+#define ATT_LD_FWD 64
+#endif
+#ifndef ATT_LD_BWD_SMALL
+#define ATT_LD_BWD_SMALL 64
+#endif
+#ifndef ATT_LD_BWD_MID
+#define ATT_LD_BWD_MID 80
+#endif
+#ifndef ATT_LD_BWD_BIG
+#define ATT_LD_BWD_BIG 64
 #endif
 
 namespace {
@@ -42,16 +61,37 @@ __device__ __forceinline__ bf16x8 rowfrag(const bf16* base, size_t stride, int r
     return load_bf16x8(base + (size_t)row * stride + 32 * s + 8 * g);
 }
 
+// 16-byte row fragment of an LDS tile (swizzled chunks): row `row`, elements 32*s+8*g..+7
+template <int LD>
+__device__ __forceinline__ int att_swz(int r) { return LD == 64 ? (r >> 1) & 7 : 0; }
+template <int LD>
+__device__ __forceinline__ bf16x8 ldsfrag(const bf16* Ys, int row, int s, int g) {
+    return *reinterpret_cast<const bf16x8*>(Ys + row * LD + 8 * ((4 * s + g) ^ att_swz<LD>(row)));
+}
+// the same from either side: an LDS tile (LDS = true) or a row-major global matrix
+template <bool LDS, int LD>
+__device__ __forceinline__ bf16x8 xfrag(const bf16* base, size_t stride, int row, int s, int g) {
+    if constexpr (LDS) return ldsfrag<LD>(base, row, s, g);
+    else return rowfrag(base, stride, row, s, g);
+}
+// 16-byte piece `c` of row `y` of an LDS tile (staging writes)
+template <int LD>
+__device__ __forceinline__ bf16x8* ldschunk(bf16* Ys, int y, int c) {
+    return reinterpret_cast<bf16x8*>(Ys + y * LD + 8 * (c ^ att_swz<LD>(y)));
+}
+
 // Fragment of the TRANSPOSE of a row-major tile Ys[y][LDR] (LDS), output row m -> d = 16*(m>>2) + 4*dt + (m&3), with gfx950's
 // transposing read: in each 16-lane
 // group, lane 4j+q passes the address of 4 consecutive d of token-row j, and lane i receives, as element j, element i&3
 // of the piece addressed by lane 4j + (i>>2) (measured: scripts/probe_tr_b16.hip).  Lane 4j+q therefore points at
 // Ys[32s + 4g + j][16q + 4dt ..+3], and lane m ends up with d = 16*(m>>2) + 4*dt + (m&3) for the tokens 32s+4g+0..3
 // (second read: +16 tokens) -- no transposed copy in LDS, no scattered 2-byte writes.
-__device__ __forceinline__ bf16x8 tfrag_tr(const bf16* Ys, int LDR, int dt, int s, int lane) {
+template <int LDR>
+__device__ __forceinline__ bf16x8 tfrag_tr(const bf16* Ys, int dt, int s, int lane) {
     typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
     const int m = lane & 15, g = lane >> 4;
-    const bf16* src = Ys + (32 * s + 4 * g + (m >> 2)) * LDR + 16 * (m & 3) + 4 * dt;
+    const int R = 32 * s + 4 * g + (m >> 2);                     // (row R + 16 has the same swizzle)
+    const bf16* src = Ys + R * LDR + 8 * ((2 * (m & 3) + (dt >> 1)) ^ att_swz<LDR>(R)) + 4 * (dt & 1);
     const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(src));
     const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(src + 16 * LDR));
     bf16x8 o;
@@ -74,14 +114,14 @@ __device__ __forceinline__ void store16(bf16* dst, const f32x4 o[4], float scale
 }
 
 // ------------------------------------------------------------------------------------
-template <int KT32, int NW>
+template <int KT32, int NW, int LDK>
 __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
                                                        const bf16* __restrict__ v, bf16* __restrict__ out, int ldo,
                                                        float* __restrict__ lse, int H, int N, unsigned char* __restrict__ out8) {
-    constexpr int NPAD = 32 * KT32, LDK = ATT_LDR;
+    constexpr int NPAD = 32 * KT32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16* Ks = reinterpret_cast<bf16*>(smem);                 // [NPAD][LDK] row-major, padded rows
-    bf16* Vs = Ks + NPAD * LDK;                               // [NPAD][LDK] row-major, padded rows zero
+    bf16* Ks = reinterpret_cast<bf16*>(smem);                 // [NPAD][LDK] row-major (rows beyond N: whatever row N - 1 holds)
+    bf16* Vs = Ks + NPAD * LDK;                               // [NPAD][LDK] row-major, rows beyond N zero
     const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
     const bf16* qh = q + (size_t)bh * N * 64;
     const bf16* kh = k + (size_t)bh * N * 64;
@@ -113,8 +153,8 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const bf16* __restric
         for (int it = 0; it < IT; ++it) {
             const int idx = threadIdx.x + 64 * NW * it, y = idx >> 3, c = idx & 7;
             if (idx < NPAD * 8) {
-                *reinterpret_cast<bf16x8*>(Ks + y * LDK + 8 * c) = kk[it];
-                *reinterpret_cast<bf16x8*>(Vs + y * LDK + 8 * c) = y < N ? vv[it] : zero_bf16x8();
+                *ldschunk<LDK>(Ks, y, c) = kk[it];
+                *ldschunk<LDK>(Vs, y, c) = y < N ? vv[it] : zero_bf16x8();
             }
         }
     } else {
@@ -123,8 +163,8 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const bf16* __restric
             const int ys = y < N ? y : N - 1;
             const bf16x8 kk = load_bf16x8(kh + (size_t)ys * 64 + 8 * c);
             const bf16x8 vv = load_bf16x8(vh + (size_t)ys * 64 + 8 * c);
-            *reinterpret_cast<bf16x8*>(Ks + y * LDK + 8 * c) = kk;
-            *reinterpret_cast<bf16x8*>(Vs + y * LDK + 8 * c) = y < N ? vv : zero_bf16x8();
+            *ldschunk<LDK>(Ks, y, c) = kk;
+            *ldschunk<LDK>(Vs, y, c) = y < N ? vv : zero_bf16x8();
         }
     }
     __syncthreads();
@@ -141,8 +181,8 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const bf16* __restric
 #pragma unroll
         for (int yt = 0; yt < 2 * KT32; ++yt) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            acc = mfma16(rowfrag(Ks, LDK, 16 * yt + c16, 0, g), qf[0], acc);
-            acc = mfma16(rowfrag(Ks, LDK, 16 * yt + c16, 1, g), qf[1], acc);
+            acc = mfma16(ldsfrag<LDK>(Ks, 16 * yt + c16, 0, g), qf[0], acc);
+            acc = mfma16(ldsfrag<LDK>(Ks, 16 * yt + c16, 1, g), qf[1], acc);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = 16 * yt + 4 * g + r;
@@ -174,7 +214,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const bf16* __restric
         for (int dt = 0; dt < 4; ++dt) {
             o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int s = 0; s < KT32; ++s) o[dt] = mfma16(tfrag_tr(Vs, LDK, dt, s, lane), pf[s], o[dt]);
+            for (int s = 0; s < KT32; ++s) o[dt] = mfma16(tfrag_tr<LDK>(Vs, dt, s, lane), pf[s], o[dt]);
         }
         if (xq < N) {
             store16(out + ((size_t)b * N + xq) * ldo + h * 64 + 16 * g, o, 1.0f / l);
@@ -196,7 +236,8 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const bf16* __restric
 // rows [0, NPAD) of a row-major LDS tile <- src rows (stride elements apart), zero beyond N; 16-byte loads and writes
 // Four pieces per thread are requested before the first LDS write and none inside a bounds branch (rows beyond N read row N - 1
 // and are zeroed by a select): with `v = 0; if (y < N) v = load` hipcc drains behind every request, one round trip per piece.
-__device__ __forceinline__ void stage_rows(bf16* dst, int LDR, const bf16* src, size_t stride, int N, int NPAD) {
+template <int LDR>
+__device__ __forceinline__ void stage_rows(bf16* dst, const bf16* src, size_t stride, int N, int NPAD) {
     const int total = NPAD * 8, step = blockDim.x;
     for (int idx0 = threadIdx.x; idx0 < total; idx0 += 4 * step) {
         bf16x8 v[4];
@@ -210,7 +251,7 @@ __device__ __forceinline__ void stage_rows(bf16* dst, int LDR, const bf16* src, 
         for (int u = 0; u < 4; ++u) {
             const int idx = idx0 + u * step;
             const int y = idx >> 3, c = idx & 7;
-            if (idx < total) *reinterpret_cast<bf16x8*>(dst + y * LDR + 8 * c) = y < N ? v[u] : zero_bf16x8();
+            if (idx < total) *ldschunk<LDR>(dst, y, c) = y < N ? v[u] : zero_bf16x8();
         }
     }
 }
@@ -222,14 +263,13 @@ __device__ __forceinline__ void stage_rows(bf16* dst, int LDR, const bf16* src, 
 #ifndef ATT_BWD_MINW
 #define ATT_BWD_MINW 3     // waves per SIMD the N <= 64 backward kernel is compiled for: 158 VGPRs, three 41 KB workgroups per CU (23.5 -> 21.6 us in step; 4 spills)
 #endif
-template <int KT32, bool ALL4, int NW>
+template <int KT32, bool ALL4, int NW, int LDR>
 __global__ __launch_bounds__(64 * NW, (ALL4 ? ATT_BWD_MINW : 1)) void attn_bwd_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
                                                           const bf16* __restrict__ v, const bf16* __restrict__ out,
                                                           int ldo, const bf16* __restrict__ dout, int lddo,
                                                           const float* __restrict__ lse, bf16* __restrict__ dqkv, int ld,
                                                           int H, int N, int dout_cls) {
     constexpr int NPAD = 32 * KT32;
-    constexpr int LDR = ATT_LDR;
     constexpr int NT = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // [lse][delta][tile 0][tile 1]([tile 2][tile 3])
@@ -274,18 +314,18 @@ __global__ __launch_bounds__(64 * NW, (ALL4 ? ATT_BWD_MINW : 1)) void attn_bwd_k
             const int idx = threadIdx.x + NT * it, y = idx >> 3, c = idx & 7;
             if (y >= N) { vq[it] = zero_bf16x8(); vk[it] = zero_bf16x8(); vv[it] = zero_bf16x8(); vd[it] = zero_bf16x8(); vl[it] = 0.f; }
             if (dout_cls && y != 0) vd[it] = zero_bf16x8();
-            *reinterpret_cast<bf16x8*>(Qs + y * LDR + 8 * c) = vq[it];
-            *reinterpret_cast<bf16x8*>(Ks + y * LDR + 8 * c) = vk[it];
-            *reinterpret_cast<bf16x8*>(Vs + y * LDR + 8 * c) = vv[it];
-            *reinterpret_cast<bf16x8*>(dOs + y * LDR + 8 * c) = vd[it];
+            *ldschunk<LDR>(Qs, y, c) = vq[it];
+            *ldschunk<LDR>(Ks, y, c) = vk[it];
+            *ldschunk<LDR>(Vs, y, c) = vv[it];
+            *ldschunk<LDR>(dOs, y, c) = vd[it];
             if (c == 0) {
                 del_s[y] = 0.f;                 // rows < N: written by pass A; the pad rows stay 0 (pass B multiplies them by p = 0)
                 lse_s[y] = vl[it];
             }
         }
     } else {
-        stage_rows(Ks, LDR, kh, 64, N, NPAD);
-        stage_rows(Vs, LDR, vh, 64, N, NPAD);
+        stage_rows<LDR>(Ks, kh, 64, N, NPAD);
+        stage_rows<LDR>(Vs, vh, 64, N, NPAD);
         // delta[y] = sum_d dO[y][d] * O[y][d]   (== sum_keys P*dP), 8 lanes per row
         for (int idx0 = threadIdx.x; idx0 < NPAD * 8; idx0 += 2 * NT) {     // two pieces per round, clamped rows, no load in a branch
             bf16x8 a[2], o[2];
@@ -336,10 +376,10 @@ __global__ __launch_bounds__(64 * NW, (ALL4 ? ATT_BWD_MINW : 1)) void attn_bwd_k
             for (int half = 0; half < 2; ++half) {
                 const int yr = 32 * s + 16 * half + c16;       // padded rows of the LDS tiles are zero
                 f32x4 z1 = {0.f, 0.f, 0.f, 0.f}, z2 = {0.f, 0.f, 0.f, 0.f};
-                z1 = mfma16(rowfrag(Ks, LDR, yr, 0, g), x1[0], z1);
-                z1 = mfma16(rowfrag(Ks, LDR, yr, 1, g), x1[1], z1);
-                z2 = mfma16(rowfrag(Vs, LDR, yr, 0, g), x2[0], z2);
-                z2 = mfma16(rowfrag(Vs, LDR, yr, 1, g), x2[1], z2);
+                z1 = mfma16(ldsfrag<LDR>(Ks, yr, 0, g), x1[0], z1);
+                z1 = mfma16(ldsfrag<LDR>(Ks, yr, 1, g), x1[1], z1);
+                z2 = mfma16(ldsfrag<LDR>(Vs, yr, 0, g), x2[0], z2);
+                z2 = mfma16(ldsfrag<LDR>(Vs, yr, 1, g), x2[1], z2);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = 32 * s + 16 * half + 4 * g + r;
@@ -348,7 +388,7 @@ __global__ __launch_bounds__(64 * NW, (ALL4 ? ATT_BWD_MINW : 1)) void attn_bwd_k
                 }
             }
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16(tfrag_tr(Ks, LDR, dt, s, lane), dsb, o[dt]);
+            for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16(tfrag_tr<LDR>(Ks, dt, s, lane), dsb, o[dt]);
         }
     };
     // partial sums of the shared tile: every wave with a chunk leaves 16 floats per lane, wave 0 adds them in chunk order
@@ -376,8 +416,8 @@ __global__ __launch_bounds__(64 * NW, (ALL4 ? ATT_BWD_MINW : 1)) void attn_bwd_k
             const int xq = 16 * xt + c16;
             const int xs = xq < N ? xq : N - 1;
             bf16x8 x1[2], x2[2];
-            x1[0] = rowfrag(Qr, qst, xs, 0, g);  x1[1] = rowfrag(Qr, qst, xs, 1, g);
-            x2[0] = rowfrag(Dr, dst_, xs, 0, g); x2[1] = rowfrag(Dr, dst_, xs, 1, g);
+            x1[0] = xfrag<ALL4, LDR>(Qr, qst, xs, 0, g);  x1[1] = xfrag<ALL4, LDR>(Qr, qst, xs, 1, g);
+            x2[0] = xfrag<ALL4, LDR>(Dr, dst_, xs, 0, g); x2[1] = xfrag<ALL4, LDR>(Dr, dst_, xs, 1, g);
             const float lse_x = lse_s[xs];
             f32x4 o[4];
             if constexpr (ALL4) {
@@ -391,10 +431,10 @@ __global__ __launch_bounds__(64 * NW, (ALL4 ? ATT_BWD_MINW : 1)) void attn_bwd_k
                     for (int half = 0; half < 2; ++half) {
                         const int yr = 32 * s + 16 * half + c16;       // padded rows of the LDS tiles are zero
                         f32x4 z1 = {0.f, 0.f, 0.f, 0.f}, z2 = {0.f, 0.f, 0.f, 0.f};
-                        z1 = mfma16(rowfrag(Ks, LDR, yr, 0, g), x1[0], z1);
-                        z1 = mfma16(rowfrag(Ks, LDR, yr, 1, g), x1[1], z1);
-                        z2 = mfma16(rowfrag(Vs, LDR, yr, 0, g), x2[0], z2);
-                        z2 = mfma16(rowfrag(Vs, LDR, yr, 1, g), x2[1], z2);
+                        z1 = mfma16(ldsfrag<LDR>(Ks, yr, 0, g), x1[0], z1);
+                        z1 = mfma16(ldsfrag<LDR>(Ks, yr, 1, g), x1[1], z1);
+                        z2 = mfma16(ldsfrag<LDR>(Vs, yr, 0, g), x2[0], z2);
+                        z2 = mfma16(ldsfrag<LDR>(Vs, yr, 1, g), x2[1], z2);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int key = 32 * s + 16 * half + 4 * g + r;
@@ -417,7 +457,7 @@ __global__ __launch_bounds__(64 * NW, (ALL4 ? ATT_BWD_MINW : 1)) void attn_bwd_k
 #pragma unroll
                         for (int r = 0; r < 4; ++r) dsb[half * 4 + r] = f2bf(zp[s][half][r] * (zd[s][half][r] - dsum));
 #pragma unroll
-                    for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16(tfrag_tr(Ks, LDR, dt, s, lane), dsb, o[dt]);
+                    for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16(tfrag_tr<LDR>(Ks, dt, s, lane), dsb, o[dt]);
                 }
             } else {
             passA_chunks(x1, x2, lse_x, del_s[xs], 0, KT32, o);
@@ -430,8 +470,8 @@ __global__ __launch_bounds__(64 * NW, (ALL4 ? ATT_BWD_MINW : 1)) void attn_bwd_k
                 f32x4 o[4];
                 if (wid < KT32) {
                     bf16x8 x1[2], x2[2];
-                    x1[0] = rowfrag(Qr, qst, xs, 0, g);  x1[1] = rowfrag(Qr, qst, xs, 1, g);
-                    x2[0] = rowfrag(Dr, dst_, xs, 0, g); x2[1] = rowfrag(Dr, dst_, xs, 1, g);
+                    x1[0] = xfrag<ALL4, LDR>(Qr, qst, xs, 0, g);  x1[1] = xfrag<ALL4, LDR>(Qr, qst, xs, 1, g);
+                    x2[0] = xfrag<ALL4, LDR>(Dr, dst_, xs, 0, g); x2[1] = xfrag<ALL4, LDR>(Dr, dst_, xs, 1, g);
                     passA_chunks(x1, x2, lse_s[xs], del_s[xs], wid, wid + 1, o);
                 }
                 coop_put(o);
@@ -456,8 +496,8 @@ __global__ __launch_bounds__(64 * NW, (ALL4 ? ATT_BWD_MINW : 1)) void attn_bwd_k
     }
     if constexpr (!ALL4) {
         __syncthreads();                       // every wave is done with K, V
-        stage_rows(Qs, LDR, qh, 64, N, NPAD);
-        stage_rows(dOs, LDR, doh, (size_t)lddo, N, NPAD);
+        stage_rows<LDR>(Qs, qh, 64, N, NPAD);
+        stage_rows<LDR>(dOs, doh, (size_t)lddo, N, NPAD);
         __syncthreads();
     }
     // ---------------- pass B: x = keys, y = queries -> dK, dV -------------------------
@@ -476,10 +516,10 @@ __global__ __launch_bounds__(64 * NW, (ALL4 ? ATT_BWD_MINW : 1)) void attn_bwd_k
                     const int yt = 2 * s + half;
                     const int yr = 16 * yt + c16;
                     f32x4 z1 = {0.f, 0.f, 0.f, 0.f}, z2 = {0.f, 0.f, 0.f, 0.f};
-                    z1 = mfma16(rowfrag(Qs, LDR, yr, 0, g), x1[0], z1);
-                    z1 = mfma16(rowfrag(Qs, LDR, yr, 1, g), x1[1], z1);
-                    z2 = mfma16(rowfrag(dOs, LDR, yr, 0, g), x2[0], z2);
-                    z2 = mfma16(rowfrag(dOs, LDR, yr, 1, g), x2[1], z2);
+                    z1 = mfma16(ldsfrag<LDR>(Qs, yr, 0, g), x1[0], z1);
+                    z1 = mfma16(ldsfrag<LDR>(Qs, yr, 1, g), x1[1], z1);
+                    z2 = mfma16(ldsfrag<LDR>(dOs, yr, 0, g), x2[0], z2);
+                    z2 = mfma16(ldsfrag<LDR>(dOs, yr, 1, g), x2[1], z2);
                     const f32x4 lse_y = *reinterpret_cast<const f32x4*>(lse_s + 16 * yt + 4 * g);
                     const f32x4 del_y = *reinterpret_cast<const f32x4*>(del_s + 16 * yt + 4 * g);
 #pragma unroll
@@ -492,8 +532,8 @@ __global__ __launch_bounds__(64 * NW, (ALL4 ? ATT_BWD_MINW : 1)) void attn_bwd_k
                 }
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
-                    ok[dt] = mfma16(tfrag_tr(Qs, LDR, dt, s, lane), dsb, ok[dt]);
-                    ov[dt] = mfma16(tfrag_tr(dOs, LDR, dt, s, lane), pb, ov[dt]);
+                    ok[dt] = mfma16(tfrag_tr<LDR>(Qs, dt, s, lane), dsb, ok[dt]);
+                    ov[dt] = mfma16(tfrag_tr<LDR>(dOs, dt, s, lane), pb, ov[dt]);
                 }
             }
         };
@@ -501,8 +541,8 @@ __global__ __launch_bounds__(64 * NW, (ALL4 ? ATT_BWD_MINW : 1)) void attn_bwd_k
             const int xk = 16 * xt + c16;
             const int xs = xk < N ? xk : N - 1;
             bf16x8 x1[2], x2[2];
-            x1[0] = rowfrag(Kr, kst, xs, 0, g); x1[1] = rowfrag(Kr, kst, xs, 1, g);
-            x2[0] = rowfrag(Vr, vst, xs, 0, g); x2[1] = rowfrag(Vr, vst, xs, 1, g);
+            x1[0] = xfrag<ALL4, LDR>(Kr, kst, xs, 0, g); x1[1] = xfrag<ALL4, LDR>(Kr, kst, xs, 1, g);
+            x2[0] = xfrag<ALL4, LDR>(Vr, vst, xs, 0, g); x2[1] = xfrag<ALL4, LDR>(Vr, vst, xs, 1, g);
             f32x4 ok[4], ov[4];
             passB_chunks(x1, x2, 0, KT32, ok, ov);
             if (xk < N) {
@@ -517,8 +557,8 @@ __global__ __launch_bounds__(64 * NW, (ALL4 ? ATT_BWD_MINW : 1)) void attn_bwd_k
                 f32x4 ok[4], ov[4];
                 if (wid < KT32) {
                     bf16x8 x1[2], x2[2];
-                    x1[0] = rowfrag(Kr, kst, xs, 0, g); x1[1] = rowfrag(Kr, kst, xs, 1, g);
-                    x2[0] = rowfrag(Vr, vst, xs, 0, g); x2[1] = rowfrag(Vr, vst, xs, 1, g);
+                    x1[0] = xfrag<ALL4, LDR>(Kr, kst, xs, 0, g); x1[1] = xfrag<ALL4, LDR>(Kr, kst, xs, 1, g);
+                    x2[0] = xfrag<ALL4, LDR>(Vr, vst, xs, 0, g); x2[1] = xfrag<ALL4, LDR>(Vr, vst, xs, 1, g);
                     passB_chunks(x1, x2, wid, wid + 1, ok, ov);
                 }
                 __syncthreads();                               // pass A's reduction has read the scratch
@@ -535,25 +575,25 @@ __global__ __launch_bounds__(64 * NW, (ALL4 ? ATT_BWD_MINW : 1)) void attn_bwd_k
     }
 }
 
-template <int KT32, int NW>
+template <int KT32, int NW, int LD>
 int launch_fwd(const bf16* q, const bf16* k, const bf16* v, bf16* out, int ldo, float* lse, int B, int H, int N,
                hipStream_t s, unsigned char* out8) {
     constexpr int NPAD = 32 * KT32;
-    const int bytes = 2 * NPAD * ATT_LDR * 2;
+    const int bytes = 2 * NPAD * LD * 2;
     static bool attr = false;
     if (!attr && bytes > 48 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<KT32, NW>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<KT32, NW, LD>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
             pevit_set_error("attn_fwd: cannot reserve %d bytes of LDS", bytes); return -1;
         }
         attr = true;
     }
-    hipLaunchKernelGGL((attn_fwd_kernel<KT32, NW>), dim3(B * H), dim3(64 * NW), bytes, s, q, k, v, out, ldo, lse, H, N, out8);
+    hipLaunchKernelGGL((attn_fwd_kernel<KT32, NW, LD>), dim3(B * H), dim3(64 * NW), bytes, s, q, k, v, out, ldo, lse, H, N, out8);
     LAUNCH_OK("attn_fwd_kernel");
     return 0;
 }
 
-template <int KT32, bool ALL4, int NW>
+template <int KT32, bool ALL4, int NW, int LD>
 int launch_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* out, int ldo, const bf16* dout, int lddo,
                const float* lse, bf16* dqkv, int ld, int B, int H, int N, hipStream_t s, int dout_cls = 0) {
     constexpr int NPAD = 32 * KT32;
@@ -561,17 +601,17 @@ int launch_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* out, int
     // where it is used: at N = 197 (13 tiles on 8 waves: no shared tile) the 74 KB block must keep admitting two workgroups per CU
     const int ntile = (N + 15) >> 4;
     const bool coop = !ALL4 && (ntile % NW) == 1 && ntile > NW && KT32 <= NW;
-    const int bytes = 2 * NPAD * 4 + (ALL4 ? 4 : 2) * NPAD * ATT_LDR * 2 + (coop ? KT32 * 64 * 16 * 4 : 0);
-    constexpr int bytes_max = 2 * NPAD * 4 + (ALL4 ? 4 : 2) * NPAD * ATT_LDR * 2 + (ALL4 ? 0 : KT32 * 64 * 16 * 4);   // the LIMIT set once; a launch passes what it uses
+    const int bytes = 2 * NPAD * 4 + (ALL4 ? 4 : 2) * NPAD * LD * 2 + (coop ? KT32 * 64 * 16 * 4 : 0);
+    constexpr int bytes_max = 2 * NPAD * 4 + (ALL4 ? 4 : 2) * NPAD * LD * 2 + (ALL4 ? 0 : KT32 * 64 * 16 * 4);   // the LIMIT set once; a launch passes what it uses
     static bool attr = false;
     if (!attr && bytes_max > 48 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<KT32, ALL4, NW>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<KT32, ALL4, NW, LD>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, bytes_max) != hipSuccess) {
             pevit_set_error("attn_bwd: cannot reserve %d bytes of LDS", bytes_max); return -1;
         }
         attr = true;
     }
-    hipLaunchKernelGGL((attn_bwd_kernel<KT32, ALL4, NW>), dim3(B * H), dim3(64 * NW), bytes, s, q, k, v, out, ldo, dout, lddo, lse,
+    hipLaunchKernelGGL((attn_bwd_kernel<KT32, ALL4, NW, LD>), dim3(B * H), dim3(64 * NW), bytes, s, q, k, v, out, ldo, dout, lddo, lse,
                        dqkv, ld, H, N, ALL4 ? dout_cls : 0);
     LAUNCH_OK("attn_bwd_kernel");
     return 0;
@@ -598,9 +638,9 @@ int pevit_launch_attn_fwd(const bf16* q, const bf16* k, const bf16* v, bf16* out
                           int N, hipStream_t s, unsigned char* out8) {
     if (N < 1 || N > 288) { pevit_set_error("attn_fwd: tokens per image N=%d outside [1,288]", N); return -1; }
     if (ldo % 8) { pevit_set_error("attn_fwd: ldo must be a multiple of 8"); return -1; }
-    if (N <= 64) return launch_fwd<2, 4>(q, k, v, out, ldo, lse, B, H, N, s, out8);
-    if (N <= 224) return launch_fwd<7, ATT_NW_MID_F>(q, k, v, out, ldo, lse, B, H, N, s, out8);
-    return launch_fwd<9, ATT_NW_BIG_F>(q, k, v, out, ldo, lse, B, H, N, s, out8);
+    if (N <= 64) return launch_fwd<2, 4, ATT_LD_FWD>(q, k, v, out, ldo, lse, B, H, N, s, out8);
+    if (N <= 224) return launch_fwd<7, ATT_NW_MID_F, ATT_LD_FWD>(q, k, v, out, ldo, lse, B, H, N, s, out8);
+    return launch_fwd<9, ATT_NW_BIG_F, ATT_LD_FWD>(q, k, v, out, ldo, lse, B, H, N, s, out8);
 }
 
 int pevit_launch_attn_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* out, int ldo, const bf16* dout,
@@ -608,8 +648,8 @@ int pevit_launch_attn_bwd(const bf16* q, const bf16* k, const bf16* v, const bf1
     if (N < 1 || N > 288) { pevit_set_error("attn_bwd: tokens per image N=%d outside [1,288]", N); return -1; }
     if ((ldo % 8) || (lddo % 8) || (ld % 8)) { pevit_set_error("attn_bwd: leading dims must be multiples of 8"); return -1; }
     // N <= 64: all four operands LDS-resident; above, the loop side of each pass
-    if (N <= 64) return launch_bwd<2, true, 4>(q, k, v, out, ldo, dout, lddo, lse, dqkv, ld, B, H, N, s, dout_cls_only);
+    if (N <= 64) return launch_bwd<2, true, 4, ATT_LD_BWD_SMALL>(q, k, v, out, ldo, dout, lddo, lse, dqkv, ld, B, H, N, s, dout_cls_only);
     if (dout_cls_only) { pevit_set_error("attn_bwd: dout_cls_only needs N <= 64 (N = %d)", N); return -1; }
-    if (N <= 224) return launch_bwd<7, false, ATT_NW_MID>(q, k, v, out, ldo, dout, lddo, lse, dqkv, ld, B, H, N, s);   // 74 KB: two workgroups per CU
-    return launch_bwd<9, false, ATT_NW_BIG>(q, k, v, out, ldo, dout, lddo, lse, dqkv, ld, B, H, N, s);           // 94 KB: one per CU
+    if (N <= 224) return launch_bwd<7, false, ATT_NW_MID, ATT_LD_BWD_MID>(q, k, v, out, ldo, dout, lddo, lse, dqkv, ld, B, H, N, s);   // 74 KB (padded rows): two workgroups per CU
+    return launch_bwd<9, false, ATT_NW_BIG, ATT_LD_BWD_BIG>(q, k, v, out, ldo, dout, lddo, lse, dqkv, ld, B, H, N, s);           // 76 KB of tiles + 37 KB shared-tile scratch: one per CU
 }
