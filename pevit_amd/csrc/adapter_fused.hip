@@ -235,7 +235,13 @@ __global__ __launch_bounds__(64 * AF_WAVES, AF_MINW) void adapter_fwd_kernel(con
                                                                     const float* __restrict__ b_up, bf16* __restrict__ z,
                                                                     float* __restrict__ mean_a, float* __restrict__ rstd_a,
                                                                     bf16* __restrict__ act, bf16* __restrict__ apre,
-                                                                    float* __restrict__ x_out, int T, int E, int rb) {
+                                                                    float* __restrict__ x_out, int T, int E_rt, int rb) {
+#ifdef AF_E_RUNTIME                                              // (A/B builds)
+    const int E = E_rt;
+#else
+    constexpr int E = 256 * NV;                                 // (the launcher dispatches on E / 256: every offset and trip count below is a constant)
+    (void)E_rt;
+#endif
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const AfLds L = af_layout(E);
     bf16* Zs = reinterpret_cast<bf16*>(smem + L.zs);
@@ -480,8 +486,14 @@ __global__ __launch_bounds__(64 * AF_WAVES, (NV == 4 ? 2 : AF_MINW)) void adapte
                                                                     const float* __restrict__ bpr, const float* __restrict__ mean_a,
                                                                     const float* __restrict__ rstd_a, const float* __restrict__ gamma,
                                                                     bf16* __restrict__ dpre, bf16* __restrict__ dh_bf16,
-                                                                    float* __restrict__ partial, int T, int E, int rb, int nb,
+                                                                    float* __restrict__ partial, int T, int E_rt, int rb, int nb,
                                                                     AfTn tn) {
+#ifdef AF_E_RUNTIME
+    const int E = E_rt;
+#else
+    constexpr int E = 256 * NV;
+    (void)E_rt;
+#endif
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if ((int)blockIdx.x >= nb) {                                 // the contraction range (see af_tn_range)
         af_tn_range(smem, (int)blockIdx.x - nb, (int)gridDim.x - nb, tn, T, E);

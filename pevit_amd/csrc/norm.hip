@@ -11,12 +11,15 @@ namespace {
 
 constexpr int MAXV = 4;   // float4 per lane -> E <= 1024
 
-template <typename ST>
+// NV = E / 256 when E is a multiple of 256 (round 5: no column predicates, no masked fourth group at E = 768), 0 = any E <= 1024
+template <typename ST, int NV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, int rows, int E, size_t xstride,
                                                      bf16* __restrict__ yb, float* __restrict__ yf,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                      unsigned char* __restrict__ y8) {
+    constexpr int NVV = NV > 0 ? NV : MAXV;
+    if constexpr (NV > 0) E = 256 * NV;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -25,12 +28,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     // branch (columns beyond E read column 0 and are masked): a value loaded inside a branch makes hipcc wait with vmcnt(0) at its
     // first use after the join, and on gfx950 that also waits for the STORES issued so far -- the store loop below then paid one
     // store latency per 256 columns (profiles/NOTES_gemm.md (r03_gemm_experiments) section 3 has the same finding for the GEMM epilogues).
-    float4 v[MAXV], gm[MAXV], bt[MAXV];
-    bool ok[MAXV];
+    float4 v[NVV], gm[NVV], bt[NVV];
+    bool ok[NVV];
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NVV; ++i) {
         const int c = lane * 4 + i * 256;
-        ok[i] = c < E;
+        ok[i] = NV > 0 || c < E;
         const int cc = ok[i] ? c : 0;
         v[i] = *reinterpret_cast<const float4*>(xr + cc);
         gm[i] = *reinterpret_cast<const float4*>(gamma + cc);
@@ -38,11 +41,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     }
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) s += ok[i] ? v[i].x + v[i].y + v[i].z + v[i].w : 0.f;
+    for (int i = 0; i < NVV; ++i) s += ok[i] ? v[i].x + v[i].y + v[i].z + v[i].w : 0.f;
     const float mean = wave_sum(s) / (float)E;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NVV; ++i) {
         const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
         q += ok[i] ? a * a + b * b + cc * cc + d * d : 0.f;
     }
@@ -53,7 +56,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         if (rstd_out) rstd_out[row] = rstd;
     }
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NVV; ++i) {
         const int c = lane * 4 + i * 256;
         if (ok[i]) {
             const float4 g = gm[i], b = bt[i];
@@ -79,13 +82,17 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // RES16 (round 5): the residual gradient arrives in the activation storage type (the bf16 copy of the gradient stream that the
 // dX GEMMs read anyway) instead of f32, and dx may be null -- the stream is then carried in bf16 only, read-modify-write in place
 // (dres == dx_bf16: every lane has all its loads in registers before its first store): 10 instead of 16 bytes per element.
-template <typename ST, typename DYT, bool RES16 = false>
+// SCL: power-of-two channel scales may be present (fp8 weights: bscale on the outgoing bf16 copy, rscale on the incoming bf16 residual);
+// false: neither is, and their loads are not issued (they used to re-read gamma as a stand-in: 6 of a lane's 18 requests at E = 768)
+template <typename ST, typename DYT, bool RES16, int NV, bool SCL>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy_, const float* __restrict__ x,
                                                      const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                      const float* __restrict__ gamma, const float* dres,
                                                      float* dx, bf16* dx_bf16, int rows, int E, size_t xstride,
                                                      const float* __restrict__ bscale, int res_period,
-                                                     const float* __restrict__ rscale = nullptr) {
+                                                     const float* __restrict__ rscale) {
+    constexpr int NVV = NV > 0 ? NV : MAXV;
+    if constexpr (NV > 0) E = 256 * NV;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -96,36 +103,36 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
     // bounds branch (columns beyond E read column 0 and are masked; a missing residual gradient reads x and the value is dropped):
     // with the loads inside `if (c < E)` hipcc waited for each 256-column group before requesting the next (four memory round
     // trips per row), and the residual gradient, loaded between the stores, cost a fifth plus one store latency per group.
-    float4 gd[MAXV], xh[MAXV], rs[MAXV], sc[MAXV], xv[MAXV], gv[MAXV];
-    typename std::conditional<sizeof(DYT) == 2, bf16x4, float4>::type dv[MAXV];
-    bf16x4 rs16[MAXV];
-    float4 ru[MAXV];        // RES16 with fp8 weights: the power-of-two channel scales folded into the incoming bf16 stream (taken out again, exactly)
-    const float* usrc = (RES16 && rscale) ? rscale : gamma;
-    bool ok[MAXV];
+    float4 gd[NVV], xh[NVV], rs[NVV], sc[NVV], xv[NVV], gv[NVV];
+    typename std::conditional<sizeof(DYT) == 2, bf16x4, float4>::type dv[NVV];
+    bf16x4 rs16[NVV];
+    float4 ru[NVV];        // RES16 with fp8 weights: the power-of-two channel scales folded into the incoming bf16 stream (taken out again, exactly)
+    const float* usrc = (RES16 && SCL && rscale) ? rscale : gamma;
+    bool ok[NVV];
     // res_period > 0: the residual gradient is zero except on rows that are multiples of res_period (the class-token rows of the
     // last block, whose upstream gradient exists on those rows only): the other rows read nothing of it (row 0 stands in, dropped)
     const float* rsrc = (dres && !RES16) ? dres : x;
     const bf16* rsrc16 = reinterpret_cast<const bf16*>(dres);
     const bool has_res = dres != nullptr && (res_period <= 0 || row % res_period == 0);
     const size_t rb = has_res ? xb : 0;
-    const bool scaled = dx_bf16 && bscale;
+    const bool scaled = SCL && dx_bf16 && bscale;
     const float* ssrc = scaled ? bscale : gamma;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NVV; ++i) {
         const int c = lane * 4 + i * 256;
-        ok[i] = c < E;
+        ok[i] = NV > 0 || c < E;
         const int cc = ok[i] ? c : 0;
         if constexpr (sizeof(DYT) == 2) dv[i] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(dy_) + base + cc);
         else dv[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(dy_) + base + cc);
         xv[i] = *reinterpret_cast<const float4*>(x + xb + cc);
         gv[i] = *reinterpret_cast<const float4*>(gamma + cc);
-        if constexpr (RES16) { rs16[i] = *reinterpret_cast<const bf16x4*>(rsrc16 + rb + cc); ru[i] = *reinterpret_cast<const float4*>(usrc + cc); }
+        if constexpr (RES16) { rs16[i] = *reinterpret_cast<const bf16x4*>(rsrc16 + rb + cc); if constexpr (SCL) ru[i] = *reinterpret_cast<const float4*>(usrc + cc); }
         else rs[i] = *reinterpret_cast<const float4*>(rsrc + rb + cc);
-        sc[i] = *reinterpret_cast<const float4*>(ssrc + cc);
+        if constexpr (SCL) sc[i] = *reinterpret_cast<const float4*>(ssrc + cc);
     }
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NVV; ++i) {
         float4 d;
         if constexpr (sizeof(DYT) == 2) d = make_float4(bf2f(dv[i][0]), bf2f(dv[i][1]), bf2f(dv[i][2]), bf2f(dv[i][3]));
         else d = dv[i];
@@ -136,19 +143,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         s2 += ok[i] ? gd[i].x * xh[i].x + gd[i].y * xh[i].y + gd[i].z * xh[i].z + gd[i].w * xh[i].w : 0.f;
         if constexpr (RES16) {
             rs[i] = make_float4(bf2f(rs16[i][0]), bf2f(rs16[i][1]), bf2f(rs16[i][2]), bf2f(rs16[i][3]));
-            if (rscale) {   // 1 / 2^k, exact: (254 << 23) - bits(2^k)
+            if (SCL && rscale) {   // 1 / 2^k, exact: (254 << 23) - bits(2^k)
                 rs[i].x *= __int_as_float(0x7F000000 - __float_as_int(ru[i].x)); rs[i].y *= __int_as_float(0x7F000000 - __float_as_int(ru[i].y));
                 rs[i].z *= __int_as_float(0x7F000000 - __float_as_int(ru[i].z)); rs[i].w *= __int_as_float(0x7F000000 - __float_as_int(ru[i].w));
             }
         }
         rs[i] = has_res ? rs[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-        sc[i] = scaled ? sc[i] : make_float4(1.f, 1.f, 1.f, 1.f);
+        if constexpr (SCL) sc[i] = scaled ? sc[i] : make_float4(1.f, 1.f, 1.f, 1.f);
     }
     const float m1 = wave_sum(s1) / (float)E;
     const float m2 = wave_sum(s2) / (float)E;
     __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0), visible to the compiler: every load is in before the first (conditional) store
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NVV; ++i) {
         const int c = lane * 4 + i * 256;
         if (ok[i]) {
             float4 o;
@@ -161,7 +168,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
             if (dx_bf16) {
                 // fp8 weights: the consuming GEMM contracts over these columns; their power-of-two channel
                 // scales are folded into its bf16 operand here (exact: ones otherwise), the f32 stream stays unscaled
-                o.x *= sc[i].x; o.y *= sc[i].y; o.z *= sc[i].z; o.w *= sc[i].w;
+                if constexpr (SCL) { o.x *= sc[i].x; o.y *= sc[i].y; o.z *= sc[i].z; o.w *= sc[i].w; }
                 st_store4<ST>(dx_bf16, xb + c, o.x, o.y, o.z, o.w);
             }
         }
@@ -176,10 +183,20 @@ int pevit_launch_ln_fwd(const float* x, const float* gamma, const float* beta, i
     if (E % 4 != 0 || E > 256 * MAXV) { pevit_set_error("ln_fwd: unsupported width %d", E); return -1; }
     if (y_fp8 && E % 128 != 0) { pevit_set_error("ln_fwd: the fp8 copy needs a width that is a multiple of 128"); return -1; }
     if (rows <= 0) return 0;
-    if (f32) hipLaunchKernelGGL(ln_fwd_kernel<float>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, x, gamma, beta, rows, E, xstride,
-                                y_bf16, y_f32, mean, rstd, y_fp8);
-    else hipLaunchKernelGGL(ln_fwd_kernel<bf16>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, x, gamma, beta, rows, E, xstride,
-                            y_bf16, y_f32, mean, rstd, y_fp8);
+    // The E / 256 instances are NOT used by the forward kernel: measured on one box (scripts/experiments/gpu_r5_ln.sh) the generic
+    // predicated form is the faster one here (7.2 against 7.5 us at E = 768, 10.3 against 10.9 at E = 1024) while the backward kernel
+    // gains 14 % from them (11.0 -> 9.5 us); LN_FWD_NV builds them for A/B runs.
+#ifdef LN_FWD_NV_ON
+    const int nv = E % 256 == 0 ? E / 256 : 0;
+#else
+    const int nv = 0;
+#endif
+#define LN_FWD_GO(ST, N) hipLaunchKernelGGL((ln_fwd_kernel<ST, N>), dim3(ceil_div(rows, 4)), dim3(256), 0, s, x, gamma, beta, rows, E, xstride, y_bf16, y_f32, mean, rstd, y_fp8)
+#define LN_FWD_NV(ST) switch (nv) { case 1: LN_FWD_GO(ST, 1); break; case 2: LN_FWD_GO(ST, 2); break; case 3: LN_FWD_GO(ST, 3); break; \
+                                    case 4: LN_FWD_GO(ST, 4); break; default: LN_FWD_GO(ST, 0); }
+    if (f32) { LN_FWD_NV(float) } else { LN_FWD_NV(bf16) }
+#undef LN_FWD_NV
+#undef LN_FWD_GO
     LAUNCH_OK("ln_fwd_kernel");
     return 0;
 }
@@ -192,17 +209,25 @@ int pevit_launch_ln_bwd(const void* dy, const float* x, const float* mean, const
     if (E % 4 != 0 || E > 256 * MAXV) { pevit_set_error("ln_bwd: unsupported width %d", E); return -1; }
     if (rows <= 0) return 0;
     const dim3 grid(ceil_div(rows, 4));
-    if (res16) {
-        if (f32 || !dy_stored || !dx_bf16) { pevit_set_error("ln_bwd: the bf16 residual form needs bf16 storage on both sides"); return -1; }
-        hipLaunchKernelGGL((ln_bwd_kernel<bf16, bf16, true>), grid, dim3(256), 0, s, dy, x, mean, rstd, gamma, dres,
-                           dx_out, dx_bf16, rows, E, xstride, bf16_colscale, res_period, res_colscale);
-    }
-    else if (f32) hipLaunchKernelGGL((ln_bwd_kernel<float, float>), grid, dim3(256), 0, s, dy, x, mean, rstd, gamma, dres,
-                                dx_out, dx_bf16, rows, E, xstride, bf16_colscale, res_period);
-    else if (dy_stored) hipLaunchKernelGGL((ln_bwd_kernel<bf16, bf16>), grid, dim3(256), 0, s, dy, x, mean, rstd, gamma, dres,
-                                           dx_out, dx_bf16, rows, E, xstride, bf16_colscale, res_period);
-    else hipLaunchKernelGGL((ln_bwd_kernel<bf16, float>), grid, dim3(256), 0, s, dy, x, mean, rstd, gamma, dres,
-                            dx_out, dx_bf16, rows, E, xstride, bf16_colscale, res_period);
+    if (res16 && (f32 || !dy_stored || !dx_bf16)) { pevit_set_error("ln_bwd: the bf16 residual form needs bf16 storage on both sides"); return -1; }
+#ifdef LN_NV_OFF
+    const int nv = 0;                          // (A/B builds: the generic kernels)
+#else
+    const int nv = E % 256 == 0 ? E / 256 : 0;
+#endif
+    const bool scl = bf16_colscale != nullptr || res_colscale != nullptr;
+#define LN_BWD_GO(ST, DYT, R, N) do { if (scl) hipLaunchKernelGGL((ln_bwd_kernel<ST, DYT, R, N, true>), grid, dim3(256), 0, s, dy, x, mean, rstd, gamma, dres, \
+                                                    dx_out, dx_bf16, rows, E, xstride, bf16_colscale, res_period, res_colscale); \
+                                      else hipLaunchKernelGGL((ln_bwd_kernel<ST, DYT, R, N, false>), grid, dim3(256), 0, s, dy, x, mean, rstd, gamma, dres, \
+                                                    dx_out, dx_bf16, rows, E, xstride, bf16_colscale, res_period, res_colscale); } while (0)
+#define LN_BWD_NV(ST, DYT, R) switch (nv) { case 1: LN_BWD_GO(ST, DYT, R, 1); break; case 2: LN_BWD_GO(ST, DYT, R, 2); break; \
+                                            case 3: LN_BWD_GO(ST, DYT, R, 3); break; case 4: LN_BWD_GO(ST, DYT, R, 4); break; default: LN_BWD_GO(ST, DYT, R, 0); }
+    if (res16) { LN_BWD_NV(bf16, bf16, true) }
+    else if (f32) { LN_BWD_NV(float, float, false) }
+    else if (dy_stored) { LN_BWD_NV(bf16, bf16, false) }
+    else { LN_BWD_NV(bf16, float, false) }
+#undef LN_BWD_NV
+#undef LN_BWD_GO
     LAUNCH_OK("ln_bwd_kernel");
     return 0;
 }

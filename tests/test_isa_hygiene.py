@@ -57,8 +57,13 @@ def listings(tmp_path_factory):
 
 # (file, mangled-name fragment, loads drained right behind the request, vmcnt(0) between stores, loads between stores): upper bounds
 CASES = [
-    ("norm", "ln_fwd_kernelIDF16b", 0, 0, 0),
-    ("norm", "ln_bwd_kernelIDF16bDF16b", 1, 0, 0),
+    # LayerNorm: the E = 768 instances the towers run (NV = E / 256 = 3; backward: the bf16 gradient-stream form and the f32-residual
+    # form) and the generic any-E ones (NV = 0)
+    ("norm", "ln_fwd_kernelIDF16bLi3E", 0, 0, 0),
+    ("norm", "ln_fwd_kernelIDF16bLi0E", 0, 0, 0),
+    ("norm", "ln_bwd_kernelIDF16bDF16bLb1ELi3E", 1, 0, 0),
+    ("norm", "ln_bwd_kernelIDF16bDF16bLb0ELi3E", 1, 0, 0),
+    ("norm", "ln_bwd_kernelIDF16bDF16bLb0ELi0E", 1, 0, 0),
     ("lowrank", "delta_add_kernelIDF16b", 0, 0, 0),
     # the next slab's X panel is requested between two slabs' stores, and the one explicit vmcnt(0) that brings it in sits there too
     ("lowrank", "lowrank_grad_kernel", 0, 1, 8),
