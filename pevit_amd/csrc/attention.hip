@@ -50,6 +50,9 @@
 #define ATT_LD_BWD_BIG 64
 #endif
 
+// Round 5 measured the token count N as a compile-time constant of these kernels (scripts/experiments/gpu_r5_fixn.sh, _fixn2.sh):
+// the large-N FORWARD kernel gains 10-12 % (31.0 -> 28.0 us at N = 197, 32.2 -> 28.2 at N = 257) and has such instances (template
+// parameter NC; 0 = the runtime argument); the backward kernel does not (-2 % at N = 50, +5 % / +1.5 % at 197 / 257).
 namespace {
 
 __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
@@ -114,10 +117,11 @@ __device__ __forceinline__ void store16(bf16* dst, const f32x4 o[4], float scale
 }
 
 // ------------------------------------------------------------------------------------
-template <int KT32, int NW, int LDK>
+template <int KT32, int NW, int LDK, int NC>
 __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
                                                        const bf16* __restrict__ v, bf16* __restrict__ out, int ldo,
-                                                       float* __restrict__ lse, int H, int N, unsigned char* __restrict__ out8) {
+                                                       float* __restrict__ lse, int H, int N_rt, unsigned char* __restrict__ out8) {
+    const int N = NC ? NC : N_rt;
     constexpr int NPAD = 32 * KT32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* Ks = reinterpret_cast<bf16*>(smem);                 // [NPAD][LDK] row-major (rows beyond N: whatever row N - 1 holds)
@@ -268,7 +272,8 @@ __global__ __launch_bounds__(64 * NW, (ALL4 ? ATT_BWD_MINW : 1)) void attn_bwd_k
                                                           const bf16* __restrict__ v, const bf16* __restrict__ out,
                                                           int ldo, const bf16* __restrict__ dout, int lddo,
                                                           const float* __restrict__ lse, bf16* __restrict__ dqkv, int ld,
-                                                          int H, int N, int dout_cls) {
+                                                          int H, int N_rt, int dout_cls) {
+    const int N = N_rt;
     constexpr int NPAD = 32 * KT32;
     constexpr int NT = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -575,20 +580,20 @@ __global__ __launch_bounds__(64 * NW, (ALL4 ? ATT_BWD_MINW : 1)) void attn_bwd_k
     }
 }
 
-template <int KT32, int NW, int LD>
+template <int KT32, int NW, int LD, int NC = 0>
 int launch_fwd(const bf16* q, const bf16* k, const bf16* v, bf16* out, int ldo, float* lse, int B, int H, int N,
                hipStream_t s, unsigned char* out8) {
     constexpr int NPAD = 32 * KT32;
     const int bytes = 2 * NPAD * LD * 2;
     static bool attr = false;
     if (!attr && bytes > 48 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<KT32, NW, LD>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<KT32, NW, LD, NC>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
             pevit_set_error("attn_fwd: cannot reserve %d bytes of LDS", bytes); return -1;
         }
         attr = true;
     }
-    hipLaunchKernelGGL((attn_fwd_kernel<KT32, NW, LD>), dim3(B * H), dim3(64 * NW), bytes, s, q, k, v, out, ldo, lse, H, N, out8);
+    hipLaunchKernelGGL((attn_fwd_kernel<KT32, NW, LD, NC>), dim3(B * H), dim3(64 * NW), bytes, s, q, k, v, out, ldo, lse, H, N, out8);
     LAUNCH_OK("attn_fwd_kernel");
     return 0;
 }
@@ -639,6 +644,8 @@ int pevit_launch_attn_fwd(const bf16* q, const bf16* k, const bf16* v, bf16* out
     if (N < 1 || N > 288) { pevit_set_error("attn_fwd: tokens per image N=%d outside [1,288]", N); return -1; }
     if (ldo % 8) { pevit_set_error("attn_fwd: ldo must be a multiple of 8"); return -1; }
     if (N <= 64) return launch_fwd<2, 4, ATT_LD_FWD>(q, k, v, out, ldo, lse, B, H, N, s, out8);
+    if (N == 197) return launch_fwd<7, ATT_NW_MID_F, ATT_LD_FWD, 197>(q, k, v, out, ldo, lse, B, H, N, s, out8);      // ViT-B/16
+    if (N == 257) return launch_fwd<9, ATT_NW_BIG_F, ATT_LD_FWD, 257>(q, k, v, out, ldo, lse, B, H, N, s, out8);      // ViT-L/14
     if (N <= 224) return launch_fwd<7, ATT_NW_MID_F, ATT_LD_FWD>(q, k, v, out, ldo, lse, B, H, N, s, out8);
     return launch_fwd<9, ATT_NW_BIG_F, ATT_LD_FWD>(q, k, v, out, ldo, lse, B, H, N, s, out8);
 }
