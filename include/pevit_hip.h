@@ -280,7 +280,8 @@ int pevit_op_im2col_u8(void* stream, const uint8_t* images, const float* mean3, 
  * use the one-tile-per-CU 160x128 / 96x128 k-split tile of the N = E products; 2 = also on problems of several rounds),
  * "gemm_ksplit_stagger" (2 = phased kernel, default; 1 / 0 = the alternate-k-tile kernel with / without the half-iteration
  * offset), "gemm_ksplit_small", "gemm_ksplit_mink", "gemm_kphase_nl" (requests in the LOAD section: 8, or between the
- * MFMAs: 2), "gemm_stagger" (0 = legacy 8-wave kernel, 1 = staggered, 2 = also the 256x128 tile), "gemm_band",
+ * MFMAs: 2), "gemm_kz2" (1 = two workgroups per 160x128 tile, half of K each, where those tiles fill at most half the chip;
+ * default 0: measured slower, profiles/r05_experiments.md), "gemm_stagger" (0 = legacy 8-wave kernel, 1 = staggered, 2 = also the 256x128 tile), "gemm_band",
  * "gemm_skinny" (0 = never use the few-row split-K kernel), "gemm_skinny_maxm" / "_mink" / "_slices", "gemm_sk_share" /
  * "gemm_sk_band" (with gemm_streamk = 2), "lowrank_xcd", "fused_bottleneck", "profile_all", "fused_attn_delta" (0 = delta_add + attn_fwd as two launches), "fp8_tail" (0 = t = xn P as a launch of its own with fp8 weights), "adapter_fused" (0 = the post-MLP adapter as separate
  * LayerNorm / GEMM launches), "lowrank_combo" (0 = lowrank_u and lowrank_grad as two launches per layer) and

@@ -1535,6 +1535,7 @@ extern "C" int pevit_tune(pevit_ctx* c, const char* key, int value) {
     if (key && !strcmp(key, "gemm_ksplit_stagger")) { t.ksplit_stagger = value; return 0; }
     if (key && !strcmp(key, "gemm_ksplit_mink")) { t.ksplit_mink = value; return 0; }
     if (key && !strcmp(key, "gemm_kphase_nl")) { t.kphase_nl = value; return 0; }
+    if (key && !strcmp(key, "gemm_kz2")) { t.kz2 = value; return 0; }
     if (key && !strcmp(key, "gemm_skinny")) { t.skinny = value; return 0; }
     if (key && !strcmp(key, "gemm_skinny_maxm")) { t.skinny_maxm = value; return 0; }
     if (key && !strcmp(key, "gemm_skinny_mink")) { t.skinny_mink = value; return 0; }

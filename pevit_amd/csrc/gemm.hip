@@ -1118,11 +1118,19 @@ __global__ __launch_bounds__(256, 1) void gemm_skinny_kernel(GemmParams p, int t
 // LDS (every wave is past its last k-tile and has no request in flight): fragment f = i * WN + j is FINISHED by group f % 2,
 // which receives the other group's partial at hand[((gw * NF + f) * 16 + r) * 64 + lane] and runs that fragment's epilogue.
 // SCRATCH_OFF: byte offset of the 4 KiB-per-wave epilogue scratch, behind the hand-off area.
-template <int EPI, int WM, int WN, int NWG, int NOWN, int SCRATCH_OFF>
-__device__ __forceinline__ void ksplit_finish(const GemmParams& p, char* smem, f32x16 (&acc)[WM][WN], float4 (&rpre)[NOWN][2][2],
-                                              float (&bpre)[WN][8], int m0, int n0, int grp, int gw, int wm, int wn, int wid, int lane) {
+// KZ (round 5): the tile's K range is split over TWO workgroups (slice z = 0, 1).  After the groups' hand-off each wave holds the
+// workgroup's sums of the fragments it finishes; it publishes them in the stream-K workspace (slab tile * 2 + z, write-through),
+// the workgroup draws a ticket, and the one that arrives LAST adds the other's slab and runs the epilogue -- nobody waits for
+// anybody (no residency requirement), and with two slices the sum does not depend on who was last (a + b = b + a).  Returns false
+// in the workgroup that arrived first (it has nothing left to do for this tile).
+template <int EPI, int WM, int WN, int NWG, int NOWN, int SCRATCH_OFF, bool KZ = false>
+__device__ __forceinline__ bool ksplit_finish(const GemmParams& p, char* smem, f32x16 (&acc)[WM][WN], float4 (&rpre)[NOWN][2][2],
+                                              float (&bpre)[WN][8], int m0, int n0, int grp, int gw, int wm, int wn, int wid, int lane,
+                                              int tile = 0, int z = 0) {
     constexpr bool PRE = (EPI == EPI_BIAS_RESID_F32 || EPI == EPI_BIAS_RESID_KEEP);
     constexpr int NF = WM * WN;
+    constexpr int NOWNF = (NF + 1) / 2;                          // fragments a wave finishes at most
+    constexpr int SLABF = 2 * NWG * NOWNF * 16 * 64;            // floats a workgroup publishes
     float* hand = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int i = 0; i < WM; ++i)
@@ -1133,6 +1141,47 @@ __device__ __forceinline__ void ksplit_finish(const GemmParams& p, char* smem, f
                 for (int r = 0; r < 16; ++r) hand[((gw * NF + i * WN + j) * 16 + r) * 64 + lane] = acc[i][j][r];
             }
     __syncthreads();
+    if constexpr (KZ) {
+        __shared__ unsigned kz_ticket;
+        float* mine = p.sk_slab + (size_t)(tile * 2 + z) * SLABF + (size_t)wid * NOWNF * 1024;
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                if (((i * WN + j) & 1) != grp) continue;
+                const int k = (i * WN + j) >> 1;                  // fragment 2k + grp is this wave's k-th (a compile-time index)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += hand[((gw * NF + i * WN + j) * 16 + r) * 64 + lane];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                    sk_store16_sc1(mine + ((k * 4 + q) * 64 + lane) * 4, v);
+                }
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) kz_ticket = __hip_atomic_fetch_add(p.sk_flag + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (kz_ticket != 1u) return false;                      // workgroup-uniform: the other slice finishes the tile
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (threadIdx.x == 0) __hip_atomic_store(p.sk_flag + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+        const float* other = p.sk_slab + (size_t)(tile * 2 + (1 - z)) * SLABF + (size_t)wid * NOWNF * 1024;
+        f32x4 part[NOWNF][4];                                    // every piece requested before the first add
+#pragma unroll
+        for (int kk = 0; kk < NOWNF; ++kk)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) part[kk][q] = *reinterpret_cast<const f32x4*>(other + ((kk * 4 + q) * 64 + lane) * 4);
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                if (((i * WN + j) & 1) != grp) continue;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][4 * q + r] += part[(i * WN + j) >> 1][q][r];
+            }
+    }
     static_assert(SCRATCH_OFF >= NWG * NF * 16 * 64 * 4, "epilogue scratch must not overlap the hand-off area");
     // 4 KiB of epilogue scratch per wave behind the hand-off area (launch_ksplit sizes the LDS for it)
     float* cw = reinterpret_cast<float*>(smem + SCRATCH_OFF + wid * 4096);
@@ -1144,7 +1193,8 @@ __device__ __forceinline__ void ksplit_finish(const GemmParams& p, char* smem, f
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                cw[row * 32 + (lane & 31)] = acc[i][j][r] + hand[((gw * NF + i * WN + j) * 16 + r) * 64 + lane];
+                if constexpr (KZ) cw[row * 32 + (lane & 31)] = acc[i][j][r];      // (the other group's share went in above)
+                else cw[row * 32 + (lane & 31)] = acc[i][j][r] + hand[((gw * NF + i * WN + j) * 16 + r) * 64 + lane];
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1174,6 +1224,7 @@ __device__ __forceinline__ void ksplit_finish(const GemmParams& p, char* smem, f
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
+    return true;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1345,7 +1396,14 @@ __global__ __launch_bounds__(2 * WGM * WGN * 64, 1) void gemm_ksplit_kernel(Gemm
 //     ends interval 2kt+1 (group 0: after MFMA(kt); group 1: at the end of LOAD(kt)), having issued up to k-tile kt+S-1.
 // Same MFMA order per accumulator and the same final sum (even-steps partial + odd-steps partial differs from the alternate-
 // k-tile split of gemm_ksplit_kernel: results agree to f32 rounding, not bit for bit; tests/test_gpu_ops.py).
-template <int EPI, int WM, int NLREQ>
+// KZ (round 5): two workgroups per tile, each half of the k-tiles (work items [0, ntiles): slice 0, [ntiles, 2 ntiles): slice 1);
+// they meet in ksplit_finish<..., KZ>.  For the long-K N = E products at M = 3200 (batch 64), where 160x128 tiles fill 120 CUs and
+// 96x128 tiles (204) stream 224 rows per k-tile for 96 rows of output: two slices of the larger tile put 240 workgroups on the
+// chip with half the k-walk each.  MEASURED (batch 64, same box, scripts/experiments/gpu_r5_kz.sh): 31.8 / 35.7 us against 29.0 /
+// 31.5 us for the 96x128 tiles (step 3.34 against 3.03 ms): the k-walk does halve, but the meeting of the two slices -- 96 KB
+// written through, a ticket, 96 KB read back by another CU -- costs 9-11 us, more than the walk saves; as everywhere on this part,
+// a dependency through memory inside a kernel costs what a kernel boundary costs.  Off by default (gemm_kz2 = 1 enables it).
+template <int EPI, int WM, int NLREQ, bool KZ = false>
 __global__ __launch_bounds__(512, 2) void gemm_kphase_kernel(GemmParams p, int ntiles) {
     constexpr int NW = 8, NWG = 4, WN = 1, S = 4;
     constexpr int BM = WM * 32, BN = 128, BK = 64;
@@ -1364,10 +1422,13 @@ __global__ __launch_bounds__(512, 2) void gemm_kphase_kernel(GemmParams p, int n
     int coff[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) coff[s] = ((((grp * 2 + s) * 2 + fhalf) ^ fswz) << 4);
-    const int nk = p.K / BK;
+    const int nk_all = p.K / BK;
     // outstanding requests this wave may leave when it needs k-tile t: its pieces of the k-tiles issued after t (at most S - 2)
     // tail / first k-tile: everything this wave has requested so far (drains; at most S - 1 times per tile)
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  for (int work = blockIdx.x; work < (KZ ? 2 * ntiles : ntiles); work += gridDim.x) {
+    const int z = (KZ && work >= ntiles) ? 1 : 0, tile = work - z * ntiles;
+    const int k0 = KZ ? z * (nk_all / 2) : 0;                 // this slice: k-tiles [k0, k0 + nk)
+    const int nk = KZ ? (z ? nk_all - nk_all / 2 : nk_all / 2) : nk_all;
     int m0, n0;
     tile_origin<BM, BN>(p, tile, m0, n0);
     int voff[NP];
@@ -1381,7 +1442,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kphase_kernel(GemmParams p, int n
         int r = (is_a ? m0 : n0) + row;
         const int lim = is_a ? p.M : p.Nb;
         r = r < lim ? r : lim - 1;
-        voff[i] = r * (is_a ? p.lda : p.ldb) * 2 + chunk * 16;
+        voff[i] = r * (is_a ? p.lda : p.ldb) * 2 + chunk * 16 + k0 * 128;
     }
     auto issue_piece = [&](int kt, int i) {
         char* st = smem + (kt & (S - 1)) * STAGE_BYTES;
@@ -1492,7 +1553,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kphase_kernel(GemmParams p, int n
     wait_vmcnt<0>();
     __syncthreads();
     constexpr int SCRATCH = 3 * STAGE_BYTES > NWG * WM * 4096 ? 3 * STAGE_BYTES : NWG * WM * 4096;
-    ksplit_finish<EPI, WM, WN, NWG, NOWN, SCRATCH>(p, smem, acc, rpre, bpre, m0, n0, grp, gw, wm, wn, wid, lane);
+    ksplit_finish<EPI, WM, WN, NWG, NOWN, SCRATCH, KZ>(p, smem, acc, rpre, bpre, m0, n0, grp, gw, wm, wn, wid, lane, tile, z);
     __syncthreads();                                       // the LDS scratch is free before the next tile's first k-tile lands in it
   }
 }
@@ -1532,12 +1593,15 @@ int launch_ksplit(const GemmParams& p, const GemmTune& t, hipStream_t stream) {
     return 0;
 }
 
-template <int EPI, int WM, int NL>
+// floats of stream-K workspace a two-slice launch needs: two slabs per tile (ksplit_finish: 8 waves x ceil(WM / 2) fragments x 1024)
+constexpr long kz_slab_floats(int wm) { return 2L * 8 * ((wm + 1) / 2) * 1024; }
+
+template <int EPI, int WM, int NL, bool KZ = false>
 int launch_kphase(const GemmParams& p, const GemmTune& t, hipStream_t stream) {
     constexpr int bm = WM * 32, bn = 128, stage = (bm + bn) * 128;
     constexpr int scratch = 3 * stage > 4 * WM * 4096 ? 3 * stage : 4 * WM * 4096;
     constexpr int lds = 4 * stage > scratch + 8 * 4096 ? 4 * stage : scratch + 8 * 4096;
-    auto kern = gemm_kphase_kernel<EPI, WM, NL>;
+    auto kern = gemm_kphase_kernel<EPI, WM, NL, KZ>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
@@ -1549,12 +1613,16 @@ int launch_kphase(const GemmParams& p, const GemmTune& t, hipStream_t stream) {
     const long long a = ((long long)p.M * p.lda + p.K) * 2, b = ((long long)p.Nb * p.ldb + p.K) * 2;
     if (a >= (1LL << 31) || b >= (1LL << 31)) return launch_ksplit<EPI, 1, 4, WM, 1, true>(p, t, stream);   // 31-bit buffer offsets
     const int tiles = ceil_div(p.M, bm) * ceil_div(p.N, bn);
-    const int grid = min(tiles, num_cus() & ~7);
+    const int grid = min(KZ ? 2 * tiles : tiles, num_cus() & ~7);
     GemmParams pb = p;
-    pb.band = xcd_band(tiles, ceil_div(p.N, bn), grid, t);
+    pb.band = xcd_band(tiles, ceil_div(p.N, bn), min(tiles, grid), t);
+    pb.kz = KZ ? 2 : 0;
+    if (KZ && (!p.sk_slab || !p.sk_flag || tiles > p.sk_slots || tiles * kz_slab_floats(WM) > (long)p.sk_slots * PEVIT_SK_SLAB_FLOATS)) {
+        pevit_set_error("gemm (two K slices per tile): the stream-K workspace is missing or too small for %d tiles", tiles); return -1;
+    }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, pb, tiles);
     LAUNCH_OK("gemm (phased k-split)");
-    g_last_path = 4;
+    g_last_path = KZ ? 7 : 4;
     return 0;
 }
 
@@ -1762,6 +1830,16 @@ int use_ksplit(const GemmParams& p, const GemmTune& t, int cfg) {
     return 0;
 }
 
+// two workgroups per 160x128 tile, half of K each (gemm_kphase_kernel<..., KZ>): where those tiles fill at most half the chip and
+// each slice still walks >= 16 k-tiles (M = 3200, N = 768, K >= 2048: three products per layer at batch 64)
+bool use_kz2(const GemmParams& p, const GemmTune& t) {
+    if (!t.kz2 || !p.sk_slab || !p.sk_flag) return false;
+    const long tiles = (long)ceil_div(p.M, 160) * ceil_div(p.N, 128);
+    const long long a = ((long long)p.M * p.lda + p.K) * 2, b = ((long long)p.Nb * p.ldb + p.K) * 2;
+    return 2 * tiles <= (num_cus() & ~7) && 4 * tiles >= (num_cus() & ~7) && p.K / 64 >= 32 && tiles <= p.sk_slots &&
+           tiles * kz_slab_floats(5) <= (long)p.sk_slots * PEVIT_SK_SLAB_FLOATS && a < (1LL << 31) && b < (1LL << 31);
+}
+
 // the staggered 8-wave kernel: 256x256 (configuration 4) and 320x256 (5), bf16 B, operands addressable with 31-bit byte offsets
 template <int EPI, int WGM, int WGN, int WM, int WN, int KSP, int OPS>
 int launch_big8(const GemmParams& p, const GemmTune& t, hipStream_t stream) {
@@ -1809,6 +1887,7 @@ int launch_epi(const GemmParams& p, const GemmTune& t, hipStream_t stream) {
     }
     if constexpr (!BF8 && (EPI == EPI_BIAS_RESID_F32 || EPI == EPI_F32 || EPI == EPI_BF16 || EPI == EPI_BIAS_RESID_KEEP || EPI == EPI_PATCH_EMBED)) {
         const int kwm = use_ksplit(p, t, cfg);
+        if (kwm && t.ksplit_stagger == 2 && use_kz2(p, t)) return launch_kphase<EPI, 5, 8, true>(p, t, stream);
         if (kwm && t.ksplit_stagger == 2) {
             // requests between the MFMAs (kphase_nl = 2: two in LOAD, the rest behind every second MFMA) win 3 % back to back and
             // lose 0.9 % in the step (28.14 k vs 27.89 k images/s, two pairs; profiles/NOTES_gemm.md (r03_gemm_experiments) section 8)

@@ -46,6 +46,7 @@ struct GemmParams {
     float* sk_slab; unsigned* sk_flag; int sk_slots;
     int sk_share, sk_band;   // set by the launcher: k-iterations per workgroup, m-tiles per band of the tile walk
     int band;                // set by the launcher: m-tiles per band of gemm.hip tile_origin (0 = TILE_BAND)
+    int kz;                  // set by the launcher: K slices per tile across WORKGROUPS (gemm_kphase_kernel<..., KZ = true>: 2), else 0
 };
 
 // A/B-measurement knobs.  They live in the context (pevit_tune(ctx, ...)); the single-kernel pevit_op_* entry
@@ -64,6 +65,7 @@ struct GemmTune {
     int ksplit_stagger = 2;   // ... 1: its two wave groups half an iteration apart (alternate k-tiles); 2: phased kernel (groups split each k-tile, 4 stages)
     int skinny = 1;           // few-row long-K products (M <= skinny_maxm, K >= 64 * skinny_mink): K slices, last arriver sums the slabs (gemm_skinny_kernel)
     int skinny_maxm = 128, skinny_mink = 24, skinny_slices = 0;   // skinny_slices > 0: measurement
+    int kz2 = 0;              // ... opt-in (round 5, measured slower): two workgroups per 160x128 tile, half of K each, where those tiles fill at most half the chip (M = 3200, N = 768, long K)
     int kphase_nl = 8;        // ... phased kernel: LDS-DMA pieces per k-tile requested in the LOAD section (the rest between the MFMAs)
     int ksplit_mink = 512;    // ... from this K on
     int band = -1;        // >= 0 forces GemmParams::band of the one-round 8-wave launches (measurement); -1 = XCD-aligned

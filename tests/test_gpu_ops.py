@@ -400,6 +400,51 @@ def test_gemm_phased_ksplit_tile(lib, M, N, K, nl):
     assert torch.equal(x, o1)
 
 
+@pytest.mark.parametrize("M,N,K", [(3200, 768, 3072), (3111, 768, 2368), (3200, 768, 2048), (3200, 760, 3072)])
+def test_gemm_two_k_slices_per_tile(lib, M, N, K):
+    """gemm_kphase_kernel<..., KZ> (round 5): where 160x128 tiles fill at most half the chip (batch 64: M = 3200, N = 768) and K is
+    long, TWO workgroups share a tile, half of the k-tiles each; the one that arrives last adds the other's partial (stream-K
+    workspace, one ticket per tile) and runs the epilogue.  Every epilogue the step runs on it against the torch product; an odd
+    number of k-tiles (K = 2368: 18 + 19), the shortest slices the heuristic admits (K = 2048), ragged M and N; launched three times
+    (the tickets must be back at zero) with bit-identical results (two slices: the sum does not depend on who arrives last); and
+    against the one-workgroup-per-tile form of the same shapes to f32 summation order."""
+    A = rnd(M, K, seed=1, dtype=torch.bfloat16)
+    B = rnd(N, K, seed=2, scale=0.05, dtype=torch.bfloat16)
+    bias = rnd(N, seed=5, scale=0.1)
+    resid = rnd(M, N, seed=6)
+    ref = A.float() @ B.float().T
+    outs = []
+    assert lib.pevit_tune(None, b"gemm_kz2", 1) == 0          # opt-in: measured slower than the 96x128 tiles it replaces (gemm.hip)
+    try:
+        for rep in range(3):
+            o1 = torch.full((M, N), float("nan"), device="cuda")
+            gemm(lib, EPI["BIAS_RESID"], A, B, M, N, K, bias=bias, resid=resid, outf=o1)
+            assert lib.pevit_debug_last_gemm_path() == 7, "the heuristic did not take the two-slice form for this shape"
+            o2 = torch.full((M, N), float("nan"), device="cuda")
+            gemm(lib, EPI["F32"], A, B, M, N, K, outf=o2)
+            o3 = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
+            gemm(lib, EPI["BF16"], A, B, M, N, K, outb=o3)
+            assert lib.pevit_debug_last_gemm_path() == 7
+            x = resid.clone()
+            gemm(lib, EPI["BIAS_RESID"], A, B, M, N, K, bias=bias, resid=x, outf=x)      # in place on the residual stream
+            outs.append((o1, o2, o3, x))
+    finally:
+        lib.pevit_tune(None, b"gemm_kz2", 0)
+    p2 = torch.full((M, N), float("nan"), device="cuda")
+    gemm(lib, EPI["F32"], A, B, M, N, K, outf=p2)
+    assert lib.pevit_debug_last_gemm_path() != 7
+    o1, o2, o3, x = outs[0]
+    assert max_rel(o1.cpu(), (ref + bias + resid).cpu()) < 2e-4
+    assert max_rel(o2.cpu(), ref.cpu()) < 2e-4
+    assert max_rel(o3.float().cpu(), ref.cpu()) < 1e-2
+    assert max_rel(o2.cpu(), p2.cpu()) < 1e-5
+    assert torch.equal(x, o1)
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert torch.equal(a, b)
+    assert lib.pevit_streamk_error(None, S()) == 0
+
+
 @pytest.mark.parametrize("M,N,K,slices", [(128, 768, 3072, 0), (64, 768, 3072, 0), (128, 768, 3072, 2), (128, 768, 3072, 6), (128, 768, 3072, 1),
                                           (100, 512, 1600, 0), (1, 768, 2048, 3), (128, 760, 1536, 5), (37, 1024, 4096, 0)])
 def test_gemm_few_row_split_k(lib, M, N, K, slices):
