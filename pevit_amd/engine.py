@@ -492,12 +492,30 @@ class HipEngine:
                 torch.cuda.current_stream(self.device).wait_event(done)
         return _W()
 
-    def forward_backward_dp(self, images, labels, bn_training=True, process_group=None):
-        """forward_backward() cut into stages so that the gradient exchange overlaps the backward; leaves the
-        SUM over ranks in ``self.grads``.  Three buckets of the flat buffer, each all-reduced asynchronously as soon as its
-        gradients are final:  head (after the head backward) | blocks L/2..L-1 (after the upper half of the tower backward)
-        | shared rules + blocks 0..L/2-1 (at the end).  Same kernels in the same order as the fused call, so a single rank
-        reproduces forward_backward() bit for bit."""
+    #: how forward_backward_dp exchanges the gradients: "single" = the fused forward/backward call, then ONE all-reduce of the whole
+    #: flat buffer (406 KB for KAdaptation) | "staged" = the backward cut into stages with three overlapped buckets (rounds 2-4).
+    #: Round 5 made "single" the default: the exchange is latency-bound at this size, so what the staged route can hide is the
+    #: transfer of two of its three buckets, while the LAST bucket's latency is exposed either way -- and the staging itself (a
+    #: second reduce / chain / rule-sum group, three hand-overs to the collective's stream, stream-K off) costs 2.2-3.9 % of the
+    #: step on one rank (profiles/r04_dp_evidence.md) against 0.4-0.8 % for one exchange behind the fused call (bench.py --dp-route).
+    dp_exchange_mode = "single"
+
+    def forward_backward_dp(self, images, labels, bn_training=True, process_group=None, mode=None):
+        """forward_backward() followed by the gradient exchange; leaves the SUM over ranks in ``self.grads``.
+        mode "single" (default, ``dp_exchange_mode``): the fused call, then one all-reduce of the flat gradient buffer.
+        mode "staged": the call cut into stages so that the exchange overlaps the backward -- three buckets of the flat buffer, each
+        all-reduced asynchronously as soon as its gradients are final:  head (after the head backward) | blocks L/2..L-1 (after
+        the upper half of the tower backward) | shared rules + blocks 0..L/2-1 (at the end).  Same kernels in the same order as
+        the fused call either way, so a single rank reproduces forward_backward() bit for bit."""
+        mode = mode or self.dp_exchange_mode
+        if mode == "single":
+            if getattr(self, "_dp_streamk_off", False):        # (a staged step before this one switched it off)
+                self.tune("gemm_streamk", 1); self._dp_streamk_off = False
+            logits, loss = self.forward_backward(images, labels, bn_training)
+            self._exchange(self.grads, process_group).wait()
+            return logits, loss
+        if mode != "staged":
+            raise ValueError(f"forward_backward_dp: unknown mode {mode!r}")
         import torch.distributed as dist
         B = images.shape[0]
         self._check_batch(images, labels)

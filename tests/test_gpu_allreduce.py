@@ -133,12 +133,13 @@ def test_external_error_word_withholds_the_update_and_marks_the_loss():
     _lib.check(eng.lib.pevit_set_external_poison(eng._ctx, None), "pevit_set_external_poison")
 
 
-def _step_worker(rank, world, port, case, flat, out_dir):
+def _step_worker(rank, world, port, case, flat, out_dir, mode="staged"):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from test_gpu_dp import LR, MOM, STEPS, WD, _batch, _make_engine
     eng, t = _make_engine(case, 4)
+    eng.dp_exchange_mode = mode
     eng.sync_replicas()
     if flat:
         eng.use_flat_allreduce()
@@ -154,17 +155,18 @@ def _step_worker(rank, world, port, case, flat, out_dir):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("mode", ["staged", "single"])
 @pytest.mark.parametrize("case", ["tiny_kadaptation", "tiny_adapter"])
-def test_dp_step_through_allreduce_flat_equals_the_process_group_route(case, tmp_path):
-    """engine.forward_backward_dp with its three buckets exchanged by pevit_allreduce_flat on a side stream (use_flat_allreduce)
-    against the same step through torch.distributed.all_reduce: parameters, momentum and gradients agree bit for bit on both
-    ranks after three steps."""
+def test_dp_step_through_allreduce_flat_equals_the_process_group_route(case, mode, tmp_path):
+    """engine.forward_backward_dp with its buckets (three overlapped ones, "staged"; or the whole flat buffer behind the fused call,
+    "single") exchanged by pevit_allreduce_flat on a side stream (use_flat_allreduce) against the same step through
+    torch.distributed.all_reduce: parameters, momentum and gradients agree bit for bit on both ranks after three steps."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     world = 2
     for flat in (False, True):
-        port = 29900 + (os.getpid() % 1000) + (500 if flat else 0)
-        mp.spawn(_step_worker, args=(world, port, case, flat, str(tmp_path)), nprocs=world, join=True)
+        port = 29900 + (os.getpid() % 1000) + (500 if flat else 0) + (250 if mode == "single" else 0)
+        mp.spawn(_step_worker, args=(world, port, case, flat, str(tmp_path), mode), nprocs=world, join=True)
     for r in range(world):
         a, b = torch.load(tmp_path / f"flat{r}.pt"), torch.load(tmp_path / f"pg{r}.pt")
         for k in ("p", "g", "m"):

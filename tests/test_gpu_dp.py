@@ -39,11 +39,12 @@ def _batch(t, rank, world):
     return dp.shard_batch(img, lab, rank, world)
 
 
-def _worker(rank, world, port, case, out_dir):
+def _worker(rank, world, port, case, out_dir, mode):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     eng, t = _make_engine(case, 4)
+    eng.dp_exchange_mode = mode
     if rank == 1:
         eng.params.mul_(1.5); eng.running_mean.add_(3.0)          # a diverged replica ...
     eng.sync_replicas()                                            # ... is brought back to rank 0's state
@@ -62,12 +63,15 @@ def _worker(rank, world, port, case, out_dir):
     dist.destroy_process_group()
 
 
+# mode: "single" = the fused call + one all-reduce of the flat gradient buffer (the default since round 5); "staged" = the backward in
+# two halves with three overlapped buckets
+@pytest.mark.parametrize("mode", ["single", "staged"])
 @pytest.mark.parametrize("case", ["tiny_kadaptation", "tiny_lora", "tiny_adapter"])
-def test_two_rank_hip_step_equals_mean_of_shard_steps(case, tmp_path):
+def test_two_rank_hip_step_equals_mean_of_shard_steps(case, mode, tmp_path):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    world, port = 2, 29600 + (os.getpid() % 2000)
-    mp.spawn(_worker, args=(world, port, case, str(tmp_path)), nprocs=world, join=True)
+    world, port = 2, 29600 + (os.getpid() % 2000) + (11 if mode == "staged" else 0)
+    mp.spawn(_worker, args=(world, port, case, str(tmp_path), mode), nprocs=world, join=True)
     r0 = torch.load(tmp_path / "rank0.pt"); r1 = torch.load(tmp_path / "rank1.pt")
     for k in ("p", "g", "m"):
         assert torch.equal(r0[k], r1[k]), k                      # replicas bit-identical after 3 steps
