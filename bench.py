@@ -230,9 +230,10 @@ def main():
     ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8", "fp8-act"],
                     help="frozen block weights: bf16, or e4m3 codes + per-channel scales (BASELINE config 5 with --arch ViT-L/14)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dp-exchange", choices=["single", "staged"], default="single",
+    ap.add_argument("--dp-exchange", choices=["single", "staged", "pipelined"], default="single",
                     help="(N > 1) single: the fused forward/backward call, then ONE all-reduce of the flat gradient buffer (default); "
-                         "staged: the backward in two halves with three overlapped buckets (rounds 2-4)")
+                         "staged: the backward in two halves with three overlapped buckets (rounds 2-4); pipelined: single with the "
+                         "exchange + SGD on a second stream under the next step's stem (pevit_set_step_gate)")
     ap.add_argument("--dp-route", action="store_true",
                     help="(N = 1) also time the step through engine.forward_backward_dp on a 1-rank RCCL group -- staged backward, "
                          "stream-K off, three asynchronous bucketed all-reduces -- and report it beside the fused step (dp_route)")
@@ -397,9 +398,13 @@ def main():
         def dp_staged():
             eng.forward_backward_dp(images, labels, mode="staged")
             eng.sgd_step(0.01, 0.9, 1e-6, 1.0)
+        def dp_pipelined():
+            eng._train_step_pipelined(images, labels, 0.01, 0.9, 1e-6, True, None, 1, False, None, None)
         res = {}
         # (the staged route switches stream-K off; "fused_streamk_off" is the fused step in that state)
-        for name, fn in (("dp_single", dp_single), ("dp_staged", dp_staged), ("fused_streamk_off", step)):
+        for name, fn in (("dp_single", dp_single), ("dp_pipelined", dp_pipelined), ("dp_staged", dp_staged), ("fused_streamk_off", step)):
+            if name == "dp_staged":
+                eng.dp_pipeline_off()
             for _ in range(5):
                 fn()
             torch.cuda.synchronize()
@@ -412,11 +417,13 @@ def main():
             res[name] = v[len(v) // 2]
         torch.distributed.destroy_process_group()
         dp_route = {"median_ms_per_step": res["dp_" + args.dp_exchange], "single_exchange_median_ms": res["dp_single"],
-                    "staged_exchange_median_ms": res["dp_staged"], "fused_step_streamk_off_median_ms": res["fused_streamk_off"],
+                    "staged_exchange_median_ms": res["dp_staged"], "pipelined_exchange_median_ms": res["dp_pipelined"],
+                    "pipelined_over_fused": res["dp_pipelined"] / median_ms, "fused_step_streamk_off_median_ms": res["fused_streamk_off"],
                     "fused_step_median_ms": median_ms, "dp_route_over_fused": res["dp_" + args.dp_exchange] / median_ms,
                     "single_over_fused": res["dp_single"] / median_ms, "staged_over_fused": res["dp_staged"] / median_ms,
                     "how": "engine.forward_backward_dp + SGD on a 1-rank RCCL process group: single = the fused call + one all-reduce of "
-                           "the flat gradient buffer; staged = backward in two halves, stream-K off, head / upper-half / lower-half "
+                           "the flat gradient buffer; pipelined = single with the exchange + SGD on a second stream under the next "
+                           "step's stem; staged = backward in two halves, stream-K off, head / upper-half / lower-half "
                            "buckets all-reduced asynchronously.  The host-side and launch-structure cost of the DP path; N > 1 "
                            "remains unmeasured"}
         eng.tune("gemm_streamk", 1); eng._dp_streamk_off = False
@@ -480,8 +487,8 @@ def main():
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "step_launch": "hip-graph replay" if (args.graph and world == 1) else "eager (one C call, ~200 kernel launches)",
                        "gradient_exchange": ("none" if world == 1 else args.exchange), "rccl_ranks": world if (world > 1 and args.dist_backend == "nccl") else 0,
-                       "gradient_buckets": 0 if world == 1 else (1 if args.dp_exchange == "single" else 3),
-                       "gradient_exchange_schedule": "none" if world == 1 else ("one all-reduce of the flat buffer behind the fused forward/backward call" if args.dp_exchange == "single" else "three buckets overlapped with the staged backward"), "exchanged_floats_per_step": 0 if world == 1 else int(eng.n_params),
+                       "gradient_buckets": 0 if world == 1 else (3 if args.dp_exchange == "staged" else 1),
+                       "gradient_exchange_schedule": "none" if world == 1 else {"single": "one all-reduce of the flat buffer behind the fused forward/backward call", "pipelined": "one all-reduce of the flat buffer + SGD on a second stream under the next step's stem", "staged": "three buckets overlapped with the staged backward"}[args.dp_exchange], "exchanged_floats_per_step": 0 if world == 1 else int(eng.n_params),
                        "train_gflop_per_image": gflop, "final_loss": final_loss},
             "roofline": {"bound": "mfma", "kernel": "gemm8_kernel<...> + gemm_kphase_kernel<...> + gemm_kernel<...> + gemm_streamk_kernel<...> (pevit_amd/csrc/gemm.hip: all epilogues / tile shapes)",
                          "achieved": gemm_tflops, "peak": peak, "unit": "TFLOP/s",

@@ -333,6 +333,12 @@ const unsigned* pevit_ar_error_word(pevit_ar* ar);
 int pevit_ar_reset(pevit_ar* ar, void* stream);
 int pevit_ar_fine_grained(pevit_ar* ar);
 int pevit_set_external_poison(pevit_ctx* ctx, const unsigned* device_word);
+/* Round 5 (data parallelism; no reference counterpart -- /root/reference/vision_benchmark/utils/comm.py is dormant): a hipEvent_t the
+ * fused step (pevit_train_forward_backward[_u8]) waits for on its stream AFTER the stem (patch gather, patch embedding, class /
+ * position rows, ln_pre: no trainable parameter, no gradient) and BEFORE the adapters are first read and the gradient buffer is
+ * cleared.  Recorded by the caller behind the previous step's gradient exchange + pevit_sgd_step, which may then run on another
+ * stream, under the next step's stem (engine.HipEngine dp_exchange_mode = "pipelined").  NULL detaches it. */
+int pevit_set_step_gate(pevit_ctx* ctx, void* hip_event);
 
 #ifdef __cplusplus
 }

@@ -107,6 +107,7 @@ SIGNATURES = {
     "pevit_ar_fine_grained": (c_int, [P]),
     "pevit_ar_reset": (c_int, [P, P]),
     "pevit_set_external_poison": (c_int, [P, P]),
+    "pevit_set_step_gate": (c_int, [P, P]),               # round 5: the fused step waits for this event behind its stem (pipelined DP)
     "pevit_streamk_error": (c_int, [P, P]),
     "pevit_streamk_status": (c_int, [P, P, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
 }

@@ -109,6 +109,8 @@ struct pevit_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // A/B-measurement knobs (pevit_tune): per context, so that contexts stay independent of each other
     GemmTune tune;
+    hipEvent_t step_gate = nullptr;         // pevit_set_step_gate: the fused step waits for it between the stem and the first block
+    bool gate_now = false;                  // (set by train_fb_impl for the forward pass it starts)
     const unsigned* ext_poison = nullptr;   // pevit_set_external_poison: a second error word that withholds the optimizer update (the DP exchange's)
     bool in_fused_step = false;
     const float* dfeatb_of = nullptr;       // the dfeat buffer whose bf16 copy the head's BatchNorm backward has just left in w_dfeatb (consumed by the next visual backward)
@@ -1083,6 +1085,17 @@ extern "C" int pevit_set_external_poison(pevit_ctx* c, const unsigned* device_wo
     return 0;
 }
 
+// Round 5, data parallelism: an event the FUSED step (pevit_train_forward_backward[_u8]) waits for on its stream AFTER the stem
+// (patch gather, patch embedding, class / position rows, ln_pre -- nothing of which reads a trainable parameter or touches the
+// gradient buffer) and BEFORE the first use of the adapters and the clearing of the gradients.  The caller records it behind the
+// previous step's gradient exchange + optimizer update, which it may then run on another stream: the exchange's latency and its
+// cross-stream hand-overs run under ~70 us of the next step's stem instead of between two steps.  nullptr detaches it.
+extern "C" int pevit_set_step_gate(pevit_ctx* c, void* event) {
+    if (!c) { pevit_set_error("set_step_gate: null context"); return -1; }
+    c->step_gate = (hipEvent_t)event;
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------
 extern "C" int pevit_load_stem(pevit_ctx* c, void* stream, const float* conv_w, const float* cls, const float* pos,
                                const float* lnpre_w, const float* lnpre_b, const float* lnpost_w, const float* lnpost_b,
@@ -1157,6 +1170,11 @@ static int visual_forward_impl(pevit_ctx* c, void* stream, const void* images_an
     }
     CHECK(pevit_launch_ln_fwd(xpre, at<float>(A, c->a_lnpre_w), at<float>(A, c->a_lnpre_b), T, E, nullptr,
                               at<float>(W, c->sav[0].x_in), nullptr, nullptr, s));
+    if (c->gate_now) {                                  // fused step with a gate (pevit_set_step_gate): parameters and gradient buffer from here on
+        c->gate_now = false;
+        HIP_OK(hipStreamWaitEvent(s, c->step_gate, 0));
+        CHECK(pevit_zero_grads(c, stream));
+    }
     CHECK(blocks_forward(c, s, B, true));
     // ln_post on the class token of every image (row b*N), then @ proj
     CHECK(pevit_launch_ln_fwd(at<float>(W, c->w_xfinal), at<float>(A, c->a_lnpost_w), at<float>(A, c->a_lnpost_b), B, E,
@@ -1260,8 +1278,11 @@ extern "C" int pevit_train_forward_backward_u8(pevit_ctx* c, void* stream, const
 static int train_fb_impl(pevit_ctx* c, void* stream, const void* images, int u8, const int64_t* labels, float* running_mean,
                          float* running_var, int bn_training, float* logits, float* loss, int B) {
     CHECK(check_ready(c, B, "train_forward_backward"));
-    CHECK(pevit_zero_grads(c, stream));
-    CHECK(visual_forward_impl(c, stream, images, u8, nullptr, B, 1));
+    c->gate_now = c->step_gate != nullptr;              // with a gate the gradients are cleared behind it, inside the forward pass
+    if (!c->gate_now) CHECK(pevit_zero_grads(c, stream));
+    const int frc = visual_forward_impl(c, stream, images, u8, nullptr, B, 1);
+    c->gate_now = false;
+    if (frc) return frc;
     float* feat = at<float>(c->ws, c->w_feat);
     float* dfeat = at<float>(c->ws, c->w_dfeat);
     c->in_fused_step = true;

@@ -161,6 +161,7 @@ class HipEngine:
         return out
 
     def grad_views(self):
+        self.dp_flush()
         return self.param_views(self.grads)
 
     # ------------------------------------------------------------------ frozen weights
@@ -275,6 +276,7 @@ class HipEngine:
         return dx
 
     def visual_forward(self, images: torch.Tensor, save: bool = True) -> torch.Tensor:
+        self.dp_flush()
         B = images.shape[0]
         img = images.contiguous() if images.dtype == torch.uint8 else images.contiguous().float()
         self._check_batch(img)
@@ -287,6 +289,7 @@ class HipEngine:
         return feat
 
     def visual_backward(self, dfeat: torch.Tensor):
+        self.dp_flush()
         B = dfeat.shape[0]
         d = dfeat.contiguous().float()
         _lib.check(self.lib.pevit_visual_backward(self._ctx, _lib.stream_ptr(), _lib.ptr(d), B), "pevit_visual_backward")
@@ -303,6 +306,7 @@ class HipEngine:
         return logits, loss, dfeat
 
     def zero_grad(self):
+        self.dp_flush()
         _lib.check(self.lib.pevit_zero_grads(self._ctx, _lib.stream_ptr()), "pevit_zero_grads")
 
     def forward_backward(self, images, labels, bn_training=True, logits_out=None, loss_out=None):
@@ -403,6 +407,7 @@ class HipEngine:
     def reset_run(self):
         """State a fresh ``Classifier`` would have, with the frozen backbone left resident (the
         reference rebuilds everything for each of its ~90 sweep runs)."""
+        self.dp_flush()
         self.reset_optimizer()
         self.params.zero_(); self.grads.zero_()
         self.running_mean.zero_(); self.running_var.fill_(1.0)
@@ -418,6 +423,9 @@ class HipEngine:
             logits, loss = self.forward_backward(images, labels, bn_training, logits_out, loss_out)
             self.sgd_step(lr, momentum, weight_decay, 1.0, nesterov)
             return logits, loss
+        if self.dp_exchange_mode == "pipelined":
+            return self._train_step_pipelined(images, labels, lr, momentum, weight_decay, bn_training, process_group, world_size,
+                                              nesterov, logits_out, loss_out)
         logits, loss = self.forward_backward_dp(images, labels, bn_training, process_group)
         if logits_out is not None:
             logits_out.copy_(logits)
@@ -425,6 +433,48 @@ class HipEngine:
             loss_out.copy_(loss)
         self.sgd_step(lr, momentum, weight_decay, 1.0 / world_size, nesterov)
         return logits, loss
+
+    # ---- DP with the exchange under the next step's stem (round 5) ----------------------------------------------------------------
+    def _train_step_pipelined(self, images, labels, lr, momentum, weight_decay, bn_training, process_group, world_size, nesterov,
+                              logits_out, loss_out):
+        """``dp_exchange_mode = "pipelined"``: the fused forward/backward call on the current stream; the all-reduce of the flat
+        gradient buffer and the fused SGD kernel on a SECOND stream behind it; the next fused call runs its stem (patch gather,
+        patch embedding, ln_pre: ~70 us that read no trainable parameter) and only then waits, on the device, for the update
+        (``pevit_set_step_gate``).  The exchange's latency and the cross-stream hand-overs around the collective leave the critical
+        path.  Same kernels, same order of arithmetic as the other modes: bit-identical results (tests/test_gpu_dp.py).
+        The caller's obligations: every step of a run goes through ``train_step`` on ONE stream; ``dp_flush()`` before anything
+        else reads parameters / momentum / gradients or launches on them (validation, ``state_dict``, another mode) -- the
+        engine's own entry points that do so call it."""
+        cur = torch.cuda.current_stream(self.device)
+        st = getattr(self, "_pipe", None)
+        if st is None:
+            st = self._pipe = {"stream": torch.cuda.Stream(self.device), "grads": torch.cuda.Event(), "params": torch.cuda.Event(),
+                               "open": False}
+            st["params"].record(cur)                       # (creates the event: nothing to wait for before the first step)
+            _lib.check(self.lib.pevit_set_step_gate(self._ctx, C.c_void_p(st["params"].cuda_event)), "pevit_set_step_gate")
+        st["open"] = True
+        logits, loss = self.forward_backward(images, labels, bn_training, logits_out, loss_out)     # waits for st["params"] behind its stem
+        st["grads"].record(cur)
+        with torch.cuda.stream(st["stream"]):
+            st["stream"].wait_event(st["grads"])
+            self._exchange(self.grads, process_group, in_stream=True).wait()
+            self.sgd_step(lr, momentum, weight_decay, 1.0 / world_size, nesterov)
+            st["params"].record(st["stream"])
+        return logits, loss
+
+    def dp_flush(self):
+        """Pipelined DP: make the current stream wait for the last exchange + update (no-op otherwise)."""
+        st = getattr(self, "_pipe", None)
+        if st is not None and st["open"]:
+            torch.cuda.current_stream(self.device).wait_event(st["params"])
+            st["open"] = False
+
+    def dp_pipeline_off(self):
+        """Leave the pipelined schedule: flush, detach the step gate from the context, drop the second stream."""
+        self.dp_flush()
+        if getattr(self, "_pipe", None) is not None:
+            _lib.check(self.lib.pevit_set_step_gate(self._ctx, None), "pevit_set_step_gate")
+            self._pipe = None
 
     # ---- whole-step HIP graph (SURVEY section 7 step 7; VERDICT r4 item 5) -----------------------------------------------------
     def capture_train_step(self, images, labels, lr, momentum=0.9, weight_decay=0.0, bn_training=True, nesterov=False):
@@ -436,6 +486,7 @@ class HipEngine:
         (tests/test_gpu_mirror.py::test_graph_replay_equals_eager).  Measured: profiles/r05_graph_capture.md."""
         if self._steps == 0:
             raise _lib.PevitError("capture_train_step: run one eager train_step first (first-step flag, one-time kernel attributes)")
+        self.dp_flush()
         B = images.shape[0]
         self._check_batch(images, labels)
         fn = self.lib.pevit_train_forward_backward_u8 if images.dtype == torch.uint8 else self.lib.pevit_train_forward_backward
@@ -475,12 +526,30 @@ class HipEngine:
         _lib.check(self.lib.pevit_set_external_poison(self._ctx, C.c_void_p(self._flat_ar.error_word())), "pevit_set_external_poison")
         return self._flat_ar
 
-    def _exchange(self, view, process_group):
-        """Start the sum all-reduce of one gradient bucket; returns something with .wait()."""
+    def _exchange(self, view, process_group, in_stream=False):
+        """Start the sum all-reduce of one gradient bucket; returns something with .wait().
+        in_stream: nothing is to run beside the exchange (the single-exchange schedule): the SYNCHRONOUS form of the collective,
+        which this torch enqueues on the CURRENT stream.  Measured on a 1-rank RCCL group (scripts/r5_dp_hosttime.py): a round trip
+        through a second stream -- what ``async_op=True`` + ``wait()`` is, with or without a collective on it -- costs 74 us of
+        device time per step on this platform, the synchronous call 7 us."""
         import torch.distributed as dist
         ar = getattr(self, "_flat_ar", None)
+        if ar is None and in_stream:
+            dist.all_reduce(view, op=dist.ReduceOp.SUM, group=process_group)
+
+            class _Done:
+                def wait(_self):
+                    pass
+            return _Done()
         if ar is None:
             return dist.all_reduce(view, op=dist.ReduceOp.SUM, group=process_group, async_op=True)
+        if in_stream:
+            ar.all_reduce(view, stream=torch.cuda.current_stream(self.device))
+
+            class _Done2:
+                def wait(_self):
+                    pass
+            return _Done2()
         cur, side = torch.cuda.current_stream(self.device), self._flat_ar_stream
         ready = torch.cuda.Event(); ready.record(cur)
         side.wait_event(ready)                          # the bucket's gradients are final
@@ -492,8 +561,9 @@ class HipEngine:
                 torch.cuda.current_stream(self.device).wait_event(done)
         return _W()
 
-    #: how forward_backward_dp exchanges the gradients: "single" = the fused forward/backward call, then ONE all-reduce of the whole
-    #: flat buffer (406 KB for KAdaptation) | "staged" = the backward cut into stages with three overlapped buckets (rounds 2-4).
+    #: how the DP step exchanges the gradients: "single" = the fused forward/backward call, then ONE all-reduce of the whole
+    #: flat buffer (406 KB for KAdaptation) | "staged" = the backward cut into stages with three overlapped buckets (rounds 2-4) |
+    #: "pipelined" (train_step only) = "single" with the exchange + SGD on a second stream under the NEXT step's stem.
     #: Round 5 made "single" the default: the exchange is latency-bound at this size, so what the staged route can hide is the
     #: transfer of two of its three buckets, while the LAST bucket's latency is exposed either way -- and the staging itself (a
     #: second reduce / chain / rule-sum group, three hand-overs to the collective's stream, stream-K off) costs 2.2-3.9 % of the
@@ -508,11 +578,14 @@ class HipEngine:
         the upper half of the tower backward) | shared rules + blocks 0..L/2-1 (at the end).  Same kernels in the same order as
         the fused call either way, so a single rank reproduces forward_backward() bit for bit."""
         mode = mode or self.dp_exchange_mode
+        self.dp_flush()
+        if mode == "pipelined":
+            raise ValueError("forward_backward_dp: the pipelined schedule spans the optimizer step -- use train_step")
         if mode == "single":
             if getattr(self, "_dp_streamk_off", False):        # (a staged step before this one switched it off)
                 self.tune("gemm_streamk", 1); self._dp_streamk_off = False
             logits, loss = self.forward_backward(images, labels, bn_training)
-            self._exchange(self.grads, process_group).wait()
+            self._exchange(self.grads, process_group, in_stream=True).wait()
             return logits, loss
         if mode != "staged":
             raise ValueError(f"forward_backward_dp: unknown mode {mode!r}")
@@ -555,6 +628,7 @@ class HipEngine:
     def sync_replicas(self, process_group=None, src: int = 0):
         """Make every rank's trainable state identical to rank ``src``'s (parameters, momentum, BatchNorm running
         statistics, step counter semantics): call once after the engines have been loaded and before the first DP step."""
+        self.dp_flush()
         import torch.distributed as dist
         for t in (self.params, self.momentum, self.running_mean, self.running_var):
             dist.broadcast(t, src=src, group=process_group)
@@ -562,6 +636,7 @@ class HipEngine:
     def average_bn_buffers(self, process_group=None):
         """BatchNorm running statistics follow the LOCAL shards; average them across ranks before validation or a
         checkpoint (dp.average_bn_buffers)."""
+        self.dp_flush()
         dp.average_bn_buffers(self.running_mean, self.running_var, process_group)
 
     def _dfeat(self, B):

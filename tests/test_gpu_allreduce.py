@@ -155,7 +155,7 @@ def _step_worker(rank, world, port, case, flat, out_dir, mode="staged"):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["staged", "single"])
+@pytest.mark.parametrize("mode", ["staged", "single", "pipelined"])
 @pytest.mark.parametrize("case", ["tiny_kadaptation", "tiny_adapter"])
 def test_dp_step_through_allreduce_flat_equals_the_process_group_route(case, mode, tmp_path):
     """engine.forward_backward_dp with its buckets (three overlapped ones, "staged"; or the whole flat buffer behind the fused call,
@@ -165,7 +165,7 @@ def test_dp_step_through_allreduce_flat_equals_the_process_group_route(case, mod
         pytest.skip("no GPU")
     world = 2
     for flat in (False, True):
-        port = 29900 + (os.getpid() % 1000) + (500 if flat else 0) + (250 if mode == "single" else 0)
+        port = 29900 + (os.getpid() % 1000) + (500 if flat else 0) + {"staged": 0, "single": 250, "pipelined": 125}[mode]
         mp.spawn(_step_worker, args=(world, port, case, flat, str(tmp_path), mode), nprocs=world, join=True)
     for r in range(world):
         a, b = torch.load(tmp_path / f"flat{r}.pt"), torch.load(tmp_path / f"pg{r}.pt")

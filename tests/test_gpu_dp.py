@@ -64,13 +64,13 @@ def _worker(rank, world, port, case, out_dir, mode):
 
 
 # mode: "single" = the fused call + one all-reduce of the flat gradient buffer (the default since round 5); "staged" = the backward in
-# two halves with three overlapped buckets
-@pytest.mark.parametrize("mode", ["single", "staged"])
+# two halves with three overlapped buckets; "pipelined" = single with the exchange + SGD on a second stream under the next step's stem
+@pytest.mark.parametrize("mode", ["single", "staged", "pipelined"])
 @pytest.mark.parametrize("case", ["tiny_kadaptation", "tiny_lora", "tiny_adapter"])
 def test_two_rank_hip_step_equals_mean_of_shard_steps(case, mode, tmp_path):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    world, port = 2, 29600 + (os.getpid() % 2000) + (11 if mode == "staged" else 0)
+    world, port = 2, 29600 + (os.getpid() % 2000) + {"single": 0, "staged": 11, "pipelined": 23}[mode]
     mp.spawn(_worker, args=(world, port, case, str(tmp_path), mode), nprocs=world, join=True)
     r0 = torch.load(tmp_path / "rank0.pt"); r1 = torch.load(tmp_path / "rank1.pt")
     for k in ("p", "g", "m"):
