@@ -437,8 +437,11 @@ class DeviceFeeder:
                 if isinstance(item, BaseException):
                     raise item
                 k, n, ev = item
-                cur = torch.cuda.current_stream(self.device)
-                cur.wait_event(ev)
+                # the upload was enqueued a batch or more ago and has normally finished: the HOST seeing the event complete orders the
+                # copy before everything launched from here on, and spares the consumer's stream a cross-queue dependency (round 5:
+                # such a dependency costs tens of microseconds of dispatch latency on this platform: profiles/r05_dp_single_exchange.md)
+                if not ev.query():
+                    torch.cuda.current_stream(self.device).wait_event(ev)
                 yield slots[k]["d_img"][:n], slots[k]["d_tgt"][:n].clone()    # targets outlive the ring (epoch metric): a copy of their own
                 # back here the consumer has enqueued everything that reads this pair: the ring may come round to it after that
                 used = torch.cuda.Event(); used.record(torch.cuda.current_stream(self.device))
