@@ -235,8 +235,8 @@ def main():
                          "staged: the backward in two halves with three overlapped buckets (rounds 2-4); pipelined: single with the "
                          "exchange + SGD on a second stream under the next step's stem (pevit_set_step_gate)")
     ap.add_argument("--dp-route", action="store_true",
-                    help="(N = 1) also time the step through engine.forward_backward_dp on a 1-rank RCCL group -- staged backward, "
-                         "stream-K off, three asynchronous bucketed all-reduces -- and report it beside the fused step (dp_route)")
+                    help="(N = 1) also time the DP step on a 1-rank RCCL group in its three exchange schedules (single / pipelined / "
+                         "staged) and report them beside the fused step (dp_route)")
     ap.add_argument("--no-harness", action="store_true", help="skip the reference-API (train_one) throughput measurement")
     ap.add_argument("--graph", action="store_true",
                     help="(N = 1, measurement) time the step as ONE captured HIP graph replay (engine.capture_train_step) instead of the "

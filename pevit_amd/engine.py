@@ -415,10 +415,8 @@ class HipEngine:
     def train_step(self, images, labels, lr, momentum=0.9, weight_decay=0.0, bn_training=True, process_group=None,
                    world_size=1, nesterov=False, logits_out=None, loss_out=None):
         """One reference ``train_one`` iteration (kadaptation_clip.py:347-353).  With DP the flat gradient buffer
-        is the only thing that crosses xGMI (the frozen backbone never does), in two buckets: the head gradients
-        (available right after the head backward) are all-reduced while the tower backward runs, the adapter
-        gradients (the per-layer partials are chained onto the reference's tensors at the very end of the
-        backward) after it."""
+        is the only thing that crosses xGMI (the frozen backbone never does); how it is exchanged is ``dp_exchange_mode``
+        (default: one in-stream all-reduce behind the fused forward/backward call, 1/world folded into the SGD kernel)."""
         if world_size <= 1:
             logits, loss = self.forward_backward(images, labels, bn_training, logits_out, loss_out)
             self.sgd_step(lr, momentum, weight_decay, 1.0, nesterov)
@@ -566,8 +564,9 @@ class HipEngine:
     #: "pipelined" (train_step only) = "single" with the exchange + SGD on a second stream under the NEXT step's stem.
     #: Round 5 made "single" the default: the exchange is latency-bound at this size, so what the staged route can hide is the
     #: transfer of two of its three buckets, while the LAST bucket's latency is exposed either way -- and the staging itself (a
-    #: second reduce / chain / rule-sum group, three hand-overs to the collective's stream, stream-K off) costs 2.2-3.9 % of the
-    #: step on one rank (profiles/r04_dp_evidence.md) against 0.4-0.8 % for one exchange behind the fused call (bench.py --dp-route).
+    #: second reduce / chain / rule-sum group, three round trips through the collective's stream at ~74 us each, stream-K off)
+    #: costs 3.6 % of the step on one rank against 0.2 % for one in-stream exchange behind the fused call
+    #: (bench.py --dp-route; profiles/r05_dp_single_exchange.md).
     dp_exchange_mode = "single"
 
     def forward_backward_dp(self, images, labels, bn_training=True, process_group=None, mode=None):
