@@ -640,7 +640,10 @@ def test_weight_gradient_products_inside_the_adapter_backward_launch_are_bit_ide
         assert torch.equal(g1[k], g0[k]), (k, rel_err(g1[k], g0[k]))
 
 
-@pytest.mark.parametrize("method,arch_name,B", [("kadaptation", "ViT-B/32-2L", 24), ("lora", "tiny-256", 7), ("kadaptation", "tiny-n197", 3)])
+# (ViT-B/32-2L, ViT-B/16, ViT-L/14: the instances of lowrank_combo_kernel with heads / tokens as compile-time constants, <12, 50>,
+# <12, 197>, <16, 257> (round 5), against kernels that take them at run time; the tiny towers: its run-time instance)
+@pytest.mark.parametrize("method,arch_name,B", [("kadaptation", "ViT-B/32-2L", 24), ("lora", "tiny-256", 7), ("kadaptation", "tiny-n197", 3),
+                                                 ("kadaptation", "ViT-B/16", 3), ("lora", "ViT-L/14", 2)])
 def test_combined_lowrank_backward_equals_the_two_launches(method, arch_name, B):
     """lowrank_combo_kernel (u + dQ + d bias of a layer and the dP of the layer walked before it in one launch, the last layer's dP
     in a launch of its own) against lowrank_u + lowrank_grad per layer (`lowrank_combo` = 0): same products on the same bf16
