@@ -219,6 +219,14 @@ def pin_rank_to_cores(local_rank, local_world):
         return None
 
 
+def _flush_c_stdio():
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -346,6 +354,7 @@ def main():
     for _ in range(args.warmup):
         step()
     if world > 1:
+        _flush_c_stdio()                                # (the collective library's banner, printed when its communicator came up)
         torch.distributed.barrier()
     torch.cuda.synchronize()
     # one event per step on the launch stream (the engine launches on torch's current stream): the median step time
@@ -545,9 +554,15 @@ def main():
             except Exception as e:
                 out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}", "kind": "port"}
                 print(f"[bench] CPU baseline failed: {e}", file=sys.stderr, flush=True)
-        print(json.dumps(out), flush=True)
+    # The JSON line is the LAST thing on stdout: the collective library writes a version banner through C stdio, which sits in the
+    # process's buffer until exit when stdout is a pipe -- tear the process group down first, flush C stdio, then print.
+    _flush_c_stdio()
     if world > 1:
+        torch.distributed.barrier()                     # every rank has emptied its C stdio buffer
         torch.distributed.destroy_process_group()
+        _flush_c_stdio()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
