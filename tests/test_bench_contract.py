@@ -72,3 +72,29 @@ def test_step_floors_follow_the_survey_formula():
     assert abs(g - 17.673449472) < 1e-6
     assert abs(g * 128 / bench.PEAK_TFLOPS_BF16 - 0.9048806) < 1e-5   # ms of MFMA work per bs-128 step (roofline.mfma_floor_ms)
     assert abs(bench.PEAK_TFLOPS_BF16 * 1e12 / (bench.PEAK_HBM_TBS * 1e12) - 312.5) < 1e-9   # the ridge
+
+
+def test_flush_helper_and_the_dp_schedule_option(monkeypatch, capsys):
+    """The JSON line must be the last line of stdout even when a C library has buffered output of its own (the collective library's
+    banner): `_flush_c_stdio` empties the process's C stdio buffers and never raises; `--dp-exchange` offers the three schedules and
+    defaults to the single in-stream exchange (and the re-exec for `--gpus N` hands the choice on to the ranks)."""
+    bench = _bench()
+    bench._flush_c_stdio()                                   # callable without a GPU, idempotent
+    bench._flush_c_stdio()
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'choices=["single", "staged", "pipelined"], default="single"' in src
+    # the print of the line comes after the process group is gone and the buffers are flushed
+    tail = src[src.rindex("destroy_process_group()"):]
+    assert "_flush_c_stdio()" in tail and tail.index("_flush_c_stdio()") < tail.index("print(json.dumps(out)")
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"] = cmd
+        return 0
+    import subprocess
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.delenv("WORLD_SIZE", raising=False); monkeypatch.delenv("RANK", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--dp-exchange", "staged"])
+    with pytest.raises(SystemExit):
+        bench.main()
+    assert "--dp-exchange" in seen["cmd"] and "staged" in seen["cmd"]
