@@ -561,34 +561,57 @@ __global__ __launch_bounds__(256, 2) void lowrank_combo_kernel(const bf16* __res
 __global__ void lowrank_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ dbias_partial,
                                       int chunks, float* __restrict__ G, float* g_b, int E, size_t partial_layer,
                                       size_t dbias_layer, size_t gb_layer) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    // Four consecutive elements per thread (16-byte requests; round 5: was one), eight chunks per round (one memory round trip each:
+    // 25 chunks = 4 trips).  Fixed summation tree per element -- the same one as before: deterministic, same bits.
+    const int idx = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
     const int total = 4 * E * 32, l = blockIdx.y;
     partial += (size_t)l * partial_layer;
     if (idx < total) {
-        // fixed summation tree: deterministic.  Eight chunks per round (one memory round trip each: 25 chunks = 4 trips, not 7)
-        float sacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float4 sacc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sacc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
         int c = 0;
         for (; c + 7 < chunks; c += 8) {
-            float v[8];
+            float4 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(c + u) * total + idx];
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(partial + (size_t)(c + u) * total + idx);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) sacc[u] += v[u];
+            for (int u = 0; u < 8; ++u) { sacc[u].x += v[u].x; sacc[u].y += v[u].y; sacc[u].z += v[u].z; sacc[u].w += v[u].w; }
         }
         {
-            float v[8];
+            float4 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)min(c + u, chunks - 1) * total + idx];    // clamped: no load inside a branch
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(partial + (size_t)min(c + u, chunks - 1) * total + idx);    // clamped: no load inside a branch
 #pragma unroll
-            for (int u = 0; u < 8; ++u) sacc[u] += (c + u < chunks) ? v[u] : 0.f;
+            for (int u = 0; u < 8; ++u)
+                if (c + u < chunks) { sacc[u].x += v[u].x; sacc[u].y += v[u].y; sacc[u].z += v[u].z; sacc[u].w += v[u].w; }
         }
-        G[(size_t)l * total + idx] = ((sacc[0] + sacc[1]) + (sacc[2] + sacc[3])) + ((sacc[4] + sacc[5]) + (sacc[6] + sacc[7]));
+        float4 o;
+        o.x = ((sacc[0].x + sacc[1].x) + (sacc[2].x + sacc[3].x)) + ((sacc[4].x + sacc[5].x) + (sacc[6].x + sacc[7].x));
+        o.y = ((sacc[0].y + sacc[1].y) + (sacc[2].y + sacc[3].y)) + ((sacc[4].y + sacc[5].y) + (sacc[6].y + sacc[7].y));
+        o.z = ((sacc[0].z + sacc[1].z) + (sacc[2].z + sacc[3].z)) + ((sacc[4].z + sacc[5].z) + (sacc[6].z + sacc[7].z));
+        o.w = ((sacc[0].w + sacc[1].w) + (sacc[2].w + sacc[3].w)) + ((sacc[4].w + sacc[5].w) + (sacc[6].w + sacc[7].w));
+        *reinterpret_cast<float4*>(G + (size_t)l * total + idx) = o;
     }
-    if (g_b && idx < E) {
+    // the bias gradient: one column per thread of the LAST blocks of the grid (they have the fewest elements to sum), the chunks'
+    // two partial rows requested eight chunks at a time (round 5: the plain loop made every chunk its own memory round trip -- 25
+    // of them in a row while the rest of the grid had long finished); summed in chunk order as before: same bits
+    const int col = ((int)(gridDim.x - 1 - blockIdx.x) * (int)blockDim.x + (int)threadIdx.x);
+    if (g_b && col < E) {
         const float* db = dbias_partial + (size_t)l * dbias_layer;
         float s = 0.f;
-        for (int c = 0; c < chunks; ++c) s += db[((size_t)c * 2) * E + idx] + db[((size_t)c * 2 + 1) * E + idx];
-        g_b[(size_t)l * gb_layer + idx] += s;
+        for (int c0 = 0; c0 < chunks; c0 += 8) {
+            float a[8], b[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = min(c0 + u, chunks - 1);
+                a[u] = db[((size_t)c * 2) * E + col]; b[u] = db[((size_t)c * 2 + 1) * E + col];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (c0 + u < chunks) s += a[u] + b[u];
+        }
+        g_b[(size_t)l * gb_layer + col] += s;
     }
 }
 
@@ -608,7 +631,16 @@ __global__ __launch_bounds__(256) void chain_kadapt_kernel(const float* __restri
     q_left += (size_t)l * param_layer; q_right += (size_t)l * param_layer;
     g_q_left += (size_t)l * param_layer; g_q_right += (size_t)l * param_layer;
     float* rs = rule_scratch + (size_t)l * 4096;
-    for (int i = tid; i < 4 * E; i += blockDim.x) gs[i] = G[(size_t)i * 32 + j];
+    // column j of G into LDS, eight requests per thread in flight (round 5: one per trip made the 12 trips of E = 768 twelve memory
+    // round trips: this kernel's 12 us)
+    for (int i0 = tid; i0 < 4 * E; i0 += 8 * blockDim.x) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = G[(size_t)min(i0 + u * (int)blockDim.x, 4 * E - 1) * 32 + j];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (i0 + u * (int)blockDim.x < 4 * E) gs[i0 + u * blockDim.x] = v[u];
+    }
     __syncthreads();
     const float* G0 = gs; const float* G1 = gs + E; const float* G2 = gs + 2 * E; const float* G3 = gs + 3 * E;
     const float* lf = q_left + j * F; const float* r = q_right + j * F;
@@ -646,7 +678,15 @@ __global__ void rule_sum_kernel(const float* __restrict__ rule_scratch, float* g
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 4096) return;
     float s = g_rule[i];
-    for (int l = l_hi - 1; l >= l_lo; --l) s += rule_scratch[(size_t)l * 4096 + i];
+    // top layer first, one running sum (the order the staged backward relies on); eight layers' values requested per trip
+    for (int l0 = l_hi - 1; l0 >= l_lo; l0 -= 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = rule_scratch[(size_t)max(l0 - u, l_lo) * 4096 + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (l0 - u >= l_lo) s += v[u];
+    }
     g_rule[i] = s;
 }
 
@@ -776,7 +816,7 @@ int pevit_launch_chain_kadapt(const float* partial, size_t partial_layer, const 
                               float* grads, size_t p_layer0, size_t p_layer_stride, int E, hipStream_t s) {
     if (64 + 2 * (E / 32) > 256) { pevit_set_error("chain_kadapt: width %d too large", E); return -1; }
     float* g_b = grads + p_layer0 + 4 * (size_t)E;
-    hipLaunchKernelGGL(lowrank_reduce_kernel, dim3(ceil_div(4 * E * 32, 256), layers), dim3(256), 0, s, partial,
+    hipLaunchKernelGGL(lowrank_reduce_kernel, dim3(ceil_div(4 * E * 32, 4 * 256), layers), dim3(256), 0, s, partial,
                        dbias_partial, chunks, G, g_b, E, partial_layer, dbias_layer, p_layer_stride);
     LAUNCH_OK("lowrank_reduce_kernel");
     const float* r = params;
@@ -798,7 +838,7 @@ int pevit_launch_rule_sum(const float* rule_scratch, float* grads, int l_lo, int
 
 int pevit_launch_chain_lora(const float* partial, size_t partial_layer, int chunks, float ascale, int r, int layers,
                             float* G, float* grads, size_t p_layer0, size_t p_layer_stride, int E, hipStream_t s) {
-    hipLaunchKernelGGL(lowrank_reduce_kernel, dim3(ceil_div(4 * E * 32, 256), layers), dim3(256), 0, s, partial,
+    hipLaunchKernelGGL(lowrank_reduce_kernel, dim3(ceil_div(4 * E * 32, 4 * 256), layers), dim3(256), 0, s, partial,
                        (const float*)nullptr, chunks, G, (float*)nullptr, E, partial_layer, (size_t)0, (size_t)0);
     LAUNCH_OK("lowrank_reduce_kernel");
     const size_t rE = (size_t)r * E;
