@@ -143,6 +143,63 @@ def harness_throughput(dev, steps=20):
     return out
 
 
+def concurrent_runs_throughput(dev, sd, arch, steps=40):
+    """K independent fine-tune runs (K engine contexts: own parameters, workspace and optimizer state, the same frozen checkpoint)
+    on K streams, stepped in lockstep by one host thread -- the reference's real workload is ~90 short sweep runs at batch 64 on one
+    frozen backbone (kadaptation_clip.py:188-243,446-466; feature.py:101), and a batch-64 step fills 120 of the 256 CUs in its
+    large GEMMs.  Aggregate images/s over the runs; every concurrent run's parameters are compared bit for bit with the same run
+    stepped alone.  A side measurement: `value` is ONE run at batch 128."""
+    from pevit_amd.engine import HipEngine
+    from pevit_amd.synth import reference_init_, synth_batch
+    out = {"how": f"K engine contexts on K streams, {steps} lockstep train_steps after 8 warm-up steps, lr differs per run; "
+                  "aggregate images/s of the K runs; parameters of every run bit-identical to the same run alone"}
+    for bs, ks in ((64, (1, 2, 3)), (128, (1, 2))):
+        engines, batches, streams = [], [], []
+        for r in range(max(ks)):
+            e = HipEngine(arch, "kadaptation", 100, bs, device=dev)
+            e.load_state_dict(sd)
+            reference_init_(e.param_views().items(), "kadaptation", seed=7 + r)
+            g = torch.Generator().manual_seed(5 + r)
+            with torch.no_grad():
+                v = e.param_views(); bound = arch.embed_dim ** -0.5
+                v["layers.0.weight"].copy_(((torch.rand(v["layers.0.weight"].shape, generator=g) * 2 - 1) * bound).to(dev))
+            im, lb = synth_batch(bs, arch.resolution, 100, seed_img=10 + 2 * r, seed_lbl=11 + 2 * r)
+            engines.append(e); batches.append((im.to(dev), lb.to(dev))); streams.append(torch.cuda.Stream(dev))
+        init = [e.params.clone() for e in engines]
+
+        def reset():
+            for e, p in zip(engines, init):
+                e.reset_run(); e.params.copy_(p)
+            torch.cuda.synchronize(dev)
+
+        def run(k, n):
+            for _ in range(n):
+                for r in range(k):
+                    with torch.cuda.stream(streams[r]):
+                        engines[r].train_step(*batches[r], lr=0.01 * (r + 1), momentum=0.9, weight_decay=1e-6)
+        solo = []
+        for r in range(max(ks)):
+            reset()
+            with torch.cuda.stream(streams[r]):
+                for _ in range(steps + 8):
+                    engines[r].train_step(*batches[r], lr=0.01 * (r + 1), momentum=0.9, weight_decay=1e-6)
+            torch.cuda.synchronize(dev)
+            solo.append(engines[r].params.clone())
+        res, same = {}, True
+        for k in ks:
+            reset(); run(k, 8); torch.cuda.synchronize(dev)
+            t0 = time.perf_counter(); run(k, steps); torch.cuda.synchronize(dev)
+            res[str(k)] = k * bs * steps / (time.perf_counter() - t0)
+            same = same and all(torch.equal(engines[r].params, solo[r]) for r in range(k))
+        for e in engines:
+            e.check_streamk()
+        out[f"bs{bs}"] = {"aggregate_images_per_sec_by_runs": res, "bit_identical_to_solo": same,
+                          "gain_over_one_run": {k: v / res["1"] for k, v in res.items()}}
+        del engines, batches, init, solo
+        torch.cuda.empty_cache()
+    return out
+
+
 def cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -238,10 +295,13 @@ def main():
     ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8", "fp8-act"],
                     help="frozen block weights: bf16, or e4m3 codes + per-channel scales (BASELINE config 5 with --arch ViT-L/14)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dp-exchange", choices=["single", "staged", "pipelined"], default="single",
-                    help="(N > 1) single: the fused forward/backward call, then ONE all-reduce of the flat gradient buffer (default); "
-                         "staged: the backward in two halves with three overlapped buckets (rounds 2-4); pipelined: single with the "
-                         "exchange + SGD on a second stream under the next step's stem (pevit_set_step_gate)")
+    ap.add_argument("--dp-exchange", choices=["auto", "single", "staged", "pipelined"], default="auto",
+                    help="(N > 1) auto (default): time BOTH single and staged, W warm-up + K timed steps each, report the faster one "
+                         "as `value` and both under config.exchange_schedules -- which of the two wins on N real GPUs has never been "
+                         "measured; single: the fused forward/backward call, then ONE all-reduce of the flat gradient buffer (NOT "
+                         "overlapped with the backward); staged: the backward in two halves with three buckets all-reduced while it "
+                         "continues; pipelined: single with the exchange + SGD on a second stream under the next step's stem "
+                         "(pevit_set_step_gate)")
     ap.add_argument("--dp-route", action="store_true",
                     help="(N = 1) also time the DP step on a 1-rank RCCL group in its three exchange schedules (single / pipelined / "
                          "staged) and report them beside the fused step (dp_route)")
@@ -338,7 +398,10 @@ def main():
         torch.cuda.synchronize()
         del src, dst16
 
-    eng.dp_exchange_mode = args.dp_exchange
+    schedules = ["single", "staged"] if args.dp_exchange == "auto" else [args.dp_exchange]
+    if world == 1:
+        schedules = schedules[:1]
+    eng.dp_exchange_mode = schedules[0]
     if world > 1 and args.exchange == "flat":
         eng.use_flat_allreduce()
     if world > 1:
@@ -351,33 +414,66 @@ def main():
         eager_step()                                   # the first step (no momentum yet) cannot be the captured one
         step = eng.capture_train_step(images, labels, lr=0.01, momentum=0.9, weight_decay=1e-6)
 
-    for _ in range(args.warmup):
-        step()
+    def timed_region(schedule):
+        """W untimed warm-up steps, then EXACTLY K timed steps between barrier + synchronize on both sides; returns this rank's wall
+        time, the median of its per-step event intervals, the last loss and (N > 1) the device time of every exchange."""
+        if world > 1:
+            eng.dp_pipeline_off()
+            eng.dp_exchange_mode = schedule
+        for _ in range(args.warmup):
+            step()
+        if world > 1:
+            eng.dp_flush()
+            _flush_c_stdio()                            # (the collective library's banner, printed when its communicator came up)
+            torch.distributed.barrier()
+            eng.time_exchange(True)
+        torch.cuda.synchronize()
+        # one event per step on the launch stream (the engine launches on torch's current stream): the median step time
+        # next to the wall-clock mean
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        t0 = time.perf_counter()
+        marks[0].record()
+        for i in range(args.steps):
+            logits, loss = step()
+            marks[i + 1].record()
+        eng.dp_flush()
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        dt = time.perf_counter() - t0
+        v = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+        med = v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
+        xus = sorted(eng.exchange_times_us()) if world > 1 else []
+        eng.time_exchange(False)
+        return dt, med, loss, (xus[len(xus) // 2] if xus else None)
+
+    per_schedule = {}
+    for sch in schedules:
+        dt, median_ms, loss, x_us = timed_region(sch)
+        print(f"[bench rank {rank}/{world}] {sch if world > 1 else 'step'}: {dt / args.steps * 1e3:.3f} ms/step (median {median_ms:.3f})"
+              + (f", exchange {x_us:.1f} us" if x_us is not None else ""), file=sys.stderr, flush=True)   # stragglers show here
+        rec = {"dt": dt, "median_ms": median_ms, "loss": float(loss)}
+        if world > 1:
+            # every rank's own clock: the whole-job time is the MAX (a straggler shows as one large entry), and the exchange time per
+            # rank says whether a slow step is the collective or the rank's kernels
+            mine = torch.tensor([dt, median_ms, -1.0 if x_us is None else x_us], dtype=torch.float64, device=dev)
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            torch.distributed.all_gather(allr, mine)
+            allr = torch.stack(allr).cpu()
+            rec.update(dt=float(allr[:, 0].max()), median_ms=float(allr[:, 1].max()),
+                       per_rank_ms_per_step=[float(x) / args.steps * 1e3 for x in allr[:, 0]],
+                       per_rank_median_ms=[float(x) for x in allr[:, 1]],
+                       per_rank_exchange_us=[None if float(x) < 0 else float(x) for x in allr[:, 2]])
+            xs = [x for x in rec["per_rank_exchange_us"] if x is not None]
+            rec["exchange_us_per_step"] = max(xs) if xs else None
+        per_schedule[sch] = rec
+    best = min(per_schedule, key=lambda k: per_schedule[k]["dt"])
     if world > 1:
-        _flush_c_stdio()                                # (the collective library's banner, printed when its communicator came up)
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    # one event per step on the launch stream (the engine launches on torch's current stream): the median step time
-    # next to the wall-clock mean
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    t0 = time.perf_counter()
-    marks[0].record()
-    for i in range(args.steps):
-        logits, loss = step()
-        marks[i + 1].record()
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    dt = time.perf_counter() - t0
-    per_step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
-    median_ms = per_step_ms[len(per_step_ms) // 2] if len(per_step_ms) % 2 else \
-        0.5 * (per_step_ms[len(per_step_ms) // 2 - 1] + per_step_ms[len(per_step_ms) // 2])
-    print(f"[bench rank {rank}/{world}] {dt / args.steps * 1e3:.3f} ms/step (median {median_ms:.3f})", file=sys.stderr, flush=True)   # stragglers show here
-    if world > 1:
-        tt = torch.tensor([dt, median_ms], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        dt, median_ms = float(tt[0]), float(tt[1])
-    final_loss = float(loss)
+        eng.dp_pipeline_off()
+        eng.dp_exchange_mode = best
+    dt, median_ms = per_schedule[best]["dt"], per_schedule[best]["median_ms"]
+    args.dp_exchange = best
+    final_loss = per_schedule[best]["loss"]
     eng.check_streamk()          # a stream-K hand-off that timed out would make the timed steps invalid: fail loudly
 
     # ---- dominant kernel (MFMA GEMM family): HIP events around every GEMM launch, measured over
@@ -497,6 +593,16 @@ def main():
                        "step_launch": "hip-graph replay" if (args.graph and world == 1) else "eager (one C call, ~200 kernel launches)",
                        "gradient_exchange": ("none" if world == 1 else args.exchange), "rccl_ranks": world if (world > 1 and args.dist_backend == "nccl") else 0,
                        "gradient_buckets": 0 if world == 1 else (3 if args.dp_exchange == "staged" else 1),
+                       "exchange_us_per_step": per_schedule[best].get("exchange_us_per_step"),
+                       "per_rank_ms_per_step": per_schedule[best].get("per_rank_ms_per_step"),
+                       "exchange_schedules": None if world == 1 else {
+                           k: {"images_per_sec": args.batch * world * args.steps / v["dt"], "ms_per_step": v["dt"] / args.steps * 1e3,
+                               "median_ms_per_step": v["median_ms"], "exchange_us_per_step": v.get("exchange_us_per_step"),
+                               "per_rank_ms_per_step": v.get("per_rank_ms_per_step"), "per_rank_exchange_us": v.get("per_rank_exchange_us"),
+                               "overlapped_with_backward": k == "staged"}
+                           for k, v in per_schedule.items()},
+                       "exchange_schedule_chosen": None if world == 1 else ("the faster of " + " / ".join(per_schedule) + f" in THIS run: {best}" if len(per_schedule) > 1 else best),
+                       "exchange_us_how": None if world == 1 else "median over the timed steps of an event pair on the stream the exchange is enqueued on, max over ranks (single: around the in-stream all-reduce; staged: around the waits behind the backward = what the overlap did not hide; pipelined: on the second stream)",
                        "gradient_exchange_schedule": "none" if world == 1 else {"single": "one all-reduce of the flat buffer behind the fused forward/backward call", "pipelined": "one all-reduce of the flat buffer + SGD on a second stream under the next step's stem", "staged": "three buckets overlapped with the staged backward"}[args.dp_exchange], "exchanged_floats_per_step": 0 if world == 1 else int(eng.n_params),
                        "train_gflop_per_image": gflop, "final_loss": final_loss},
             "roofline": {"bound": "mfma", "kernel": "gemm8_kernel<...> + gemm_kphase_kernel<...> + gemm_kernel<...> + gemm_streamk_kernel<...> (pevit_amd/csrc/gemm.hip: all epilogues / tile shapes)",
@@ -543,6 +649,11 @@ def main():
         if world == 1 and not args.no_harness and headline:
             del eng, images, labels
             torch.cuda.empty_cache()
+            try:
+                out["concurrent_runs"] = concurrent_runs_throughput(dev, sd, arch)
+            except Exception as e:           # a side measurement must never cost the headline line
+                out["concurrent_runs"] = {"error": f"{type(e).__name__}: {e}"}
+                print(f"[bench] concurrent-runs measurement failed: {e}", file=sys.stderr, flush=True)
             try:
                 out["harness_images_per_sec"] = harness_throughput(dev)
             except Exception as e:           # a side measurement must never cost the headline line

@@ -310,7 +310,8 @@ int pevit_streamk_status(pevit_ctx* ctx, void* stream, unsigned* error_word, uns
  * contribution into every peer's mailbox + one 4-byte flag copy behind it (copy engines over xGMI; no kernel on the sending GPU),
  * and a small local kernel that waits for the peers' flags and adds the contributions in RANK ORDER (identical bits on every
  * rank).  Asynchronous on `stream`; all calls of one pevit_ar must use the same stream, in the same order on every rank.
- * pevit_ar_error: 1 if a reduction ever gave up waiting for a peer (its buffer is then left unreduced), clears the word. */
+ * pevit_ar_error: 1 if a reduction ever gave up waiting for a peer (its buffer is then left unreduced); the word stays raised until
+ * pevit_ar_reset (round 6: reading it no longer clears it). */
 typedef struct pevit_ar pevit_ar;
 int pevit_ar_create(pevit_ar** out, int rank, int world, size_t max_floats);
 void pevit_ar_destroy(pevit_ar* ar);
@@ -325,7 +326,7 @@ int pevit_ar_error(pevit_ar* ar, void* stream);       /* 0 fine, 1 a peer never 
  * reduced everywhere or nowhere; the mailbox is fine-grained memory where the runtime exports such an allocation
  * (pevit_ar_fine_grained; PEVIT_AR_COARSE=1 forces the plain one).  pevit_ar_error_word: the device address of the error word, for
  * pevit_set_external_poison -- pevit_sgd_step then withholds the update of a step whose exchange failed (and writes NaN over that
- * step's loss), as it does for a stream-K hand-off error; the word stays raised until pevit_ar_error clears it.
+ * step's loss), as it does for a stream-K hand-off error; the word stays raised until pevit_ar_reset clears it.
  * EXPERIMENTAL: exercised with 2 / 4 / 8 processes on ONE device only; the measured multi-GPU route is RCCL (torch.distributed). */
 const unsigned* pevit_ar_error_word(pevit_ar* ar);
 /* back to the initial protocol state (epoch 0, flags and error word cleared).  Collective by convention: every rank drains its device

@@ -105,6 +105,7 @@ def default_config() -> CfgNode:
                    TWO_LR=False, USE_CHANNEL_BN=True, INIT_HEAD_WITH_TEXT_ENCODER=False, LOGIT_SCALE_INIT="none",
                    TRAINABLE_LOGIT_SCALE=False, MERGE_ENCODER_AND_HEAD_PROJ=False, NORMALIZE_VISUAL_FEATURE=False,
                    SEARCH_RESULT_ON_LAST_EPOCH=False, OPTIMIZER="sgd", MOMENTUM=0.9, WD=0.0001, WD_SEARCH_LEFT=False,
+                   SWEEP_CONCURRENCY=2,      # sweep runs at a time, each on its own stream (not a reference key; 1 = sequential)
                    WITHOUT_WD_LIST=[], NESTEROV=True, BEGIN_EPOCH=0, END_EPOCH=100, EXTRA_FINAL_TRAIN_EPOCH=0,
                    EMULATE_ZERO_SHOT=False, BATCH_SIZE_PER_GPU=32, SHUFFLE=True, RMSPROP_ALPHA=0.99, RMSPROP_CENTERED=False),
         TEST=dict(BATCH_SIZE_PER_GPU=32, METRIC="accuracy", MODEL_FILE=""),

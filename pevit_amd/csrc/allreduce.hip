@@ -290,12 +290,14 @@ extern "C" int pevit_ar_reset(pevit_ar* a, void* stream) {
 extern "C" const unsigned* pevit_ar_error_word(pevit_ar* a) { return a ? reinterpret_cast<const unsigned*>(a->base + a->off_err) : nullptr; }
 extern "C" int pevit_ar_fine_grained(pevit_ar* a) { return a && a->fine ? 1 : 0; }
 
-// 1 / 2 if a reduction ever gave up waiting for a peer / saw another size (synchronises the stream), 0 otherwise; clears the word
+// 1 / 2 if a reduction ever gave up waiting for a peer / saw another size (synchronises the stream), 0 otherwise.  The word is NOT
+// cleared (round 6): while it is raised the fused SGD kernel withholds every update (pevit_set_external_poison), and only
+// pevit_ar_reset -- a collective: all ranks back to the initial protocol state -- lowers it, so that a caller who merely catches the
+// exception cannot resume updating next to peers in another state
 extern "C" int pevit_ar_error(pevit_ar* a, void* stream) {
     if (!a) return -1;
     unsigned v = 0;
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return -1;
     if (hipMemcpy(&v, a->base + a->off_err, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    if (v) (void)hipMemset(a->base + a->off_err, 0, 4);
     return (int)v;
 }

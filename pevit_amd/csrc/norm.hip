@@ -210,6 +210,7 @@ int pevit_launch_ln_bwd(const void* dy, const float* x, const float* mean, const
     if (rows <= 0) return 0;
     const dim3 grid(ceil_div(rows, 4));
     if (res16 && (f32 || !dy_stored || !dx_bf16)) { pevit_set_error("ln_bwd: the bf16 residual form needs bf16 storage on both sides"); return -1; }
+    if (res16 && !dres) { pevit_set_error("ln_bwd: the bf16 residual form reads its residual gradient from dres (null)"); return -1; }
 #ifdef LN_NV_OFF
     const int nv = 0;                          // (A/B builds: the generic kernels)
 #else

@@ -84,7 +84,9 @@ class FlatAllReduce:
                             "pevit_allreduce_flat")
 
     def check(self, stream=None):
-        """Raise if a reduction gave up (synchronises ``stream``: pass the stream the all-reduces run on); clears the word."""
+        """Raise if a reduction gave up (synchronises ``stream``: pass the stream the all-reduces run on).  The word stays raised --
+        and the engine's optimizer updates withheld -- until every rank has gone through ``resync()`` (then ``sync_replicas()``:
+        the peers that did receive every flag applied an update this rank withheld)."""
         s = self._C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
         rc = self.lib.pevit_ar_error(self._ar, s)
         if rc != 0:

@@ -147,7 +147,10 @@ class HipEngine:
 
     # ------------------------------------------------------------------ parameters
     def param_views(self, buf: torch.Tensor | None = None) -> "OrderedDict[str, torch.Tensor]":
-        """Views of the flat buffer under the reference's parameter names (+ head)."""
+        """Views of the flat buffer under the reference's parameter names (+ head).  (Pipelined DP: the current stream first
+        waits for the update still running on the second stream -- a checkpoint / state export right behind a step must not read
+        half-updated parameters.)"""
+        self.dp_flush()
         buf = self.params if buf is None else buf
         out, off = OrderedDict(), 0
         for name, shape in self._spec:
@@ -167,6 +170,7 @@ class HipEngine:
     # ------------------------------------------------------------------ frozen weights
     def load_state_dict(self, sd, prefix: str = "visual."):
         """Frozen backbone from an OpenAI-layout state-dict (any float dtype, any device)."""
+        self.dp_flush()
         s = _lib.stream_ptr()
 
         def dev(key):
@@ -230,6 +234,7 @@ class HipEngine:
                                   f"got {tuple(labels.shape)} {labels.dtype} on {labels.device}")
 
     def transformer_forward(self, x_nbe: torch.Tensor, save: bool = True) -> torch.Tensor:
+        self.dp_flush()
         N, B, E = x_nbe.shape
         if (N, E) != (self.arch.tokens, self.arch.width) or x_nbe.device != self.device:
             raise _lib.PevitError(f"transformer_forward expects ({self.arch.tokens}, B, {self.arch.width}) on {self.device}, "
@@ -245,6 +250,7 @@ class HipEngine:
 
     def blocks_forward(self, x_nbe: torch.Tensor, l_lo: int, l_hi: int, save: bool = True) -> torch.Tensor:
         """Blocks [l_lo, l_hi) on (N,B,E) activations (the reference's ResidualAttentionBlock.forward for one block)."""
+        self.dp_flush()
         N, B, E = x_nbe.shape
         if (N, E) != (self.arch.tokens, self.arch.width) or x_nbe.device != self.device:
             raise _lib.PevitError(f"blocks_forward expects ({self.arch.tokens}, B, {self.arch.width}) on {self.device}")
@@ -260,6 +266,7 @@ class HipEngine:
         return y
 
     def blocks_backward(self, dy_nbe: torch.Tensor, l_lo: int, l_hi: int, need_dx: bool = True):
+        self.dp_flush()
         N, B, E = dy_nbe.shape
         dy = dy_nbe.contiguous().float()
         dx = torch.empty_like(dy) if need_dx else None
@@ -268,6 +275,7 @@ class HipEngine:
         return dx
 
     def transformer_backward(self, dy_nbe: torch.Tensor, need_dx: bool = True):
+        self.dp_flush()
         N, B, E = dy_nbe.shape
         dy = dy_nbe.contiguous().float()
         dx = torch.empty_like(dy) if need_dx else None
@@ -295,6 +303,7 @@ class HipEngine:
         _lib.check(self.lib.pevit_visual_backward(self._ctx, _lib.stream_ptr(), _lib.ptr(d), B), "pevit_visual_backward")
 
     def head_forward_backward(self, feat, labels, bn_training=True, need_dfeat=True):
+        self.dp_flush()
         B = feat.shape[0]
         logits = torch.empty((B, self.num_classes), dtype=torch.float32, device=self.device)
         loss = torch.zeros(1, dtype=torch.float32, device=self.device)
@@ -332,13 +341,17 @@ class HipEngine:
                                   f"{tuple(t.shape)} {t.dtype} on {t.device}")
         return t
 
-    def sgd_step(self, lr, momentum=0.9, weight_decay=0.0, grad_scale=1.0, nesterov=False):
+    def sgd_step(self, lr, momentum=0.9, weight_decay=0.0, grad_scale=1.0, nesterov=False, _pipelined=False):
+        if not _pipelined:             # a direct call while a pipelined update is still running on the second stream
+            self.dp_flush()
         flags = int(self._steps == 0) | (2 if nesterov else 0)
         _lib.check(self.lib.pevit_sgd_step(self._ctx, _lib.stream_ptr(), lr, momentum, weight_decay, grad_scale, flags),
                    "pevit_sgd_step")
         # the fused SGD kernel skips the update on device when a stream-K hand-off of this step timed out; the host reads
         # the error word on the first step and then every STREAMK_CHECK_EVERY steps (each check synchronises the stream)
-        if self._steps % self.STREAMK_CHECK_EVERY == 0:
+        # ... and with the flat all-reduce as the exchange EVERY step: a rank whose reduction gave up withholds its update while its
+        # peers apply theirs, and replicas must not drift apart for 64 steps before anybody notices
+        if self._steps % self.STREAMK_CHECK_EVERY == 0 or getattr(self, "_flat_ar", None) is not None:
             self.check_streamk()
         self._steps += 1
 
@@ -401,6 +414,7 @@ class HipEngine:
         return ms.value, fl.value, n_gemm
 
     def reset_optimizer(self):
+        self.dp_flush()
         self._steps = 0
         self.momentum.zero_()
 
@@ -455,10 +469,33 @@ class HipEngine:
         st["grads"].record(cur)
         with torch.cuda.stream(st["stream"]):
             st["stream"].wait_event(st["grads"])
+            xt = self._xt_pair()
+            if xt: xt[0].record(st["stream"])
             self._exchange(self.grads, process_group, in_stream=True).wait()
-            self.sgd_step(lr, momentum, weight_decay, 1.0 / world_size, nesterov)
+            if xt: xt[1].record(st["stream"])
+            self.sgd_step(lr, momentum, weight_decay, 1.0 / world_size, nesterov, _pipelined=True)
             st["params"].record(st["stream"])
         return logits, loss
+
+    # ---- how long the exchange takes on the device (bench.py N > 1: `exchange_us_per_step`) ---------------------------------------
+    def time_exchange(self, on: bool = True):
+        """Bracket every gradient exchange of the DP step with a pair of events on the stream it is enqueued on (single / staged:
+        the compute stream -- for staged the pair brackets the WAITS at the end of the backward, i.e. the part of the three
+        asynchronous all-reduces that the backward did not hide; pipelined: the second stream).  ``exchange_times_us()`` reads
+        them back."""
+        self._xt = [] if on else None
+
+    def _xt_pair(self):
+        if getattr(self, "_xt", None) is None:
+            return None
+        pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        self._xt.append(pair)
+        return pair
+
+    def exchange_times_us(self):
+        """Microseconds of every bracketed exchange since time_exchange(True) (synchronises the device)."""
+        torch.cuda.synchronize(self.device)
+        return [a.elapsed_time(b) * 1e3 for a, b in (getattr(self, "_xt", None) or [])]
 
     def dp_flush(self):
         """Pipelined DP: make the current stream wait for the last exchange + update (no-op otherwise)."""
@@ -484,7 +521,12 @@ class HipEngine:
         (tests/test_gpu_mirror.py::test_graph_replay_equals_eager).  Measured: profiles/r05_graph_capture.md."""
         if self._steps == 0:
             raise _lib.PevitError("capture_train_step: run one eager train_step first (first-step flag, one-time kernel attributes)")
-        self.dp_flush()
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            raise _lib.PevitError("capture_train_step is a single-GPU tool: the captured step has no gradient exchange")
+        # leaves the pipelined schedule altogether: a step gate still attached to the context would bake a wait on an event
+        # recorded OUTSIDE the capture (and the gated zero_grads path) into the graph
+        self.dp_pipeline_off()
         B = images.shape[0]
         self._check_batch(images, labels)
         fn = self.lib.pevit_train_forward_backward_u8 if images.dtype == torch.uint8 else self.lib.pevit_train_forward_backward
@@ -584,7 +626,10 @@ class HipEngine:
             if getattr(self, "_dp_streamk_off", False):        # (a staged step before this one switched it off)
                 self.tune("gemm_streamk", 1); self._dp_streamk_off = False
             logits, loss = self.forward_backward(images, labels, bn_training)
+            xt = self._xt_pair()
+            if xt: xt[0].record()
             self._exchange(self.grads, process_group, in_stream=True).wait()
+            if xt: xt[1].record()
             return logits, loss
         if mode != "staged":
             raise ValueError(f"forward_backward_dp: unknown mode {mode!r}")
@@ -620,8 +665,11 @@ class HipEngine:
         else:
             self.visual_backward(dfeat)
             work.append(self._exchange(self.grads[:self.n_tower], process_group))
+        xt = self._xt_pair()
+        if xt: xt[0].record()
         for w in work:
             w.wait()
+        if xt: xt[1].record()
         return self._logits[:B], self._loss
 
     def sync_replicas(self, process_group=None, src: int = 0):

@@ -19,9 +19,12 @@ backbone.
 """
 from __future__ import annotations
 
+import contextlib
 import gc
+import itertools
 import logging
 import os
+import threading
 import time
 import weakref
 
@@ -80,28 +83,149 @@ class _BackboneCache:
     ``build_model`` does, adapter keys of the checkpoint overlaid, frozen tensors untouched (nothing on this path
     ever writes them), engine optimiser state cleared when the new Classifier binds."""
 
+    MAX_PER_KEY = 4                 # each model carries a HIP context (arena + workspace, ~2 GB at ViT-B/32 batch 64)
+
     def __init__(self):
-        self._items = {}            # key -> (weakref to the owning Classifier, model)
+        self._items = {}            # key -> [(weakref to the owning Classifier, model), ...]: one entry per concurrently live run
+        self._lock = threading.Lock()
 
     def take(self, key):
-        entry = self._items.get(key)
-        if entry is None or entry[0]() is not None:
-            return None
-        return entry[1]
+        with self._lock:
+            for owner, model in reversed(self._items.get(key, ())):
+                if owner() is None:                                  # its Classifier is gone: idle (the most recently used first)
+                    return model
+        return None
 
     def give(self, key, owner, model):
-        self._items = {k: v for k, v in self._items.items() if k == key or v[0]() is not None}   # drop other idle models
-        self._items[key] = (weakref.ref(owner), model)
+        with self._lock:
+            for k in [k for k in self._items if k != key]:           # drop the idle models of other checkpoints / methods
+                self._items[k] = [e for e in self._items[k] if e[0]() is not None]
+                if not self._items[k]:
+                    del self._items[k]
+            entries = [e for e in self._items.get(key, ()) if e[1] is not model]
+            entries.append((weakref.ref(owner), model))
+            while len(entries) > self.MAX_PER_KEY and any(e[0]() is None for e in entries[:-1]):
+                entries.remove(next(e for e in entries[:-1] if e[0]() is None))      # oldest idle model (and its engine) goes
+            self._items[key] = entries
 
     def evict(self, model):
         """A backbone whose frozen tensors were changed (head merge) must never be handed to another Classifier."""
-        self._items = {k: v for k, v in self._items.items() if v[1] is not model}
+        with self._lock:
+            self._items = {k: [e for e in v if e[1] is not model] for k, v in self._items.items()}
+            self._items = {k: v for k, v in self._items.items() if v}
 
     def clear(self):
-        self._items.clear()
+        with self._lock:
+            self._items.clear()
+
+    def __len__(self):
+        with self._lock:
+            return sum(len(v) for v in self._items.values())
 
 
 _BACKBONES = _BackboneCache()
+
+
+# ---- K sweep runs at a time (round 6) ---------------------------------------------------------------------------------------------
+# The reference's sweep is ~90 independent short runs at batch 64 on ONE frozen backbone (kadaptation_clip.py:188-243,446-466;
+# feature.py:101).  A batch-64 step fills 120 of the 256 CUs in its large GEMMs, and a second run -- its own engine context, its
+# own stream, no dependency on the first -- fills the rest: measured 21.2 k -> 28.4 k (two runs) -> 30.2 k images/s (three) in
+# aggregate, every run bit-identical to the same run stepped alone (scripts/r6_dual_stream.py, bench.py `concurrent_runs`).
+# TRAIN.SWEEP_CONCURRENCY (or PEVIT_SWEEP_CONCURRENCY; default 2, 1 = the reference's strictly sequential order) runs that many
+# train_task calls of a sweep at a time, each in a worker thread under its own stream.  What stays deterministic: everything that
+# draws from the process-wide torch generator (adapter / head initialisation of a new Classifier, the epoch's shuffle) is an
+# ORDERED SECTION -- section n of run r starts when section n of the runs before it and section n - 1 of the runs behind it
+# are done -- so that a seeded sweep gives the same scores every time (they differ from the sequential sweep's, whose runs draw in
+# another order; each run equals the same run alone from the same draws).
+_RUN = threading.local()
+
+
+class _Turns:
+    def __init__(self, k):
+        self.cv, self.done, self.finished = threading.Condition(), [0] * k, [False] * k
+
+    @contextlib.contextmanager
+    def ordered(self, r):
+        with self.cv:
+            n = self.done[r]
+            self.cv.wait_for(lambda: all(self.finished[j] or self.done[j] > n for j in range(r)) and
+                             all(self.finished[j] or self.done[j] >= n for j in range(r + 1, len(self.done))))
+        try:
+            yield
+        finally:
+            with self.cv:
+                self.done[r] += 1
+                self.cv.notify_all()
+
+    def finish(self, r):
+        with self.cv:
+            self.finished[r] = True
+            self.cv.notify_all()
+
+
+def ordered_section():
+    """Context of a block that consumes the process-wide torch generator; a no-op outside a concurrent sweep."""
+    turns = getattr(_RUN, "turns", None)
+    return turns.ordered(_RUN.index) if turns is not None else contextlib.nullcontext()
+
+
+def sweep_concurrency(config) -> int:
+    k = os.environ.get("PEVIT_SWEEP_CONCURRENCY")
+    if k is None:
+        k = config.TRAIN.get("SWEEP_CONCURRENCY", 2) if hasattr(config.TRAIN, "get") else getattr(config.TRAIN, "SWEEP_CONCURRENCY", 2)
+    k = max(1, int(k))
+    return k if (torch.cuda.is_available() and len(config.GPUS) == 1) else 1
+
+
+def run_tasks(train_task_fn, train_dataloader, val_dataloader, config, wds, k):
+    """train_task_fn(..., sweep_run=True) for every weight decay of ``wds``, ``k`` at a time; a failed run scores None (the
+    reference's bare ``except: score = 0``, kadaptation_clip.py:200-205).  Returns the scores in the order of ``wds``."""
+    def one(cfg, wd):
+        cfg.defrost()
+        cfg.TRAIN.WD = wd
+        try:
+            return train_task_fn(train_dataloader, val_dataloader, cfg, sweep_run=True)
+        except Exception:
+            gpu_gc()
+            return None
+
+    if k <= 1 or len(wds) <= 1:
+        return [one(config, wd) for wd in wds]
+    scores = [None] * len(wds)
+    cuda = torch.cuda.is_available()
+    dev = torch.device("cuda", config.GPUS[0]) if cuda else None
+    streams = _RUN_STREAMS.setdefault(str(dev), [])
+    while cuda and len(streams) < k:
+        streams.append(torch.cuda.Stream(dev))
+    for lo in range(0, len(wds), k):
+        group = list(range(lo, min(lo + k, len(wds))))
+        turns = _Turns(len(group))
+        if cuda:
+            torch.cuda.synchronize(dev)          # models handed over from the pool were last used on another stream
+
+        def worker(r, i):
+            _RUN.turns, _RUN.index = turns, r
+            try:
+                if cuda:
+                    torch.cuda.set_device(dev)
+                with (torch.cuda.stream(streams[r]) if cuda else contextlib.nullcontext()):
+                    scores[i] = one(config.clone(), wds[i])
+                    if cuda:
+                        streams[r].synchronize()
+            finally:
+                _RUN.turns = None
+                turns.finish(r)
+        threads = [threading.Thread(target=worker, args=(r, i), name=f"sweep-run-{r}") for r, i in enumerate(group)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+    config.defrost()
+    config.TRAIN.WD = wds[-1]                    # (the sequential sweep leaves the last weight decay in the shared config)
+    return scores
+
+
+_RUN_STREAMS = {}
 _ZEROSHOT = {}
 
 
@@ -337,7 +461,7 @@ def _score(metric, outputs, targets):
         return 0.0, logits
 
 
-_FEED_STATE = {}        # device -> {"stream": copy stream, "slots": staging ring}; see DeviceFeeder
+_FEED_STATE = {}        # "device/run" -> {"stream": copy stream, "slots": staging ring}; see DeviceFeeder (run = index within a concurrent sweep group)
 
 
 class DeviceFeeder:
@@ -378,7 +502,7 @@ class DeviceFeeder:
         q = queue.Queue(maxsize=self.DEPTH)
         # the copy stream and the staging ring outlive the epoch (pinning 4 x 19 MB of host memory costs tens of ms: more than
         # the uploads of a 20-step epoch); every epoch ends with a stream synchronisation, so the next one finds them idle
-        cache = _FEED_STATE.setdefault(str(self.device), {})
+        cache = _FEED_STATE.setdefault(f"{self.device}/{getattr(_RUN, 'index', 0) if getattr(_RUN, 'turns', None) is not None else 0}", {})
         if "stream" not in cache:
             cache["stream"] = torch.cuda.Stream(self.device)
             cache["slots"] = [dict(h_img=None, h_tgt=None, d_img=None, d_tgt=None, used=None) for _ in range(self.SLOTS)]
@@ -473,7 +597,10 @@ def train_one(train_loader, model, criterion, optimizer, epoch, config):
     row = step = 0
     end = time.time()
     try:     # the fused step counts its BatchNorm batches host-side: folded into num_batches_tracked whatever ends the epoch
-        for images, target in (DeviceFeeder(train_loader, dev) if single else ((b[0], b[1]) for b in train_loader)):
+        batches = iter(DeviceFeeder(train_loader, dev) if single else ((b[0], b[1]) for b in train_loader))
+        with ordered_section():                               # the epoch's shuffle is drawn on the way to the first batch
+            first = next(batches, None)
+        for images, target in (() if first is None else itertools.chain((first,), batches)):
             data_time.update(time.time() - end)
             if images.shape[0] == 1:
                 continue                                      # BatchNorm cannot take a single-sample batch (reference :341)
@@ -540,7 +667,8 @@ def validate(val_loader, model, criterion, epoch, config, return_logits=False):
 
 def train_task(classifier_cls, train_dataloader, test_dataloader, config, sweep_run=False):
     best_acc1 = 0
-    model = classifier_cls(config, 0)
+    with ordered_section():                                   # adapter / head initialisation draws from the process-wide generator
+        model = classifier_cls(config, 0)
     n_train = sum(p.numel() for p in model.parameters() if p.requires_grad)
     logging.info(f"Number of trainable params: {n_train / 1000000}M.")
 
@@ -592,17 +720,10 @@ def hyperparameter_sweep(train_task_fn, train_dataloader, val_dataloader, config
     init_idx = [i for i, v in enumerate(grid) if v in coarse]
     peak_idx, peak_score, score = -1, 0, 0.0
 
-    def run(wd):
-        config.defrost()
-        config.TRAIN.WD = wd
-        try:
-            return train_task_fn(train_dataloader, val_dataloader, config, sweep_run=True)
-        except Exception:
-            gpu_gc()
-            return None
-
-    for idx in init_idx:
-        score = run(grid[idx])
+    k = sweep_concurrency(config)
+    # the runs of one search stage are independent of each other (the reference evaluates them one after the other and only
+    # then moves the peak): k at a time, scores consumed in the reference's order
+    for idx, score in zip(init_idx, run_tasks(train_task_fn, train_dataloader, val_dataloader, config, [grid[i] for i in init_idx], k)):
         if score is None:
             score = 0.0
             continue
@@ -613,9 +734,10 @@ def hyperparameter_sweep(train_task_fn, train_dataloader, val_dataloader, config
     step_span, it = 8, 0
     while step_span > 0:
         left, right = max(peak_idx - step_span, 0), min(peak_idx + step_span, len(grid) - 1)
-        for idx in [i for i in (left, right) if i != peak_idx]:
-            # WD_SEARCH_LEFT reproduces the reference's initial release, which always probed the left neighbour
-            score = run(grid[left] if config.TRAIN.WD_SEARCH_LEFT else grid[idx])
+        cand = [i for i in (left, right) if i != peak_idx]
+        # WD_SEARCH_LEFT reproduces the reference's initial release, which always probed the left neighbour
+        wds = [grid[left] if config.TRAIN.WD_SEARCH_LEFT else grid[i] for i in cand]
+        for idx, score in zip(cand, run_tasks(train_task_fn, train_dataloader, val_dataloader, config, wds, k)):
             if score is None:
                 score = 0.0
                 continue

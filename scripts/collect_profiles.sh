@@ -1,7 +1,7 @@
 #!/bin/bash
-# copy the summaries of the last scripts/gpu_r5_final.sh call from gpurun_out/ (scratch) into profiles/ (tracked)
+# copy the summaries of the last scripts/gpu_final.sh call from gpurun_out/ (scratch) into profiles/ (tracked)
 cd "$(dirname "$0")/.."
-R=${1:-r05}
+R=${1:-r06}
 cp gpurun_out/hbm_traffic.json profiles/hbm_traffic.json
 cp gpurun_out/pmc_$R/kernel_stats.md profiles/${R}_bench_kernel_stats.md
 tail -1 gpurun_out/pmc_$R/bench_line.json > profiles/${R}_bench_line.json

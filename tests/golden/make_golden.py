@@ -19,6 +19,7 @@ param groups of optim/build.py:81-84.
 Usage:  python tests/golden/make_golden.py [--full]
 """
 import argparse
+import contextlib
 import importlib.util
 import json
 import os
@@ -121,13 +122,126 @@ def sign_projections(v, index, k=32):
     return s @ v.double().flatten()
 
 
+# ---- the bf16 floor, measured on the REFERENCE itself (round 6) --------------------------------------------------------------
+# BASELINE configs 2-4 prescribe bf16 frozen weights.  How far that alone moves the reference's own outputs is recorded next to
+# every *_refinit fixture (``floor`` in the .json) by running the imported reference a second and a third time from the same
+# initial state:
+#   leg "weights":  resblocks.*.{attn.in_proj_weight, attn.out_proj.weight, mlp.c_fc.weight, mlp.c_proj.weight}, conv1.weight and
+#                   proj rounded to bf16 (stored back as f32), everything else and every operation in f32;
+#   leg "operands": the same, plus both operands of every CONTRACTION the reference evaluates (linear, matmul, bmm, attention)
+#                   rounded to bf16 on the way in (value rounded, gradient passed through), the gradient arriving at its output
+#                   rounded to bf16 (what a dX product on the matrix core reads), and the pixels rounded in front of conv1 --
+#                   f32 accumulation, f32 everything else (class bf16_operands).
+# Neither leg involves a line of the engine or of oracle/: it is the reference's arithmetic with bf16 operands.
+FROZEN_BF16 = (".attn.in_proj_weight", ".attn.out_proj.weight", ".mlp.c_fc.weight", ".mlp.c_proj.weight")
+
+
+def round_frozen_weights_(model, fp8=False):
+    """bf16 frozen weights; fp8: the four block weights as e4m3 codes x one power-of-two scale per output channel instead
+    (BASELINE config 5; the format is stated in pevit_amd/fp8.py -- every such value is exact in bf16), stem weights bf16."""
+    from pevit_amd import fp8 as fmt
+    n = 0
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if not name.startswith("visual."):
+                continue
+            if name.endswith(FROZEN_BF16) and ".resblocks." in name:
+                p.copy_(fmt.dequantize_rows(*fmt.quantize_rows(p)) if fp8 else p.bfloat16().float()); n += 1
+            elif name in ("visual.conv1.weight", "visual.proj"):
+                p.copy_(p.bfloat16().float()); n += 1
+    return n
+
+
+class _RoundValue(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _RoundGradient(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.clone()          # (not a view: compacter_model.py:307 adds its bias in place)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().float()
+
+
+class bf16_operands:
+    """Context: every CONTRACTION the reference evaluates sees bf16 operands (value rounded on the way in, gradient passed
+    through) and the gradient arriving at its output is rounded to bf16 -- what any engine that feeds bf16 operands to a matrix
+    core with f32 accumulation does, whatever its kernels look like:
+      * ``linear``: the reference's own alias (model.py:256 / lora_model.py:256) and torch.nn.functional.linear (nn.Linear, the
+        stock nn.MultiheadAttention of adapter_model.py:314 / compacter_model.py:481);
+      * ``torch.matmul`` (x @ H of model.py:584, compacter_model.py:306; LoRA's two products, lora_model.py:492,514) and
+        ``torch.bmm`` / ``torch.baddbmm`` with an inner dimension > 1 (q k^T and p v, model.py:804-812; the rank-1 outer products
+        of :567-579 are element-wise products and stay f32);
+      * ``scaled_dot_product_attention`` (what the stock attention calls with need_weights=False): restated as
+        softmax(q k^T / sqrt(d)) v with the two products rounded as above;
+      * the pixels in front of conv1.
+    Everything else -- softmax, LayerNorm, GELU, residual adds, the Kronecker expansions, the loss, SGD -- stays f32."""
+
+    def __init__(self, model):
+        self.model = model
+
+    def __enter__(self):
+        import math
+        import torch.nn.functional as F
+        raw_linear, raw_matmul, raw_bmm, raw_baddbmm = torch._C._nn.linear, torch.matmul, torch.bmm, torch.baddbmm
+        RV, RG = _RoundValue.apply, _RoundGradient.apply
+
+        def lin(x, w, b=None):
+            return RG(raw_linear(RV(x), RV(w), b))
+
+        def matmul(input, other, **kw):
+            return RG(raw_matmul(RV(input), RV(other), **kw))
+
+        def bmm(a, b, **kw):
+            if a.shape[-1] == 1:
+                return raw_bmm(a, b, **kw)
+            return RG(raw_bmm(RV(a), RV(b), **kw))
+
+        def baddbmm(m, a, b, **kw):
+            return RG(raw_baddbmm(m, RV(a), RV(b), **kw))
+
+        def sdpa(q, k, v, attn_mask=None, dropout_p=0.0, is_causal=False, scale=None, **kw):
+            assert dropout_p == 0.0 and not is_causal
+            s = RG(raw_matmul(RV(q), RV(k).transpose(-2, -1))) * (scale if scale is not None else 1.0 / math.sqrt(q.shape[-1]))
+            if attn_mask is not None:
+                s = s + attn_mask
+            return RG(raw_matmul(RV(torch.softmax(s, dim=-1)), RV(v)))
+        self.saved = [(F, "linear", F.linear), (F, "scaled_dot_product_attention", F.scaled_dot_product_attention),
+                      (torch, "matmul", torch.matmul), (torch, "bmm", torch.bmm), (torch, "baddbmm", torch.baddbmm)]
+        for m in ("refeval.model", "refeval.lora_model"):
+            if m in sys.modules:
+                self.saved.append((sys.modules[m], "linear", sys.modules[m].linear))
+        new = {"linear": lin, "scaled_dot_product_attention": sdpa, "matmul": matmul, "bmm": bmm, "baddbmm": baddbmm}
+        for obj, attr, _ in self.saved:
+            setattr(obj, attr, new[attr])
+        self.hook = self.model.visual.conv1.register_forward_pre_hook(lambda mod, a: (a[0].bfloat16().float(),))
+        return self
+
+    def __exit__(self, *exc):
+        for obj, attr, old in self.saved:
+            setattr(obj, attr, old)
+        self.hook.remove()
+        return False
+
+
 def run_case(method, arch_name, batch, classes, lora_r=4, steps=3, lr=0.01, wd=1e-4,
-             store_tensors=True, reference_init=False, redraw=False, full_layers=None, keep_frozen_from=None):
+             store_tensors=True, reference_init=False, redraw=False, full_layers=None, keep_frozen_from=None, bf16_leg=None, raw=None):
     arch = ARCHS[arch_name]
     sd = synth_state_dict(arch, seed=2, text_tower=(arch_name.startswith("tiny")))
     if store_tensors:
         sd = {k: (v.half().float() if v.dim() > 0 else v) for k, v in sd.items()}
     model = build_ref(method, sd, lora_r)
+    if bf16_leg:                 # "weights" | "operands" | "fp8" (= operands with e4m3 block weights): the floor legs above
+        assert round_frozen_weights_(model, fp8=(bf16_leg == "fp8")) == 4 * arch.layers + 2
     if keep_frozen_from and os.path.exists(keep_frozen_from):
         # tensors the reference draws from torch's GLOBAL generator and never trains (Compacter's shared phm_rule ~ U(-1, 1),
         # compacter_model.py:511-519) depend on everything that drew before them in the recording process: a re-recording of an
@@ -170,6 +284,9 @@ def run_case(method, arch_name, batch, classes, lora_r=4, steps=3, lr=0.01, wd=1
     crit = torch.nn.CrossEntropyLoss()
 
     out = {}
+    stack = contextlib.ExitStack()
+    if bf16_leg in ("operands", "fp8"):
+        stack.enter_context(bf16_operands(model))
     # ---- step 0: forward, loss, grads
     opt.zero_grad()
     feat0 = model.encode_image(images).detach()
@@ -196,6 +313,12 @@ def run_case(method, arch_name, batch, classes, lora_r=4, steps=3, lr=0.01, wd=1
         opt.step()
         losses.append(float(ls))
     final = {n: p.detach().clone() for n, p in clf.named_parameters() if p.requires_grad}
+    stack.close()
+    if raw is not None:          # the untruncated tensors of this run (floor_case compares two runs of the reference with them)
+        raw.update(logits0=out["logits0"], loss0=float(out["loss0"]), losses=list(losses),
+                   grad={n: g for n, g in grads.items() if g is not None}, grad_last=grads_last,
+                   delta={n: v - (adapters[n[len("backbone."):]] if n.startswith("backbone.") else (head_w if n.endswith("weight") else head_b))
+                          for n, v in final.items()})
 
     meta = dict(
         method=method, arch=arch_name, batch=batch, classes=classes, lora_r=lora_r,
@@ -304,6 +427,66 @@ def run_case(method, arch_name, batch, classes, lora_r=4, steps=3, lr=0.01, wd=1
     return meta, tensors
 
 
+REFINIT_CASES = (("kadaptation", "ViT-B/32", "full_b32_kadaptation_refinit", 4, False, None),
+                 ("lora", "ViT-B/32", "full_b32_lora_r8_refinit", 8, True, [0, 5, 11]),
+                 ("adapter", "ViT-B/32", "full_b32_adapter_refinit", 4, True, [0, 11]),
+                 ("compacter", "ViT-B/16", "full_b16_compacter_refinit", 4, False, None),
+                 ("kadaptation", "ViT-L/14", "full_l14_kadaptation_refinit", 4, False, None))
+
+
+def floor_case(method, arch_name, tag, lora_r, redraw, full_layers, legs=("weights", "operands")):
+    """The bf16 floor of one *_refinit fixture: three runs of the imported reference from the same initial state (f32 as recorded,
+    bf16 frozen weights, bf16 frozen weights + bf16 linear operands), per-tensor deviation of the two bf16 legs from the f32 run.
+    Written into the fixture's .json under "floor"; the .npz is not touched (and the f32 run must reproduce its loss trajectory
+    bit for bit, or nothing is written)."""
+    path = os.path.join(HERE, f"{tag}.json")
+    with open(path) as f:
+        meta = json.load(f)
+    runs = {}
+    for leg in (None,) + tuple(legs):
+        torch.manual_seed(0)
+        torch.set_num_threads(8)
+        raw = {}
+        run_case(method, arch_name, batch=8, classes=100, lora_r=lora_r, steps=5, store_tensors=False,
+                 reference_init=True, redraw=redraw, full_layers=full_layers, bf16_leg=leg, raw=raw)
+        runs[leg] = raw
+        print(tag, leg or "f32", "losses", raw["losses"], flush=True)
+    base = runs[None]
+    assert base["losses"] == meta["losses"], (base["losses"], meta["losses"])      # this IS the recorded run
+
+    def rel(a, b):
+        a = a.double().flatten(); b = b.double().flatten()
+        return float((a - b).norm() / (b.norm() + 1e-30))
+    floor = dict(meta.get("floor", {}))
+    floor.update({"recipe": "tests/golden/make_golden.py --refinit --bf16-weights: the imported reference run on the fixture's initial "
+                       "state with (weights) the frozen block weights, conv1.weight and proj rounded to bf16, (operands) "
+                       "additionally both operands of every contraction (linear, matmul, bmm, attention) and the gradient arriving at its "
+                       "output rounded to bf16; "
+                       "per-tensor relative L2 deviation from the reference's own f32 run (logits: max abs / max abs of the f32 "
+                       "run; losses: abs).  (fp8, ViT-L/14 only: the operands leg with the four block weights as e4m3 codes x "
+                       "power-of-two channel scales, pevit_amd/fp8.py)"})
+    for leg in legs:
+        r = runs[leg]
+        d = {"logits": float((r["logits0"].double() - base["logits0"].double()).abs().max() / base["logits0"].double().abs().max()),
+             "loss0": abs(r["loss0"] - base["loss0"]),
+             "loss_traj": [abs(a - b) for a, b in zip(r["losses"], base["losses"])]}
+        for kind in ("grad", "grad_last", "delta"):
+            d[kind] = {n: rel(r[kind][n], v) for n, v in base[kind].items() if float(v.abs().max()) != 0.0}
+            # one number for the whole step: all of its tensors as one vector
+            num = sum(float((r[kind][n].double() - v.double()).pow(2).sum()) for n, v in base[kind].items())
+            den = sum(float(v.double().pow(2).sum()) for v in base[kind].values())
+            d[kind + "_all"] = (num / (den + 1e-300)) ** 0.5
+        floor[leg] = d
+    meta["floor"] = floor
+    with open(path, "w") as f:
+        json.dump(meta, f, indent=1)
+    for leg in legs:
+        d = floor[leg]
+        print(tag, "floor", leg, "logits %.3g loss0 %.3g traj %.3g" % (d["logits"], d["loss0"], max(d["loss_traj"])),
+              "| worst grad %.3g grad_last %.3g delta %.3g" % tuple(max(d[k].values()) for k in ("grad", "grad_last", "delta")),
+              "| whole-step grad %.3g grad_last %.3g delta %.3g" % tuple(d[k + "_all"] for k in ("grad", "grad_last", "delta")), flush=True)
+
+
 def param_count_table():
     """Adapter-parameter counts for every (arch, method) at reference init (README.md:84-87)."""
     table = {}
@@ -353,6 +536,17 @@ def text_case():
                 zeroshot_weights=torch.stack(cols, dim=1).numpy())
 
 
+def tiny_lora_r8():
+    """tiny_lora_r8: the global generator is re-seeded right here (the r = 8 swap of build_ref draws its N(0, 0.02) `init/*` values
+    from it), so that this fixture regenerates bit for bit on its own (--tiny-lora-r8) as well as inside the full run."""
+    torch.manual_seed(0)
+    meta, tensors = run_case("lora", "tiny-128", batch=4, classes=10, lora_r=8)
+    np.savez_compressed(os.path.join(HERE, "tiny_lora_r8.npz"), **tensors)
+    with open(os.path.join(HERE, "tiny_lora_r8.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("tiny_lora_r8 ok; losses", meta["losses"])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also run the full-size ViT-B/32 bs=8 cases")
@@ -362,10 +556,18 @@ def main():
     ap.add_argument("--refinit", action="store_true",
                     help="only generate the *_refinit fixtures: full size at the reference initialisation, bs 8, 5 SGD steps "
                          "(ViT-B/32 KAdaptation / LoRA r=8 / Adapter, ViT-B/16 Compacter, ViT-L/14 KAdaptation)")
+    ap.add_argument("--bf16-weights", action="store_true",
+                    help="with --refinit: do not re-record; run the reference again with bf16 frozen weights (and bf16 linear "
+                         "operands) and store the per-tensor deviation from its own f32 run as `floor` in each *_refinit.json")
+    ap.add_argument("--legs", default="", help="with --bf16-weights: comma-separated subset of weights,operands,fp8 (merged into the stored floor)")
     ap.add_argument("--only", default="", help="with --refinit: only the fixtures whose name contains this")
     ap.add_argument("--other-archs", action="store_true",
                     help="only generate the full-size summaries for the ViT-B/16 and ViT-L/14 configurations of BASELINE.json")
+    ap.add_argument("--tiny-lora-r8", action="store_true", help="only (re)generate tiny_lora_r8.{npz,json}")
     args = ap.parse_args()
+    if args.tiny_lora_r8:
+        tiny_lora_r8()
+        return
     if args.text_only:
         np.savez_compressed(os.path.join(HERE, "tiny_text.npz"), **text_case())
         print("tiny_text written")
@@ -373,13 +575,12 @@ def main():
     if args.refinit:
         # full size, bs 8, at the reference initialisation, 5 SGD steps (gradients of the first AND the last step recorded: by then
         # LoRA's B, the bottleneck up-projection and Compacter's factors have moved, so every low-rank gradient kernel carries signal)
-        cases = (("kadaptation", "ViT-B/32", "full_b32_kadaptation_refinit", 4, False, None),
-                 ("lora", "ViT-B/32", "full_b32_lora_r8_refinit", 8, True, [0, 5, 11]),
-                 ("adapter", "ViT-B/32", "full_b32_adapter_refinit", 4, True, [0, 11]),
-                 ("compacter", "ViT-B/16", "full_b16_compacter_refinit", 4, False, None),
-                 ("kadaptation", "ViT-L/14", "full_l14_kadaptation_refinit", 4, False, None))
-        for method, arch_name, tag, lora_r, redraw, full_layers in cases:
+        for method, arch_name, tag, lora_r, redraw, full_layers in REFINIT_CASES:
             if args.only and args.only not in tag:
+                continue
+            if args.bf16_weights:
+                legs = tuple(args.legs.split(",")) if args.legs else (("weights", "operands", "fp8") if "l14" in tag else ("weights", "operands"))
+                floor_case(method, arch_name, tag, lora_r, redraw, full_layers, legs)
                 continue
             torch.manual_seed(0)
             torch.set_num_threads(8)
@@ -426,10 +627,7 @@ def main():
         with open(os.path.join(HERE, f"tiny_{method}.json"), "w") as f:
             json.dump(meta, f, indent=1)
         print(method, "tiny ok; losses", meta["losses"], "n_adapter", meta["n_adapter_params"])
-    meta, tensors = run_case("lora", "tiny-128", batch=4, classes=10, lora_r=8)
-    np.savez_compressed(os.path.join(HERE, "tiny_lora_r8.npz"), **tensors)
-    with open(os.path.join(HERE, "tiny_lora_r8.json"), "w") as f:
-        json.dump(meta, f, indent=1)
+    tiny_lora_r8()
     np.savez_compressed(os.path.join(HERE, "tiny_text.npz"), **text_case())
     if args.counts:
         with open(os.path.join(HERE, "param_counts.json"), "w") as f:

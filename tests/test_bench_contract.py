@@ -77,12 +77,15 @@ def test_step_floors_follow_the_survey_formula():
 def test_flush_helper_and_the_dp_schedule_option(monkeypatch, capsys):
     """The JSON line must be the last line of stdout even when a C library has buffered output of its own (the collective library's
     banner): `_flush_c_stdio` empties the process's C stdio buffers and never raises; `--dp-exchange` offers the three schedules and
-    defaults to the single in-stream exchange (and the re-exec for `--gpus N` hands the choice on to the ranks)."""
+    defaults to timing the in-stream AND the overlapped one (and the re-exec for `--gpus N` hands the choice on to the ranks)."""
     bench = _bench()
     bench._flush_c_stdio()                                   # callable without a GPU, idempotent
     bench._flush_c_stdio()
     src = open(os.path.join(ROOT, "bench.py")).read()
-    assert 'choices=["single", "staged", "pipelined"], default="single"' in src
+    # N > 1 default: BOTH the in-stream exchange and the overlapped one are timed, the faster is `value`, both are reported
+    assert 'choices=["auto", "single", "staged", "pipelined"], default="auto"' in src
+    for field in ("exchange_us_per_step", "per_rank_ms_per_step", "exchange_schedules"):
+        assert f'"{field}"' in src
     # the print of the line comes after the process group is gone and the buffers are flushed
     tail = src[src.rindex("destroy_process_group()"):]
     assert "_flush_c_stdio()" in tail and tail.index("_flush_c_stdio()") < tail.index("print(json.dumps(out)")

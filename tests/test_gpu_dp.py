@@ -121,3 +121,11 @@ def test_bench_multi_rank_launch_contract(tmp_path, exchange):
     assert abs(d["value"] - 32 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]      # whole job: all ranks' images / time
     assert "cpu_baseline" not in d                                                          # rank 0 at N = 1 only
     assert d["roofline"]["achieved"] > 0
+    # the line diagnoses itself: both schedules timed, per-rank step times, the exchange's device time
+    c = d["config"]
+    assert set(c["exchange_schedules"]) == {"single", "staged"} and c["gradient_exchange_schedule"]
+    best = max(c["exchange_schedules"].values(), key=lambda v: v["images_per_sec"])
+    assert abs(best["images_per_sec"] - d["value"]) < 1e-6 * d["value"]
+    for v in c["exchange_schedules"].values():
+        assert len(v["per_rank_ms_per_step"]) == 2 and v["exchange_us_per_step"] > 0
+    assert len(c["per_rank_ms_per_step"]) == 2 and c["exchange_us_per_step"] > 0

@@ -186,7 +186,7 @@ def test_train_task_contract_and_backbone_reuse(method, ckpt):
     assert info["n_visual_params"] == meta["n_visual_params"] and info["n_backbone_params"] == meta["n_backbone_params"]
     assert info["n_params"] == meta["n_backbone_params"] + 64 * meta["classes"] + meta["classes"] + 1
     assert info["best_logits"].shape == (4, meta["classes"]) and 0.0 <= best <= 100.0
-    (owner, backbone), = _harness._BACKBONES._items.values()
+    ((owner, backbone),), = _harness._BACKBONES._items.values()
     assert owner() is None                                               # the Classifier of the run is gone ...
     engine = backbone.visual._engine
     assert engine is not None                                            # ... its backbone and HIP context are kept
@@ -194,12 +194,81 @@ def test_train_task_contract_and_backbone_reuse(method, ckpt):
     for _ in range(2):
         torch.manual_seed(0)
         results.append(mod.train_task(train, test, cfg, sweep_run=True))
-        (_, again), = _harness._BACKBONES._items.values()
+        ((_, again),), = _harness._BACKBONES._items.values()
         assert again is backbone and again.visual._engine is engine       # same objects, nothing re-created
     assert results[0] == results[1] and isinstance(results[0], float)
     cfg.TRAIN.WD = 1e-6                                                   # what a sweep does between runs
     assert isinstance(mod.train_task(train, test, cfg, sweep_run=True), float)
     _harness._BACKBONES.clear()
+
+
+def test_sweep_runs_two_at_a_time_deterministically(ckpt):
+    """Round 6: hyperparameter_sweep runs TRAIN.SWEEP_CONCURRENCY train_task calls at a time, each in its own
+    thread, engine context and stream; whatever draws from the process-wide generator is an ordered section, so that a seeded
+    sweep gives the same result every time; two backbones (+ engines) are kept between the groups; with SWEEP_CONCURRENCY = 1 the
+    sweep is the strictly sequential one."""
+    from pevit_amd.evaluation import _harness
+    from pevit_amd.evaluation import model as mirror
+    mod = importlib.import_module("pevit_amd.evaluation.kadaptation_clip")
+    meta, t = load_golden("tiny_kadaptation")
+    cfg = tiny_config(ckpt, classes=meta["classes"])
+    cfg.TRAIN.LR, cfg.TRAIN.END_EPOCH = 0.01, 2
+    cfg.TRAIN.SEARCH_WD_LOG_LOWER, cfg.TRAIN.SEARCH_WD_LOG_UPPER = -6, 0
+    train, test = OneBatch(t["images"], t["labels"], 3), OneBatch(t["images"], t["labels"], 1)
+    mirror._ENGINES.clear(); _harness._BACKBONES.clear()
+    out = {}
+    for k in (2, 2, 1, 1):
+        cfg.defrost(); cfg.TRAIN.SWEEP_CONCURRENCY = k
+        assert _harness.sweep_concurrency(cfg) == k
+        torch.manual_seed(0)
+        out.setdefault(k, []).append(mod.hyperparameter_sweep(train, test, cfg))
+        assert len(_harness._BACKBONES) == k                                  # k idle backbones (with their engines) are kept
+        if k == 2:
+            engines = {id(m.visual._engine) for entries in _harness._BACKBONES._items.values() for _, m in entries}
+            assert len(engines) == 2 and None not in engines                 # two contexts: own parameters, workspace, stream
+    assert out[2][0] == out[2][1] and out[1][0] == out[1][1]                   # deterministic at either setting
+    _harness._BACKBONES.clear()
+
+
+def test_concurrent_engine_runs_are_bit_identical_to_solo_runs():
+    """What the concurrent sweep rests on: two engine contexts stepped from two host threads on two streams leave exactly the
+    parameters each leaves when stepped alone (same kernels, own buffers; nothing process-global on the step path)."""
+    import threading
+    from pevit_amd.engine import HipEngine
+    from pevit_amd.synth import ARCHS, reference_init_, synth_batch, synth_state_dict
+    arch = ARCHS["tiny-256"]
+    sd = synth_state_dict(arch, seed=2, text_tower=False)
+    engines, batches, streams = [], [], [torch.cuda.Stream(), torch.cuda.Stream()]
+    for r in range(2):
+        e = HipEngine(arch, "kadaptation", 10, 16)
+        e.load_state_dict(sd)
+        reference_init_(e.param_views().items(), "kadaptation", seed=7 + r)
+        with torch.no_grad():
+            e.param_views()["layers.0.weight"].normal_(0, 0.05, generator=None)
+        im, lb = synth_batch(16, arch.resolution, 10, seed_img=2 * r, seed_lbl=2 * r + 1)
+        engines.append(e); batches.append((im.cuda(), lb.cuda()))
+    init = [e.params.clone() for e in engines]
+
+    def steps(r, n=12):
+        with torch.cuda.stream(streams[r]):
+            for _ in range(n):
+                engines[r].train_step(*batches[r], lr=0.01 * (r + 1), momentum=0.9, weight_decay=1e-5)
+            streams[r].synchronize()
+    solo = []
+    for r in range(2):
+        steps(r)
+        solo.append(engines[r].params.clone())
+    for e, p in zip(engines, init):
+        e.reset_run(); e.params.copy_(p)
+    torch.cuda.synchronize()
+    threads = [threading.Thread(target=steps, args=(r,)) for r in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    for r in range(2):
+        engines[r].check_streamk()
+        assert torch.equal(engines[r].params, solo[r]) and not torch.equal(solo[r], init[r])
 
 
 def test_batches_larger_than_configured_grow_the_workspace(ckpt):

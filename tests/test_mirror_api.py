@@ -231,6 +231,7 @@ def test_head_merge_folds_the_projection_into_the_head(ckpt):
 # ---------------------------------------------------------------------------------- sweep logic
 def test_weight_decay_sweep_visits_reference_grid():
     cfg = default_config()
+    cfg.TRAIN.SWEEP_CONCURRENCY = 1                                # the visiting ORDER is asserted below: one run at a time
     seen = []
 
     def fake_train_task(tr, va, config, sweep_run=False):
@@ -246,6 +247,44 @@ def test_weight_decay_sweep_visits_reference_grid():
     assert len(seen) == 7 + 2 * 4                                  # then spans 8,4,2,1, two probes each
     assert all(np.isclose(grid, s).any() for s in seen)
     assert abs(np.log10(wd) - 1.4) <= 0.125 / 2 + 1e-9 and score > 99.9
+
+
+def test_sweep_runs_k_at_a_time_in_ordered_sections():
+    """run_tasks (round 6): k train_task calls at a time in worker threads; scores come back in the order of the weight decays, a
+    failing run scores None without blocking its group, every run sees its OWN config, and what the runs draw from the process-wide
+    generator inside ordered sections is the same every time (section n of run r after section n of the runs before it and section
+    n - 1 of the runs behind it)."""
+    import threading
+    cfg = default_config()
+    wds = [10.0 ** e for e in range(-3, 4)]
+
+    def fake_train_task(tr, va, config, sweep_run=False):
+        draws = []
+        for _ in range(3):                                        # construction + two epochs
+            with _harness.ordered_section():
+                draws.append(float(torch.rand(())))
+            time.sleep(0.002 * (1 + hash(config.TRAIN.WD) % 3))   # uneven run lengths
+        if config.TRAIN.WD == 1.0:
+            raise RuntimeError("diverged")
+        assert threading.current_thread().name.startswith("sweep-run-")
+        return (config.TRAIN.WD, tuple(draws))
+
+    import time
+    res = []
+    for _ in range(2):
+        torch.manual_seed(0)
+        res.append(_harness.run_tasks(fake_train_task, None, None, cfg, wds, 3))
+    assert res[0] == res[1]                                        # deterministic
+    assert [r[0] if r else None for r in res[0]] == [w if w != 1.0 else None for w in wds]
+    # the order of the draws inside a group of three: section 0 of runs 0, 1, 2, then section 1 of runs 0, 1, 2, ...
+    torch.manual_seed(0)
+    expect = [float(torch.rand(())) for _ in range(9)]
+    group = res[0][:3]
+    assert [group[r][1][n] for n in range(3) for r in range(3)] == expect
+    # one at a time is the plain loop in the caller's thread
+    seen = []
+    _harness.run_tasks(lambda tr, va, c, sweep_run=False: seen.append((c.TRAIN.WD, threading.current_thread().name)) or 1.0, None, None, cfg, wds, 1)
+    assert [w for w, _ in seen] == wds and all(not n.startswith("sweep-run-") for _, n in seen)
 
 
 def test_lr_sweep_and_final_run_contract():

@@ -231,3 +231,30 @@ def test_oracle_trajectory_at_reference_init(case):
     n += check("delta", "layers.0.weight", tr.head_w.detach() - init["layers.0.weight"], 5e-3)
     n += check("delta", "layers.0.bias", tr.head_b.detach() - init["layers.0.bias"], 5e-3)
     assert n == sum(k.startswith(("delta/", "delta_proj/")) for k in t)
+
+
+ALL_REFINIT = REFINIT + ["full_b16_compacter_refinit", "full_l14_kadaptation_refinit"]
+
+
+@pytest.mark.parametrize("case", ALL_REFINIT)
+def test_refinit_fixtures_carry_the_reference_recorded_bf16_floor(case):
+    """Round 6: every *_refinit fixture holds, next to the reference's f32 results, how far the REFERENCE ITSELF moves when its frozen
+    weights (leg "weights") and all its contraction operands (leg "operands"; ViT-L/14 also "fp8") are rounded to bf16
+    (tests/golden/make_golden.py --refinit --bf16-weights).  tests/test_gpu_refinit.py gates the production kernels at
+    max(stated gate, 2 x this floor); here: the floor is complete (an entry for every recorded tensor), finite, and the weights-only
+    leg keeps the logits within the stated 2e-2 on every fixture -- i.e. bf16 WEIGHTS alone never cost a stated gate on the logits."""
+    import math
+    meta, t = load_golden(case)
+    fl = meta["floor"]
+    legs = ["weights", "operands"] + (["fp8"] if "l14" in case else [])
+    for leg in legs:
+        d = fl[leg]
+        for kind in ("grad", "grad_last", "delta"):
+            recorded = {k.split("/", 1)[1] for k in t if k.startswith((kind + "/", kind + "_proj/"))}
+            assert recorded <= set(d[kind]), (leg, kind, sorted(recorded - set(d[kind]))[:3])
+            assert all(math.isfinite(v) and v >= 0.0 for v in d[kind].values())
+            assert math.isfinite(d[kind + "_all"]) and 0.0 <= d[kind + "_all"] < 1.0
+        assert len(d["loss_traj"]) == meta["steps"] and all(math.isfinite(v) for v in d["loss_traj"])
+    assert fl["weights"]["logits"] < 2e-2
+    # the operand leg contains the weight leg's rounding: on the whole step it is not smaller (up to the noise of two draws)
+    assert fl["operands"]["grad_all"] > 0.5 * fl["weights"]["grad_all"]
