@@ -147,5 +147,23 @@ def update_config(config, args):
     config.defrost()
     from_file(args.cfg)
     config.merge_from_list(getattr(args, "opts", None))
+    # config/default.py:257,260: the learning rate is scaled by the world size and the rank recorded (utils/comm.py:11-33: both read
+    # torch.distributed, 1 / 0 in every run of the reference, which never initialises a process group).  Under this build's data
+    # parallelism the gradients of the ranks are AVERAGED (1 / world folded into the SGD kernel), i.e. the global batch is world x B
+    # at world x LR: the reference's own linear scaling rule, applied by the same line.
+    world, rank = distributed_world()
+    config.TRAIN.LR = config.TRAIN.LR * world
+    config.RANK = rank
     config.NAME = op.splitext(op.basename(args.cfg))[0] + config.get("NAME", "")
     config.freeze()
+
+
+def distributed_world():
+    """(world size, rank) of the default process group; (1, 0) without one (utils/comm.py:11-33)."""
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_world_size(), dist.get_rank()
+    except Exception:
+        pass
+    return 1, 0

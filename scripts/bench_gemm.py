@@ -16,7 +16,7 @@ lib = _lib.load()
 P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
 S = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
 EPI = dict(QKV=0, BIAS_RESID=1, BIAS_GELU=2, DGELU=3, F32=4, BF16=5)
-NAMES = {-1: "heuristic", 0: "128x128 4w", 1: "64x128 4w", 2: "64x64 4w", 3: "256x128 8w", 4: "256x256 8w", 5: "320x256 8w", 6: "128x64 4w", 7: "128x128 4w pipelined", 8: "64x128 4w pipelined"}
+NAMES = {-1: "heuristic", 0: "128x128 4w", 1: "64x128 4w", 2: "64x64 4w", 3: "256x128 8w", 4: "256x256 8w", 5: "320x256 8w", 6: "128x64 4w", 7: "128x128 4w pipelined", 8: "64x128 4w pipelined", 9: "160x256 8w (1x8 waves, two tiles per CU)"}
 
 
 def tune(key, val):

@@ -20,14 +20,14 @@ O=gpurun_out/$TAG; mkdir -p $O
 n=0
 for step in "$@"; do
   n=$((n + 1))
-  set -- $step
+  eval "set -- $step"          # (inner quotes of a step survive: "tests -k 'a or b'")
   verb=$1; shift
   echo "=== [$TAG $n] $verb $*"
   case $verb in
     tests)    if [ $# -eq 0 ]; then set -- tests -m gpu -q; fi
               timeout ${STEP_TIMEOUT:-1500} python -m pytest -p no:cacheprovider "$@" > $O/pytest_$n.log 2>&1; echo "rc=$?" >> $O/pytest_$n.log; tail -${TAIL:-12} $O/pytest_$n.log ;;
     bench)    timeout ${STEP_TIMEOUT:-900} python bench.py "$@" > $O/bench_$n.json 2> $O/bench_$n.err; cut -c1-600 $O/bench_$n.json ;;
-    ab)       eval "set -- $step"; shift; timeout ${STEP_TIMEOUT:-1800} bash scripts/gpu_ab.sh "$@" 2>&1 | tee $O/ab_$n.log ;;
+    ab)       timeout ${STEP_TIMEOUT:-1800} bash scripts/gpu_ab.sh "$@" 2>&1 | tee $O/ab_$n.log ;;
     kstats)   timeout ${STEP_TIMEOUT:-900} bash scripts/gpu_kstats.sh "$@" 2>&1 | tee $O/kstats_$n.log ;;
     variants) timeout ${STEP_TIMEOUT:-1800} bash scripts/gpu_variants.sh "$@" 2>&1 | tee $O/variants_$n.log ;;
     pmc)      timeout ${STEP_TIMEOUT:-2400} bash scripts/run_pmc_passes.sh "$@" 2>&1 | tail -60 | tee $O/pmc_$n.log ;;

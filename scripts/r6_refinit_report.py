@@ -62,7 +62,7 @@ def main():
                        ("grad_all", m["grad_all"]), ("grad_last_all", m["grad_last_all"]), ("delta_all", m["delta_all"])):
             fw, fo = f("weights", q), f(legs[-1], q)
             v2 = (max(m2[q]) if q == "loss_traj" else m2[q]) if m2 else None
-            lines.append(f"| {tag} | {w} | {q} | {val:.3g} | " + (f"{v2:.3g} | " if tune else "") + f"{fw:.3g} | {fo:.3g} | {val / max(fw, fo, 1e-12):.2f} |")
+            lines.append(f"| {tag} | {w} | {q} | {val:.3g} | " + (("- | " if v2 is None else f"{v2:.3g} | ") if tune else "") + f"{fw:.3g} | {fo:.3g} | {val / max(fw, fo, 1e-12):.2f} |")
         for kind in ("grad", "grad_last", "delta"):
             kf = kind_floors(fl, legs, kind) if fl else {}
             worst, worst2 = {}, {}
@@ -74,7 +74,7 @@ def main():
             rec["kinds"][kind] = {k: {"engine": v, "floor": kf.get(k), "ab": worst2.get(k)} for k, v in worst.items()}
             for k, v in sorted(worst.items(), key=lambda kv: -kv[1] / max(kf.get(kv[0], 1e-12), 1e-12))[:6]:
                 kind_lines.append(f"| {tag} | {w} | {kind} | {k.split('*.')[-1].replace('backbone.visual.transformer.', '')} | {v:.3g} | "
-                                  + (f"{worst2.get(k, float('nan')):.3g} | " if tune else "") + f"{kf.get(k, float('nan')):.3g} | {v / max(kf.get(k, 1e-12), 1e-12):.2f} |")
+                                  + (("- | " if not m2 else f"{worst2.get(k, float('nan')):.3g} | ") if tune else "") + f"{kf.get(k, float('nan')):.3g} | {v / max(kf.get(k, 1e-12), 1e-12):.2f} |")
         with open(f"gpurun_out/r6_refinit/{tag}_{w}.json", "w") as fjson:
             json.dump(rec, fjson, indent=1)
         print(tag, w, "done", flush=True)

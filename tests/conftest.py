@@ -59,6 +59,41 @@ def max_rel(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
+def kind_of(name):
+    """a tensor's kind: its name with the block index replaced by *"""
+    import re
+    return re.sub(r"resblocks\.\d+\.", "resblocks.*.", name)
+
+
+FLOOR_C = 3.0         # the ONE constant over the reference-recorded bf16 floor (tests/test_gpu_refinit.py has the reasoning)
+
+
+def reference_floors(meta, fp8=False):
+    """{quantity: floor} of a fixture that carries the reference-recorded bf16 floor (``floor`` in its .json, written by
+    tests/golden/make_golden.py --bf16-weights / --floor-random: the imported reference re-run with bf16 frozen weights and with bf16
+    contraction operands, deviation from its own f32 run): the larger of the two legs (fp8 engine: its fp8 leg as well); for the
+    gradient kinds per TENSOR KIND (largest over the blocks).  None when the fixture has no floor."""
+    f = meta.get("floor")
+    if not f:
+        return None
+    legs = [f["weights"], f["operands"]] + ([f["fp8"]] if fp8 else [])
+    out = {"logits": max(l["logits"] for l in legs), "loss0": max(l["loss0"] for l in legs),
+           "loss_traj": max(max(l["loss_traj"]) for l in legs), "loss_traj_steps": [max(l["loss_traj"][i] for l in legs) for i in range(len(legs[0]["loss_traj"]))]}
+    for kind in ("grad", "grad_last", "delta"):
+        out[kind] = {}
+        for l in legs:
+            for n, v in l[kind].items():
+                out[kind][kind_of(n)] = max(out[kind].get(kind_of(n), 0.0), v)
+        out[kind + "_all"] = max(l[kind + "_all"] for l in legs)
+    return out
+
+
+def floor_gate(stated, floor, cap=None):
+    """max(stated gate, FLOOR_C x reference floor), optionally capped (per-tensor gates stay below the score of a zero tensor)"""
+    g = max(stated, FLOOR_C * floor)
+    return min(g, cap) if cap is not None else g
+
+
 def sign_projections(v, index, k=32):
     """The k seeded +-1 projections of tests/golden/make_golden.py:sign_projections (same generator, same order)."""
     g = torch.Generator(device="cpu"); g.manual_seed(100003 + index)

@@ -178,7 +178,8 @@ class bf16_operands:
     core with f32 accumulation does, whatever its kernels look like:
       * ``linear``: the reference's own alias (model.py:256 / lora_model.py:256) and torch.nn.functional.linear (nn.Linear, the
         stock nn.MultiheadAttention of adapter_model.py:314 / compacter_model.py:481);
-      * ``torch.matmul`` (x @ H of model.py:584, compacter_model.py:306; LoRA's two products, lora_model.py:492,514) and
+      * ``torch.matmul`` (x @ H of model.py:584, compacter_model.py:306; LoRA's two products, lora_model.py:492,514), the ``@``
+        operator (the output projection ``x @ self.proj``, model.py:1049: the gradient entering the tower is rounded there) and
         ``torch.bmm`` / ``torch.baddbmm`` with an inner dimension > 1 (q k^T and p v, model.py:804-812; the rank-1 outer products
         of :567-579 are element-wise products and stay f32);
       * ``scaled_dot_product_attention`` (what the stock attention calls with need_weights=False): restated as
@@ -216,11 +217,13 @@ class bf16_operands:
                 s = s + attn_mask
             return RG(raw_matmul(RV(torch.softmax(s, dim=-1)), RV(v)))
         self.saved = [(F, "linear", F.linear), (F, "scaled_dot_product_attention", F.scaled_dot_product_attention),
-                      (torch, "matmul", torch.matmul), (torch, "bmm", torch.bmm), (torch, "baddbmm", torch.baddbmm)]
+                      (torch, "matmul", torch.matmul), (torch, "bmm", torch.bmm), (torch, "baddbmm", torch.baddbmm),
+                      (torch.Tensor, "__matmul__", torch.Tensor.__matmul__)]
         for m in ("refeval.model", "refeval.lora_model"):
             if m in sys.modules:
                 self.saved.append((sys.modules[m], "linear", sys.modules[m].linear))
-        new = {"linear": lin, "scaled_dot_product_attention": sdpa, "matmul": matmul, "bmm": bmm, "baddbmm": baddbmm}
+        new = {"linear": lin, "scaled_dot_product_attention": sdpa, "matmul": matmul, "bmm": bmm, "baddbmm": baddbmm,
+               "__matmul__": lambda a, b: matmul(a, b)}
         for obj, attr, _ in self.saved:
             setattr(obj, attr, new[attr])
         self.hook = self.model.visual.conv1.register_forward_pre_hook(lambda mod, a: (a[0].bfloat16().float(),))
@@ -434,7 +437,7 @@ REFINIT_CASES = (("kadaptation", "ViT-B/32", "full_b32_kadaptation_refinit", 4, 
                  ("kadaptation", "ViT-L/14", "full_l14_kadaptation_refinit", 4, False, None))
 
 
-def floor_case(method, arch_name, tag, lora_r, redraw, full_layers, legs=("weights", "operands")):
+def floor_case(method, arch_name, tag, lora_r, redraw, full_layers, legs=("weights", "operands"), run_kwargs=None):
     """The bf16 floor of one *_refinit fixture: three runs of the imported reference from the same initial state (f32 as recorded,
     bf16 frozen weights, bf16 frozen weights + bf16 linear operands), per-tensor deviation of the two bf16 legs from the f32 run.
     Written into the fixture's .json under "floor"; the .npz is not touched (and the f32 run must reproduce its loss trajectory
@@ -447,8 +450,8 @@ def floor_case(method, arch_name, tag, lora_r, redraw, full_layers, legs=("weigh
         torch.manual_seed(0)
         torch.set_num_threads(8)
         raw = {}
-        run_case(method, arch_name, batch=8, classes=100, lora_r=lora_r, steps=5, store_tensors=False,
-                 reference_init=True, redraw=redraw, full_layers=full_layers, bf16_leg=leg, raw=raw)
+        kw = run_kwargs or dict(batch=8, classes=100, steps=5, store_tensors=False, reference_init=True, redraw=redraw, full_layers=full_layers)
+        run_case(method, arch_name, lora_r=lora_r, bf16_leg=leg, raw=raw, **kw)
         runs[leg] = raw
         print(tag, leg or "f32", "losses", raw["losses"], flush=True)
     base = runs[None]
@@ -477,14 +480,31 @@ def floor_case(method, arch_name, tag, lora_r, redraw, full_layers, legs=("weigh
             den = sum(float(v.double().pow(2).sum()) for v in base[kind].values())
             d[kind + "_all"] = (num / (den + 1e-300)) ** 0.5
         floor[leg] = d
+    floor["contractions"] = "linear, matmul, @, bmm, baddbmm, scaled_dot_product_attention"      # what the operands leg rounds (round 6, final)
     meta["floor"] = floor
     with open(path, "w") as f:
         json.dump(meta, f, indent=1)
     for leg in legs:
         d = floor[leg]
         print(tag, "floor", leg, "logits %.3g loss0 %.3g traj %.3g" % (d["logits"], d["loss0"], max(d["loss_traj"])),
-              "| worst grad %.3g grad_last %.3g delta %.3g" % tuple(max(d[k].values()) for k in ("grad", "grad_last", "delta")),
+              "| worst grad %.3g grad_last %.3g delta %.3g" % tuple(max(d[k].values(), default=0.0) for k in ("grad", "grad_last", "delta")),
               "| whole-step grad %.3g grad_last %.3g delta %.3g" % tuple(d[k + "_all"] for k in ("grad", "grad_last", "delta")), flush=True)
+
+
+RANDOM_ADAPTER_FIXTURES = ("tiny_kadaptation", "tiny_lora", "tiny_lora_r8", "tiny_adapter", "tiny_compacter",
+                           "full_b32_kadaptation", "full_b32_lora", "full_b32_adapter", "full_b32_compacter",
+                           "full_b32_lora_r8", "full_b16_compacter", "full_l14_kadaptation")
+
+
+def floor_random_adapter_fixture(tag):
+    """The same floor for a random-adapter fixture (tiny_*, full_*): the run is rebuilt from the fixture's own .json (method,
+    arch, batch, classes, steps, lr, wd) exactly as main() recorded it -- the f32 leg must reproduce the recorded loss trajectory."""
+    with open(os.path.join(HERE, f"{tag}.json")) as f:
+        meta = json.load(f)
+    tiny = tag.startswith("tiny")
+    kw = dict(batch=meta["batch"], classes=meta["classes"], steps=meta["steps"], lr=meta["lr"], wd=meta["wd"], store_tensors=tiny,
+              keep_frozen_from=os.path.join(HERE, f"{tag}.npz"))
+    floor_case(meta["method"], meta["arch"], tag, meta["lora_r"], False, None, run_kwargs=kw)
 
 
 def param_count_table():
@@ -559,6 +579,8 @@ def main():
     ap.add_argument("--bf16-weights", action="store_true",
                     help="with --refinit: do not re-record; run the reference again with bf16 frozen weights (and bf16 linear "
                          "operands) and store the per-tensor deviation from its own f32 run as `floor` in each *_refinit.json")
+    ap.add_argument("--floor-random", action="store_true",
+                    help="store the same reference-recorded bf16 floor in the random-adapter fixtures (tiny_*, full_*; --only filters)")
     ap.add_argument("--legs", default="", help="with --bf16-weights: comma-separated subset of weights,operands,fp8 (merged into the stored floor)")
     ap.add_argument("--only", default="", help="with --refinit: only the fixtures whose name contains this")
     ap.add_argument("--other-archs", action="store_true",
@@ -567,6 +589,11 @@ def main():
     args = ap.parse_args()
     if args.tiny_lora_r8:
         tiny_lora_r8()
+        return
+    if args.floor_random:
+        for tag in RANDOM_ADAPTER_FIXTURES:
+            if not args.only or args.only in tag:
+                floor_random_adapter_fixture(tag)
         return
     if args.text_only:
         np.savez_compressed(os.path.join(HERE, "tiny_text.npz"), **text_case())

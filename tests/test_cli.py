@@ -140,7 +140,26 @@ def test_full_sweep_then_final_run_on_the_engine(tmp_path, monkeypatch):
                           "OUTPUT_DIR", str(tmp_path / "out"), "TRAIN.IMAGE_SIZE", "[48, 48]", "DATASET.SYNTHETIC_SIZES", "(40, 12)"])
     assert 6 * 11 + 1 <= len(runs) <= 6 * 15 + 1   # 7 coarse + 4 x (1 or 2) bisection probes per learning rate (one when the
                                                     # peak sits on the edge of the grid), + the final run
-    assert len(loads) == 1                       # the module tree is built from the checkpoint once, not 91 times
+    # the module tree is built from the checkpoint once per concurrently live run (TRAIN.SWEEP_CONCURRENCY, default 2), not 91 times
+    assert len(loads) == _harness.sweep_concurrency(_finetune.config)
     assert 0.0 <= acc <= 100.0 and info["best_logits"].shape == (12, 4)
     assert os.path.isfile(tmp_path / "out" / "predictions" / "finetuning_full" / "seed0_synthetic.json")
     _harness._BACKBONES.clear()
+
+
+def test_learning_rate_scales_with_the_world_size(tmp_path, monkeypatch):
+    """config/default.py:257,260: ``config.TRAIN.LR *= comm.world_size`` and ``config.RANK = comm.rank`` in update_config -- 1 and 0
+    in every reference run (no process group is ever initialised); under data parallelism the engine averages the ranks' gradients,
+    so the line is the reference's own linear scaling rule for a global batch of world x B."""
+    import argparse
+    from pevit_amd import config as cfgmod
+    y = tmp_path / "m.yaml"
+    y.write_text("TRAIN:\n  LR: 0.01\n")
+    for world, rank in ((1, 0), (8, 3)):
+        monkeypatch.setattr(cfgmod, "distributed_world", lambda w=world, r=rank: (w, r))
+        c = default_config()
+        cfgmod.update_config(c, argparse.Namespace(cfg=str(y), opts=["TRAIN.WD", "0.5"]))
+        assert abs(c.TRAIN.LR - 0.01 * world) < 1e-12 and c.RANK == rank and c.TRAIN.WD == 0.5 and c.is_frozen()
+    assert cfgmod.distributed_world.__module__                         # (the real one: (1, 0) without a process group)
+    monkeypatch.undo()
+    assert cfgmod.distributed_world() == (1, 0)

@@ -33,7 +33,8 @@ LayerNorm outputs, the residual gradient stream -- in bf16 between its kernels, 
 (Compacter's up-projection bias in the top block: a sum over the 8 class-token rows of gradients that have passed BatchNorm's
 zero-sum backward); both sides of the ratio are maxima over 12-24 draws of a heavy-tailed error.  The MEDIAN ratio over the kinds
 of a fixture is asserted at <= 2 next to it: a systematic loss of accuracy fails even when every kind stays under its own gate.
-Where the stated gate is the larger of the two -- KAdaptation, LoRA r = 8, ViT-L/14 bf16 -- it is asserted unwidened.
+The attention-site methods on bf16 weights -- KAdaptation B/32 and L/14, LoRA r = 8 -- take no floor at all: they are held to the
+STATED gates (STATED_ONLY_METHODS); the floor gates the two post-MLP adapters (config 4 among them) and the fp8 weights.
 
 Per-tensor gates stay below 1 (a zero tensor scores 1.0, a permutation 1.4, a sign flip 2.0): a kind whose gate FLOOR_C x floor
 would reach 0.95 (floor >= 0.317) is CHAOTIC at this batch -- the reference with bf16 operands is a third or more away from its own
@@ -47,19 +48,18 @@ gstream_bf16 0 / 1 A/B on the ill-conditioned kinds."""
 import json
 import math
 import os
-import re
 
 import pytest
 import torch
 
-from conftest import load_golden, max_rel, proj_rel_err, rel_err
+from conftest import FLOOR_C, kind_of, load_golden, max_rel, proj_rel_err, reference_floors, rel_err
 
 pytestmark = pytest.mark.gpu
 STATED_LOGITS, STATED_GRADS, LOSS_ABS = 2e-2, 5e-2, 2e-2          # BASELINE.md section 3 (+ the 2-layer loss gate of test_gpu_tower.py)
 PROJ_WIDTH = 1.4                                                  # 32 projections: the estimate of a relative error has sigma ~ 12.5 %
-FLOOR_C = 3.0                                                     # the one constant over the reference-recorded bf16 floor (docstring)
 PER_TENSOR_CAP = 0.95                                             # no per-tensor gate at or above the score of a zero tensor (1.0)
 CHAOTIC_FLOOR = PER_TENSOR_CAP / FLOOR_C                          # 0.317: FLOOR_C x floor would reach the cap -- no per-tensor gate (docstring)
+STATED_ONLY_METHODS = ("kadaptation", "lora")                     # bf16 weights: held to the STATED gates, no floor (B/32 and L/14 KAdaptation, LoRA r = 8)
 MEDIAN_RATIO = 2.0                                                # median over a fixture's tensor kinds of (worst engine error / kind floor)
 
 CASES = [("full_b32_kadaptation_refinit", "bf16"), ("full_b32_lora_r8_refinit", "bf16"), ("full_b32_adapter_refinit", "bf16"),
@@ -171,26 +171,11 @@ def worst(d):
 
 
 def floors(meta, weights):
-    """{quantity: floor} from the fixture: the larger of the reference's two bf16 legs (fp8 engine: its fp8 leg as well); per tensor
-    for the gradient kinds.  The f32 verification mode gets no floor: it is held to the stated gates."""
-    f = meta.get("floor")
-    if not f or weights == "f32-verify":
+    """conftest.reference_floors, except that the f32 verification mode and the attention-site methods on bf16 weights take none
+    (they are held to the stated gates)."""
+    if weights == "f32-verify" or (meta["method"] in STATED_ONLY_METHODS and weights == "bf16"):
         return None
-    legs = [f["weights"], f["operands"]] + ([f["fp8"]] if weights == "fp8" else [])
-    out = {"logits": max(l["logits"] for l in legs), "loss0": max(l["loss0"] for l in legs),
-           "loss_traj": max(max(l["loss_traj"]) for l in legs)}
-    for kind in ("grad", "grad_last", "delta"):
-        out[kind] = {}
-        for l in legs:
-            for n, v in l[kind].items():
-                out[kind][kind_of(n)] = max(out[kind].get(kind_of(n), 0.0), v)
-        out[kind + "_all"] = max(l[kind + "_all"] for l in legs)
-    return out
-
-
-def kind_of(name):
-    """a tensor's kind: its name with the block index replaced by *"""
-    return re.sub(r"resblocks\.\d+\.", "resblocks.*.", name)
+    return reference_floors(meta, fp8=(weights == "fp8"))
 
 
 def whole_step_error(kind, values, meta, t):

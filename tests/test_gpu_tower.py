@@ -19,7 +19,7 @@ within 2.5x of the emulated one.
 import pytest
 import torch
 
-from conftest import golden_param_dict, load_golden, load_tiny_sd, max_rel, rel_err
+from conftest import floor_gate, golden_param_dict, kind_of, load_golden, load_tiny_sd, max_rel, reference_floors, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -275,8 +275,15 @@ def test_full_size_bs8_matches_reference_fixture(case):
     logits, loss = eng.forward_backward(images.cuda(), labels.cuda())
     torch.cuda.synchronize()
     deep = 1.0
-    assert max_rel(logits.cpu(), t["logits0"]) < DEEP_LOGIT_TOL * deep
-    assert abs(float(loss) - float(t["loss0"])) < LOSS_TOL * deep
+    # Round 6: the PARITY gate of every quantity is max(stated gate of BASELINE.md, FLOOR_C x the bf16 floor the reference itself
+    # records in the fixture) -- conftest.reference_floors: the imported reference re-run with bf16 weights / bf16 contraction
+    # operands, no line of this repository in it.  The calibrated figures of rounds 3-5 (DEEP_LOGIT_TOL, PROJ_GRAD_TOL, ...) stay
+    # next to it as regression bounds: whichever is tighter binds.
+    fl = reference_floors(meta)
+    assert fl is not None, "fixture without a reference-recorded floor: tests/golden/make_golden.py --floor-random"
+    logit_err = max_rel(logits.cpu(), t["logits0"])
+    assert logit_err < min(DEEP_LOGIT_TOL * deep, floor_gate(2e-2, fl["logits"])), (logit_err, fl["logits"])
+    assert abs(float(loss) - float(t["loss0"])) < min(LOSS_TOL * deep, floor_gate(2e-2, fl["loss0"]))
     bad, proj_errs = [], {}
     for name, gten in eng.grad_views().items():
         key = name if name.startswith("layers.") else "backbone." + name
@@ -298,6 +305,18 @@ def test_full_size_bs8_matches_reference_fixture(case):
     worst_p = max(proj_errs.items(), key=lambda kv: kv[1]) if proj_errs else ("-", 0.0)
     print(f"projection-estimated gradient errors {case}: worst {worst_p[1]:.3e} ({worst_p[0]}), mean {sum(proj_errs.values()) / max(len(proj_errs), 1):.3e}")
     assert worst_p[1] < PROJ_GRAD_TOL, worst_p
+    # ... and per tensor against the floor of its KIND (x 1.4: the 3-sigma sampling width of 32 projections), capped below the score of
+    # a zero tensor; the ratio to the floor is printed for profiles/r06_parity_refinit.md
+    ratios = {}
+    for name, e in proj_errs.items():
+        k = kind_of(name if name.startswith("layers.") else "backbone." + name)
+        f = fl["grad"].get(k, 0.0)
+        assert e < 1.4 * floor_gate(5e-2, f, cap=0.68), (name, e, f)            # 1.4 x 0.68 = 0.95
+        if f > 0:
+            ratios[k] = max(ratios.get(k, 0.0), e / f)
+    rs = sorted(ratios.values())
+    print(f"floor ratios {case}: logits {logit_err:.3e} / floor {fl['logits']:.3e} = {logit_err / max(fl['logits'], 1e-12):.2f}; "
+          f"gradient kinds: median {rs[len(rs) // 2] if rs else 0:.2f}, max {rs[-1] if rs else 0:.2f} (estimated from projections)")
     # the recorded SGD trajectory (full_b32_*: two steps): loss of the second step and the norm of every trained tensor after it
     if len(meta["losses"]) > 1:
         eng.sgd_step(meta["lr"], 0.9, meta["wd"])
@@ -314,7 +333,7 @@ def test_full_size_bs8_matches_reference_fixture(case):
             if e > worst[1]:
                 worst = (name, e)
         print(f"trajectory {case}: |loss_{len(meta['losses']) - 1} - ref| = {dl:.3e}, worst final-norm deviation {worst[1]:.3e} ({worst[0]})")
-        assert dl < TRAJ_LOSS_TOL, dl
+        assert dl < min(TRAJ_LOSS_TOL, floor_gate(2e-2, fl["loss_traj_steps"][-1])), (dl, fl["loss_traj_steps"])
         assert worst[1] < TRAJ_NORM_TOL, worst
 
 
@@ -532,6 +551,48 @@ def test_dp_bucketed_step_equals_fused_step_on_one_rank():
             eng_b.sgd_step(0.01, 0.9, 1e-4, 1.0)
             assert torch.equal(la, lb) and lossa == float(eng_b._loss)
         assert torch.equal(eng_a.params, eng_b.params) and torch.equal(eng_a.running_mean, eng_b.running_mean)
+    finally:
+        if own_group:
+            dist.destroy_process_group()
+
+
+def test_state_reads_right_behind_a_pipelined_step_see_the_finished_update():
+    """in the pipelined DP schedule the all-reduce and the SGD kernel of step N still run on a second stream when
+    train_step returns.  Everything that reads or writes the trainable state afterwards -- param_views() (state export /
+    checkpoint), grad_views(), reset_optimizer(), a direct sgd_step(), transformer_forward, head_forward_backward, load_trainable --
+    first makes the current stream wait for that update (dp_flush): read right behind a pipelined step, without a synchronize, the
+    parameters equal those of the single-exchange schedule bit for bit."""
+    import os
+    import torch.distributed as dist
+    meta, t = load_golden("tiny_kadaptation")
+    images, labels = t["images"].cuda(), t["labels"].cuda()
+    eng_a, _ = make_engine(meta, t)
+    eng_b, _ = make_engine(meta, t)
+    own_group = not dist.is_initialized()
+    if own_group:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29534")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        for step in range(4):
+            eng_a.forward_backward_dp(images, labels, mode="single"); eng_a.sgd_step(0.01, 0.9, 1e-4, 1.0)
+            eng_b._train_step_pipelined(images, labels, 0.01, 0.9, 1e-4, True, None, 1, False, None, None)
+            got = {n: v.clone() for n, v in eng_b.param_views().items()}          # no synchronize, no explicit flush
+            want = eng_a.param_views()
+            assert all(torch.equal(got[n], want[n]) for n in want), step
+        assert eng_b._pipe is not None and not eng_b._pipe["open"]                 # the read flushed
+        eng_b._train_step_pipelined(images, labels, 0.01, 0.9, 1e-4, True, None, 1, False, None, None)
+        eng_a.forward_backward_dp(images, labels, mode="single"); eng_a.sgd_step(0.01, 0.9, 1e-4, 1.0)
+        eng_b.sgd_step(0.01, 0.9, 1e-4, 1.0); eng_a.sgd_step(0.01, 0.9, 1e-4, 1.0)   # a direct step behind a pipelined one waits for it
+        assert torch.equal(eng_a.params, eng_b.params) and torch.equal(eng_a.momentum, eng_b.momentum)
+        eng_b._train_step_pipelined(images, labels, 0.01, 0.9, 1e-4, True, None, 1, False, None, None)
+        eng_b.reset_optimizer()                                                    # ... and so does clearing the momentum
+        torch.cuda.synchronize()
+        assert float(eng_b.momentum.abs().max()) == 0.0
+        # capture leaves the pipelined schedule altogether (the step gate must not be baked into the graph)
+        eng_b._train_step_pipelined(images, labels, 0.01, 0.9, 1e-4, True, None, 1, False, None, None)
+        replay = eng_b.capture_train_step(images, labels, lr=0.01, momentum=0.9, weight_decay=1e-4)
+        assert eng_b._pipe is None
+        replay(); torch.cuda.synchronize()
     finally:
         if own_group:
             dist.destroy_process_group()
