@@ -8,3 +8,4 @@ tail -1 gpurun_out/pmc_$R/bench_line.json > profiles/${R}_bench_line.json
 cp gpurun_out/pmc_$R/mfma_util.md profiles/${R}_mfma_utilisation.md
 cp gpurun_out/pmc_$R/traffic.txt profiles/${R}_pmc_hbm_traffic.txt
 cp gpurun_out/${R}_other_configs.jsonl gpurun_out/${R}_other_configs.md profiles/ 2>/dev/null
+cp gpurun_out/pmc_$R/step_timeline.md profiles/${R}_step_timeline.md 2>/dev/null

@@ -6,7 +6,7 @@
 set -x
 export TMPDIR=/tmp
 R=$PWD
-TAG=${1:-r04}
+TAG=${1:-r06}
 O=$R/gpurun_out/pmc_$TAG
 rm -rf $O; mkdir -p $O/fetch $O/write $O/ktrace $O/mfma
 cd /tmp
@@ -20,5 +20,6 @@ python scripts/pmc_traffic.py $F $W "ViT-B/32|kadaptation|bs128" profiles/hbm_tr
 cp profiles/hbm_traffic.json $R/gpurun_out/hbm_traffic.json     # profiles/ does not travel back from the GPU box: copy it from gpurun_out/
 python scripts/prof_summary.py $K 55 > $O/kernel_stats.md 2>&1
 python scripts/pmc_mfma.py $M > $O/mfma_util.md 2>&1
+python scripts/r6_step_timeline.py $K > $O/step_timeline.md 2>&1
 python bench.py --strict-traffic > $O/bench_line.json 2>$O/bench_err.log
 tail -3 $O/traffic.txt; head -12 $O/mfma_util.md; head -8 $O/kernel_stats.md; cut -c1-900 $O/bench_line.json

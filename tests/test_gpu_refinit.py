@@ -25,14 +25,14 @@ gradient arriving at its output rounded to bf16, i.e. what ANY engine that feeds
 the deviation from the reference's own f32 run (ViT-L/14 also leg "fp8": e4m3 block weights, BASELINE config 5).  No line of this
 repository's engine, oracle or emulation enters the floor.  For a gradient tensor the floor is that of its KIND -- the name with
 the block index replaced by *, the largest value over the blocks and legs: one tensor's floor is a single draw of an
-ill-conditioned sum (measured engine / own-tensor floor 0.3-6.6, engine / kind floor 0.35-2.7).
+ill-conditioned sum (measured engine / own-tensor floor 0.3-6.6, engine / kind floor 0.35-1.8).
 
-Why 3: measured over every tensor kind of the five fixtures (profiles/r06_parity_refinit.md) the worst tensor of a kind sits at
-1.0-2.0 x the kind's floor with a median of 1.4 (the engine also STORES activations -- q / k / v, the attention output, h,
-LayerNorm outputs, the residual gradient stream -- in bf16 between its kernels, which the floor legs do not), one kind at 2.7
-(Compacter's up-projection bias in the top block: a sum over the 8 class-token rows of gradients that have passed BatchNorm's
-zero-sum backward); both sides of the ratio are maxima over 12-24 draws of a heavy-tailed error.  The MEDIAN ratio over the kinds
-of a fixture is asserted at <= 2 next to it: a systematic loss of accuracy fails even when every kind stays under its own gate.
+Why 3: measured over every tensor kind of the fixtures (profiles/r06_parity_refinit.md) the worst tensor of a kind sits at
+0.8-1.8 x the kind's floor, median 1.0-1.4 per fixture, whole-step vectors at 0.8-1.35, the five-step loss trajectory of Compacter at
+2.4 (the engine also STORES activations -- q / k / v, the attention output, h, LayerNorm outputs, the residual gradient stream -- in
+bf16 between its kernels, which the floor legs do not, and a trajectory accumulates it); both sides of a per-kind ratio are maxima
+over 12-24 draws of a heavy-tailed error.  The MEDIAN ratio over the kinds of a fixture is asserted at <= 2 next to it: a
+systematic loss of accuracy fails even when every kind stays under its own gate.
 The attention-site methods on bf16 weights -- KAdaptation B/32 and L/14, LoRA r = 8 -- take no floor at all: they are held to the
 STATED gates (STATED_ONLY_METHODS); the floor gates the two post-MLP adapters (config 4 among them) and the fp8 weights.
 
