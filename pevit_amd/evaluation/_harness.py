@@ -141,6 +141,8 @@ _RUN = threading.local()
 
 
 class _Turns:
+    TIMEOUT_S = 900
+
     def __init__(self, k):
         self.cv, self.done, self.finished = threading.Condition(), [0] * k, [False] * k
 
@@ -148,8 +150,10 @@ class _Turns:
     def ordered(self, r):
         with self.cv:
             n = self.done[r]
-            self.cv.wait_for(lambda: all(self.finished[j] or self.done[j] > n for j in range(r)) and
-                             all(self.finished[j] or self.done[j] >= n for j in range(r + 1, len(self.done))))
+            ok = self.cv.wait_for(lambda: all(self.finished[j] or self.done[j] > n for j in range(r)) and
+                                  all(self.finished[j] or self.done[j] >= n for j in range(r + 1, len(self.done))), timeout=self.TIMEOUT_S)
+            if not ok:               # a peer is stuck: fail this run loudly (it scores None) instead of hanging the sweep
+                raise RuntimeError(f"concurrent sweep: run {r} waited {self.TIMEOUT_S} s for its turn at ordered section {n}")
         try:
             yield
         finally:
