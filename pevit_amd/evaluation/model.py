@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import math
 import os
+import threading
 import weakref
 from collections import OrderedDict
 
@@ -107,6 +108,7 @@ class _EngineCache:
 
     def __init__(self):
         self._items = []          # (key, engine, weakref-to-owner)
+        self._lock = threading.Lock()      # the runs of a concurrent sweep (evaluation/_harness.py run_tasks) bind their engines from worker threads
 
     @staticmethod
     def _key(visual, device, num_classes):
@@ -117,20 +119,23 @@ class _EngineCache:
         key = self._key(visual, device, num_classes)
         if key is None:
             return None
-        for i, (k, e, w) in enumerate(self._items):
-            if k == key and w() is None:
-                self._items[i] = (k, e, weakref.ref(visual))
-                return e
+        with self._lock:
+            for i, (k, e, w) in enumerate(self._items):
+                if k == key and w() is None:
+                    self._items[i] = (k, e, weakref.ref(visual))      # owned from here on: a second thread cannot be handed the same engine
+                    return e
         return None
 
     def register(self, visual, eng):
         key = self._key(visual, eng.device, eng.num_classes)
         if key is not None:
-            self._items = [(k, e, w) for k, e, w in self._items if w() is not None][-3:]   # bound resident engines
-            self._items.append((key, eng, weakref.ref(visual)))
+            with self._lock:
+                self._items = [(k, e, w) for k, e, w in self._items if w() is not None][-3:]   # bound resident engines
+                self._items.append((key, eng, weakref.ref(visual)))
 
     def clear(self):
-        self._items.clear()
+        with self._lock:
+            self._items.clear()
 
 
 _ENGINES = _EngineCache()
