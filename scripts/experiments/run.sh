@@ -20,7 +20,11 @@ O=gpurun_out/$TAG; mkdir -p $O
 n=0
 for step in "$@"; do
   n=$((n + 1))
-  eval "set -- $step"          # (inner quotes of a step survive: "tests -k 'a or b'")
+  if [ "${step%% *}" = "sh" ]; then       # a raw command line (may hold ; | and quotes): taken verbatim
+    set -- sh "${step#sh }"
+  else
+    eval "set -- $step"        # (inner quotes of a step survive: "tests -k 'a or b'")
+  fi
   verb=$1; shift
   echo "=== [$TAG $n] $verb $*"
   case $verb in
@@ -32,7 +36,7 @@ for step in "$@"; do
     variants) timeout ${STEP_TIMEOUT:-1800} bash scripts/gpu_variants.sh "$@" 2>&1 | tee $O/variants_$n.log ;;
     pmc)      timeout ${STEP_TIMEOUT:-2400} bash scripts/run_pmc_passes.sh "$@" 2>&1 | tail -60 | tee $O/pmc_$n.log ;;
     py)       timeout ${STEP_TIMEOUT:-900} python "$@" > $O/py_$n.log 2>&1; echo "rc=$?" >> $O/py_$n.log; tail -${TAIL:-20} $O/py_$n.log ;;
-    sh)       timeout ${STEP_TIMEOUT:-900} bash -c "$*" > $O/sh_$n.log 2>&1; echo "rc=$?" >> $O/sh_$n.log; tail -${TAIL:-20} $O/sh_$n.log ;;
+    sh)       timeout ${STEP_TIMEOUT:-900} bash -c "$1" > $O/sh_$n.log 2>&1; echo "rc=$?" >> $O/sh_$n.log; tail -${TAIL:-20} $O/sh_$n.log ;;
     *)        echo "unknown verb $verb"; exit 2 ;;
   esac
 done
