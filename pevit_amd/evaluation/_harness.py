@@ -193,6 +193,8 @@ def run_tasks(train_task_fn, train_dataloader, val_dataloader, config, wds, k):
             gpu_gc()
             return None
 
+    if any(getattr(dl, "persistent_workers", False) for dl in (train_dataloader, val_dataloader)):
+        k = 1                                    # such a loader has ONE live iterator: two runs cannot walk it at the same time
     if k <= 1 or len(wds) <= 1:
         return [one(config, wd) for wd in wds]
     scores = [None] * len(wds)

@@ -101,3 +101,19 @@ def test_flush_helper_and_the_dp_schedule_option(monkeypatch, capsys):
     with pytest.raises(SystemExit):
         bench.main()
     assert "--dp-exchange" in seen["cmd"] and "staged" in seen["cmd"]
+
+
+@pytest.mark.gpu
+def test_concurrent_runs_side_measurement_is_bit_identical_to_solo_runs():
+    """bench.py's `concurrent_runs` object (round 6): K engine contexts on K streams at batch 64 (K = 1, 2, 3) and 128 (K = 1, 2);
+    the aggregate rate per K and -- what makes the figure mean anything -- every concurrent run bit-identical to the same run alone."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from pevit_amd.synth import ARCHS, synth_state_dict
+    bench = _bench()
+    arch = ARCHS["tiny-256"]
+    out = bench.concurrent_runs_throughput(torch.device("cuda", 0), synth_state_dict(arch, seed=2, text_tower=False), arch, steps=6)
+    for bs, ks in (("bs64", ("1", "2", "3")), ("bs128", ("1", "2"))):
+        assert out[bs]["bit_identical_to_solo"] is True
+        assert tuple(out[bs]["aggregate_images_per_sec_by_runs"]) == ks and all(v > 0 for v in out[bs]["aggregate_images_per_sec_by_runs"].values())
